@@ -1,0 +1,57 @@
+"""Pins oracle/emavfi_oracle.py to vectors captured from the reference's own
+EMA_VFI.forward (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from emavfi import synth
+from oracle import emavfi_oracle as oracle
+
+STAGES = ("feat", "ctx", "flow", "warped", "fused_0", "fused_1", "fused_2", "out")
+
+
+@pytest.mark.parametrize("name", ["tiny_mid8_24x40.npz", "tiny_mid8_23x37.npz"])
+def test_tiny_every_stage(name):
+    g = load_golden(name)
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    # the committed weights are exactly what the hash generator produces
+    regen = synth.synthetic_state_dict(seed=11 if "24x40" in name else 12, mid_channels=8)
+    for k, v in regen.items():
+        assert torch.equal(v, sd[k]), k
+    taps = {}
+    oracle.forward(sd, torch.from_numpy(g["frame1"]), torch.from_numpy(g["frame2"]), taps=taps)
+    for k in STAGES:
+        assert np.abs(taps[k].numpy() - g["tap." + k]).max() <= 1e-5, k
+    # channel routing of the pack (ema_vfi.py:57-59) against the hooked raw offset_conv output
+    for i in range(3):
+        raw = torch.from_numpy(g[f"tap.raw_{i}"])
+        assert torch.allclose(taps[f"offset_{i}"], torch.cat([raw[:, 0:9], raw[:, 18:27]], 1), atol=1e-5)
+        assert torch.allclose(taps[f"mask_{i}"], torch.sigmoid(raw[:, 9:18]), atol=1e-6)
+
+
+def test_config1_rubberwhale_crop():
+    """BASELINE.json configs[0]: one 256x256 Middlebury triplet through the CPU forward."""
+    g = load_golden("cfg1_rubberwhale_256.npz")
+    u8 = g["triplet_u8"]
+    f1, f2 = synth._to_model_range(u8[0:1]), synth._to_model_range(u8[2:3])
+    assert f1.min() >= -2.12 and f1.max() <= 2.65
+    taps = {}
+    out = oracle.forward(synth.synthetic_state_dict(seed=0), f1, f2, taps=taps)
+    assert np.abs(out.numpy() - g["out"]).max() <= 1e-5
+    assert np.abs(taps["flow"].numpy() - g["flow"]).max() <= 1e-4
+    for k in STAGES:
+        t = taps[k].double()
+        got = np.array([t.mean().item(), t.pow(2).sum().sqrt().item(), t.abs().max().item()])
+        assert np.allclose(got, g["stats." + k], rtol=1e-5, atol=1e-6), k
+
+
+def test_large_256_stress_samples():
+    g = load_golden("large_checks.npz")
+    B, H, W, seed, kind = (int(v) for v in g["256s.meta"])
+    f1, f2 = synth.synthetic_frames(seed, B, H, W, "stress" if kind else "natural")
+    taps = {}
+    oracle.forward(synth.synthetic_state_dict(seed=0), f1, f2, taps=taps)
+    for k in STAGES:
+        got = taps[k].contiguous().view(-1)[torch.from_numpy(g[f"256s.pos.{k}"])].numpy()
+        assert np.abs(got - g[f"256s.val.{k}"]).max() <= 2e-5 * max(1.0, np.abs(got).max()), k
