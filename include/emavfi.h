@@ -1,0 +1,122 @@
+/*
+ * emavfi.h - C-ABI of libemavfi.so, the MI355X-native (gfx950) EMA-VFI
+ * inference path.
+ *
+ * The reference (424635328/video-frame-interpolation) has no FFI layer: its hot
+ * path is the Python class EMA_VFI in src/models/ema_vfi.py, whose work is done
+ * by torch / torchvision operators.  Each entry below replaces the operator
+ * call sites cited next to it.  The Python mirror of the reference class
+ * (video-frame-interpolation_amd/emavfi/model.py) binds these with ctypes; see
+ * INTEGRATION.md for the stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer on the current HIP device, 16-byte
+ *    aligned, to a dense tensor.  Image tensors crossing this boundary are
+ *    NCHW fp32, exactly what the reference's forward() receives and returns.
+ *  - The library never allocates, frees or retains device memory and never
+ *    synchronises the device: the caller owns inputs, outputs, the packed
+ *    weight blob and the workspace (sized by the *_bytes queries) and all work
+ *    is enqueued on the hipStream_t passed as `stream` (void* here so the
+ *    header needs no HIP include; NULL = the default stream).
+ *  - Every int-returning entry returns 0 on success and a negative EMAVFI_E_*
+ *    code on failure; emavfi_last_error() then holds a thread-local message.
+ *    Nothing aborts the process (the reference wraps its loop in try/except,
+ *    inference.py:207-208).
+ *  - `dtype` selects the arithmetic of the contractions: EMAVFI_F32 computes
+ *    every convolution with fp32-input MFMA (exact fp32 FMA chains; this is the
+ *    parity mode, <= 1e-3 max-abs vs the reference's CPU forward);
+ *    EMAVFI_BF16 stores activations and weights in bf16 and accumulates in
+ *    fp32 (BASELINE.json configs[2]: "bf16 convs + fp32 warp").  Flow, warp
+ *    coordinates, deformable offsets / masks / bilinear weights, the pooled
+ *    context vector and the output are fp32 in both modes.
+ *  - The model is identified by the reference constructor's three integers
+ *    (ema_vfi.py:64): in_channels, mid_channels, num_blocks.
+ */
+#ifndef EMAVFI_H
+#define EMAVFI_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMAVFI_VERSION 100 /* 0.1.0 */
+
+#define EMAVFI_F32 0
+#define EMAVFI_BF16 1
+
+#define EMAVFI_OK 0
+#define EMAVFI_E_ARG (-1)         /* bad shape / dtype / null pointer / misaligned pointer */
+#define EMAVFI_E_UNSUPPORTED (-2) /* model widths this build has no kernel instantiation for */
+#define EMAVFI_E_WORKSPACE (-3)   /* workspace or packed buffer too small */
+#define EMAVFI_E_LAUNCH (-4)      /* hipGetLastError() after a launch */
+
+/* Activation selector of emavfi_conv3x3 (conv vs conv_block, ema_vfi.py:7-14). */
+#define EMAVFI_ACT_NONE 0
+#define EMAVFI_ACT_RELU 1
+#define EMAVFI_ACT_TANH01 2 /* tanh then (t+1)/2: reconstruction tail, ema_vfi.py:106,146 */
+
+int emavfi_version(void);
+const char *emavfi_last_error(void);
+
+/* 0 if (in_channels, mid_channels, num_blocks, dtype) has kernels in this build. */
+int emavfi_supported(int in_channels, int mid_channels, int num_blocks, int dtype);
+
+/* Number of tensors in the reference state_dict (ema_vfi.py:63-107): 16 + 8*num_blocks... see
+ * emavfi_param_count(); order = the reference's registration order:
+ *   feat_ext_conv1.0.{weight,bias}; feat_ext_blocks.conv_block_i.0.{w,b} (i < num_blocks);
+ *   context_encoding.{0.0,1.0,2.0}.{w,b}; context_encoding.5.{w,b};
+ *   motion_estimation.{0.0,1.0,2}.{w,b};
+ *   attention_blocks.i.offset_conv.{w,b}, attention_blocks.i.dcn_v2.{w,b} (i < num_blocks);
+ *   reconstruction.{0.0,1.0,2}.{w,b}. */
+int emavfi_param_count(int num_blocks);
+
+/* Re-pack the fp32 OIHW parameters into the MFMA fragment order the kernels stream
+ * (replaces nothing in the reference: torch keeps OIHW; this runs once after
+ * load_state_dict, inference.py:69).  `params[i]` are device pointers in the order above. */
+size_t emavfi_packed_bytes(int in_channels, int mid_channels, int num_blocks, int dtype);
+int emavfi_pack_weights(int in_channels, int mid_channels, int num_blocks,
+                        const void *const *params, int n_params,
+                        void *packed, size_t packed_bytes, int dtype, void *stream);
+
+/* EMA_VFI.forward(frame1, frame2) -> out, ema_vfi.py:110-147.
+ * frame1, frame2: [B, in_channels, H, W] fp32; out: [B, in_channels, H, W] fp32 in [0,1].
+ * `taps` is NULL, or 5 + num_blocks device pointers (any may be NULL) that receive NCHW fp32
+ * copies of the intermediates the golden vectors hold:
+ *   [0] feat [B,mid,H,W]  [1] ctx [B,mid]  [2] flow [B,2,H,W]  [3] warped [B,in_channels,H,W]
+ *   [4] reserved  [5+i] output of attention block i [B,mid+3,H,W]. */
+size_t emavfi_workspace_bytes(int in_channels, int mid_channels, int num_blocks,
+                              int B, int H, int W, int dtype);
+int emavfi_forward(int in_channels, int mid_channels, int num_blocks, const void *packed,
+                   const float *frame1, const float *frame2, float *out,
+                   void *workspace, size_t workspace_bytes,
+                   int B, int H, int W, int dtype, float *const *taps, void *stream);
+
+/* EMA_VFI.warp(frame2, feature, flow), ema_vfi.py:149-171 (grid build + normalise +
+ * F.grid_sample bilinear/zeros/align_corners=True), fused into one HBM-bound kernel.
+ * frame2 [B,C,H,W], flow [B,2,H,W] (channel 0 = dx, 1 = dy, pixels), out [B,C,H,W]; fp32. */
+int emavfi_warp(const float *frame2, const float *flow, float *out,
+                int B, int C, int H, int W, void *stream);
+
+/* One conv / conv_block (ema_vfi.py:7-14): Conv2d(k=3, p=1, stride 1 or 2) + activation.
+ * x [B,Cin,H,W], weight [Cout,Cin,3,3], bias [Cout], y [B,Cout,ceil(H/stride),ceil(W/stride)]. */
+size_t emavfi_conv3x3_workspace_bytes(int B, int Cin, int Cout, int H, int W, int stride, int dtype);
+int emavfi_conv3x3(const float *x, const float *weight, const float *bias, float *y,
+                   int B, int Cin, int Cout, int H, int W, int stride, int act, int dtype,
+                   void *workspace, size_t workspace_bytes, void *stream);
+
+/* torchvision.ops.deform_conv2d(x, offset, weight, bias, padding=1, mask=mask) as configured
+ * at ema_vfi.py:45-51 / :60 (3x3, stride 1, pad 1, one offset group, one weight group).
+ * x [B,C,H,W], offset [B,18,H,W] (2k = dy, 2k+1 = dx of tap k = 3i+j), mask [B,9,H,W],
+ * weight [O,C,3,3], bias [O], y [B,O,H,W]. */
+size_t emavfi_deform_conv2d_workspace_bytes(int B, int C, int O, int H, int W, int dtype);
+int emavfi_deform_conv2d(const float *x, const float *offset, const float *mask,
+                         const float *weight, const float *bias, float *y,
+                         int B, int C, int O, int H, int W, int dtype,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMAVFI_H */

@@ -1,0 +1,271 @@
+"""Parity tests proper: the HIP path, called through the C-ABI (ctypes, emavfi/lib.py), against
+the CPU oracle and the golden vectors captured from the reference's forward().
+
+Tolerances.  fp32 mode (exact-fp32 MFMA): BASELINE.json asks <= 1e-3 max-abs on the output;
+intermediates are held to 2e-4 * max|ref| (summation order differs from MKLDNN's).
+bf16 mode (BASELINE configs[2]): PSNR of the output vs the fp32 oracle, threshold in the test."""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+from emavfi import EMA_VFI, lib, synth
+from oracle import emavfi_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+STAGES = ("feat", "ctx", "flow", "warped", "fused_0", "fused_1", "fused_2", "out")
+
+
+def rel_err(got, ref):
+    return (got - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+
+
+def psnr(got, ref):
+    mse = (got.double() - ref.double()).pow(2).mean().item()
+    return 99.0 if mse == 0 else 10.0 * math.log10(1.0 / mse)
+
+
+def make_model(sd, mid=64, dtype="fp32"):
+    m = EMA_VFI(mid_channels=mid, compute_dtype=dtype).to(DEV).eval()
+    m.load_state_dict(sd, strict=True)
+    return m
+
+
+# ------------------------------------------------------------------ warp (row W)
+@pytest.mark.parametrize("B,C,H,W,sigma", [(2, 3, 17, 23, 1.0), (1, 3, 64, 48, 5.0), (2, 3, 33, 128, 40.0),
+                                           (1, 3, 1, 9, 2.0), (1, 3, 9, 1, 2.0), (1, 3, 1, 1, 0.3), (1, 1, 8, 12, 3.0),
+                                           (1, 3, 720, 1280, 6.0)])
+def test_warp_matches_oracle(B, C, H, W, sigma):
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    f2 = torch.randn(B, C, H, W, generator=g)
+    flow = torch.randn(B, 2, H, W, generator=g) * sigma
+    got = lib.warp(f2.to(DEV), flow.to(DEV)).cpu()
+    ref = oracle.warp(f2, flow)
+    assert (got - ref).abs().max().item() <= 5e-6 * max(1.0, ref.abs().max().item())
+
+
+def test_warp_far_and_nonfinite_flow_is_zero():
+    f2 = torch.randn(1, 3, 8, 8)
+    flow = torch.zeros(1, 2, 8, 8)
+    flow[0, 0, 4, 4], flow[0, 1, 5, 5] = 1e9, -300.0
+    flow[0, 0, 2, 2], flow[0, 1, 3, 3] = float("nan"), float("inf")
+    got = lib.warp(f2.to(DEV), flow.to(DEV)).cpu()
+    for y, x in ((4, 4), (5, 5), (2, 2), (3, 3)):
+        assert torch.all(got[0, :, y, x] == 0)
+    assert torch.allclose(got[0, :, 0, 0], f2[0, :, 0, 0], atol=1e-5)
+
+
+def test_model_warp_method_signature():
+    m = EMA_VFI(mid_channels=8).to(DEV)
+    f2, flow = torch.randn(1, 3, 12, 20), torch.randn(1, 2, 12, 20) * 2
+    got = m.warp(f2.to(DEV), torch.zeros(1, device=DEV), flow.to(DEV)).cpu()
+    assert torch.allclose(got, oracle.warp(f2, flow), atol=1e-5)
+
+
+# ------------------------------------------------------------------ conv3x3 (row C)
+CONV_CASES = [  # (Cin, Cout, H, W, stride, act): one per reference layer shape + ragged sizes
+    (6, 64, 40, 72, 1, 1), (64, 64, 24, 40, 1, 1), (64, 128, 33, 47, 2, 1), (128, 256, 18, 34, 2, 1),
+    (256, 256, 9, 21, 1, 1), (64, 2, 19, 33, 1, 0), (67, 27, 16, 35, 1, 0), (67, 64, 17, 64, 1, 1),
+    (64, 32, 8, 32, 1, 1), (32, 3, 21, 45, 1, 2), (8, 8, 23, 37, 1, 1), (8, 16, 23, 37, 2, 1),
+    (11, 27, 5, 7, 1, 0), (35, 32, 12, 33, 1, 1), (3, 5, 1, 1, 1, 0), (16, 16, 1, 70, 1, 1), (16, 32, 70, 1, 2, 1),
+]
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3x3_matches_aten(case, dtype, tol):
+    Cin, Cout, H, W, stride, act = case
+    g = torch.Generator().manual_seed(Cin * 131 + Cout)
+    x = torch.randn(2, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g) * 0.1
+    got = lib.conv3x3(x.to(DEV), w.to(DEV), b.to(DEV), stride=stride, act=act, dtype=dtype).cpu()
+    ref = F.conv2d(x, w, b, stride=stride, padding=1)
+    ref = F.relu(ref) if act == 1 else ((torch.tanh(ref) + 1) / 2 if act == 2 else ref)
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) <= tol
+
+
+# ------------------------------------------------------------------ deformable conv (rows O, D)
+@pytest.mark.parametrize("dtype,tol", [("fp32", 3e-5), ("bf16", 3e-2)])
+@pytest.mark.parametrize("C,O,H,W,spread", [(67, 67, 19, 41, 2.0), (67, 67, 8, 32, 12.0), (11, 11, 23, 37, 1.5),
+                                            (5, 7, 1, 1, 1.0), (19, 19, 9, 33, 3.0), (35, 35, 16, 16, 2.0)])
+def test_deform_conv2d_matches_oracle(C, O, H, W, spread, dtype, tol):
+    g = torch.Generator().manual_seed(C * 7 + H)
+    x = torch.randn(2, C, H, W, generator=g)
+    off = torch.randn(2, 18, H, W, generator=g) * spread
+    msk = torch.rand(2, 9, H, W, generator=g)
+    w = torch.randn(O, C, 3, 3, generator=g) / math.sqrt(C * 9)
+    b = torch.randn(O, generator=g) * 0.1
+    got = lib.deform_conv2d(x.to(DEV), off.to(DEV), msk.to(DEV), w.to(DEV), b.to(DEV), dtype=dtype).cpu()
+    ref = oracle.deform_conv2d(x, off, msk, w, b)
+    assert rel_err(got, ref) <= tol
+
+
+def test_deform_known_answers_on_gpu():
+    """The same clauses that pin the oracle (tests/test_oracle_deform.py), replayed on the HIP kernel."""
+    x = torch.randn(1, 3, 10, 12)
+    w = torch.randn(2, 3, 3, 3)
+    zero_off, ones = torch.zeros(1, 18, 10, 12), torch.ones(1, 9, 10, 12)
+    got = lib.deform_conv2d(x.to(DEV), zero_off.to(DEV), ones.to(DEV), w.to(DEV), None).cpu()
+    assert torch.allclose(got, F.conv2d(x, w, None, padding=1), atol=2e-5)
+    xo = torch.ones(1, 1, 6, 6)
+    wc = torch.zeros(1, 1, 3, 3)
+    wc[0, 0, 1, 1] = 1.0
+    for dy, y, want in ((-0.25, 0, 0.75), (-1.0, 0, 0.0), (0.5, 5, 0.5), (1.0, 5, 0.0)):
+        off = torch.zeros(1, 18, 6, 6)
+        off[:, 8] = dy
+        v = lib.deform_conv2d(xo.to(DEV), off.to(DEV), torch.ones(1, 9, 6, 6).to(DEV), wc.to(DEV), None).cpu()[0, 0, y, 3]
+        assert abs(v.item() - want) <= 1e-6, (dy, y, v.item())
+
+
+def test_pack_module_matches_oracle_block():
+    sd = synth.synthetic_state_dict(seed=4, mid_channels=8)
+    m = make_model(sd, mid=8)
+    x = torch.randn(1, 11, 14, 33)
+    got = m.attention_blocks[1](x.to(DEV)).cpu()
+    assert rel_err(got, oracle.attention_block(sd, 1, x)) <= 5e-5
+
+
+# ------------------------------------------------------------------ full forward (row T)
+@pytest.mark.parametrize("name", ["tiny_mid8_24x40.npz", "tiny_mid8_23x37.npz"])
+def test_forward_tiny_golden_every_stage(name):
+    g = load_golden(name)
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    m = make_model(sd, mid=8)
+    with torch.no_grad():
+        out, taps = m(torch.from_numpy(g["frame1"]).to(DEV), torch.from_numpy(g["frame2"]).to(DEV), return_taps=True)
+    for k in STAGES:
+        ref = torch.from_numpy(g["tap." + k])
+        assert rel_err(taps[k].cpu(), ref) <= 2e-4, k
+    assert (out.cpu() - torch.from_numpy(g["tap.out"])).abs().max().item() <= 1e-3
+
+
+def test_forward_config1_rubberwhale():
+    """BASELINE.json configs[0] input, replayed on the GPU against the reference-run output."""
+    g = load_golden("cfg1_rubberwhale_256.npz")
+    u8 = g["triplet_u8"]
+    f1, f2 = synth._to_model_range(u8[0:1]), synth._to_model_range(u8[2:3])
+    m = make_model(synth.synthetic_state_dict(seed=0))
+    with torch.no_grad():
+        out, taps = m(f1.to(DEV), f2.to(DEV), return_taps=True)
+    err = (out.cpu() - torch.from_numpy(g["out"])).abs().max().item()
+    assert err <= 1e-3, err
+    assert (taps["flow"].cpu() - torch.from_numpy(g["flow"])).abs().max().item() <= 2e-3
+    assert out.min().item() >= 0.0 and out.max().item() <= 1.0
+
+
+@pytest.mark.parametrize("tag", ["256", "256s", "720"])
+def test_forward_large_samples_vs_reference_run(tag):
+    """mid=64 at 256x256 (natural, stress) and 1280x720: sampled pixels of every stage recorded
+    from the reference's forward (tests/golden/large_checks.npz)."""
+    g = load_golden("large_checks.npz")
+    B, H, W, seed, kind = (int(v) for v in g[f"{tag}.meta"])
+    f1, f2 = synth.synthetic_frames(seed, B, H, W, "stress" if kind else "natural")
+    m = make_model(synth.synthetic_state_dict(seed=0))
+    with torch.no_grad():
+        out, taps = m(f1.to(DEV), f2.to(DEV), return_taps=True)
+    for k in STAGES:
+        got = taps[k].contiguous().view(-1).cpu()[torch.from_numpy(g[f"{tag}.pos.{k}"])]
+        ref = torch.from_numpy(g[f"{tag}.val.{k}"])
+        lim = 1e-3 if k == "out" else 5e-4 * max(1.0, ref.abs().max().item())
+        assert (got - ref).abs().max().item() <= lim, (k, (got - ref).abs().max().item())
+        mean, l2, amax = g[f"{tag}.stats.{k}"]
+        t = taps[k].double()
+        assert abs(t.mean().item() - mean) <= 1e-4 * max(1.0, abs(mean)) + 1e-5, k
+        assert abs(t.pow(2).sum().sqrt().item() - l2) <= 1e-4 * l2, k
+
+
+def test_forward_config2_batch16_256():
+    """BASELINE.json configs[1]: B=16 256x256 fp32.  Oracle (CPU) on 4 of the 16 samples, <= 1e-3 each;
+    every sample of the batch equals the same sample run alone, bit for bit (no cross-sample op)."""
+    sd = synth.synthetic_state_dict(seed=0)
+    f1, f2 = synth.synthetic_frames(21, 16, 256, 256, "natural")
+    m = make_model(sd)
+    with torch.no_grad():
+        out = m(f1.to(DEV), f2.to(DEV)).cpu()
+        for i in (0, 5, 10, 15):
+            ref = oracle.forward(sd, f1[i:i + 1], f2[i:i + 1])
+            err = (out[i:i + 1] - ref).abs().max().item()
+            assert err <= 1e-3, (i, err)
+            assert psnr(out[i:i + 1], ref) >= 60.0
+        for i in (3, 12):
+            alone = m(f1[i:i + 1].to(DEV), f2[i:i + 1].to(DEV)).cpu()
+            assert torch.equal(alone, out[i:i + 1])
+
+
+@pytest.mark.parametrize("H,W", [(5, 7), (1, 40), (33, 1), (64, 96)])
+def test_forward_ragged_sizes(H, W):
+    sd = synth.synthetic_state_dict(seed=6, mid_channels=8)
+    f1, f2 = synth.synthetic_frames(8, 2, H, W, "stress")
+    m = make_model(sd, mid=8)
+    with torch.no_grad():
+        out = m(f1.to(DEV), f2.to(DEV)).cpu()
+    assert (out - oracle.forward(sd, f1, f2)).abs().max().item() <= 1e-3
+
+
+def test_forward_bf16_psnr():
+    """BASELINE configs[2] arithmetic (bf16 convs, fp32 warp) on a natural pair: PSNR vs the fp32 oracle."""
+    sd = synth.synthetic_state_dict(seed=0)
+    f1, f2 = synth.synthetic_frames(1, 2, 256, 256, "natural")
+    m = make_model(sd, dtype="bf16")
+    with torch.no_grad():
+        out = m(f1.to(DEV), f2.to(DEV)).cpu()
+    ref = oracle.forward(sd, f1, f2)
+    p = psnr(out, ref)
+    print(f"bf16 vs fp32 oracle: PSNR {p:.1f} dB, max-abs {(out - ref).abs().max().item():.3e}")
+    assert p >= 30.0
+
+
+def test_full_size_properties_config3():
+    """BASELINE configs[2] size (B=8, 1280x720): size-independent properties instead of a CPU replay -
+    determinism, batch-permutation equivariance (bit exact), output range."""
+    sd = synth.synthetic_state_dict(seed=0)
+    f1, f2 = synth.fast_frames(3, 8, 720, 1280, device=DEV)
+    for dtype in ("fp32", "bf16"):
+        m = make_model(sd, dtype=dtype)
+        with torch.no_grad():
+            a = m(f1, f2)
+            b = m(f1, f2)
+            perm = torch.tensor([3, 0, 7, 1, 6, 2, 5, 4], device=DEV)
+            c = m(f1[perm].contiguous(), f2[perm].contiguous())
+        assert torch.equal(a, b)
+        assert torch.equal(a[perm], c)
+        assert a.min().item() >= 0.0 and a.max().item() <= 1.0 and torch.isfinite(a).all()
+        del a, b, c
+
+
+# ------------------------------------------------------------------ error behaviour at the C-ABI
+def test_cabi_errors_are_codes_not_aborts():
+    L = lib.load()
+    x = torch.zeros(1, 3, 16, 16, device=DEV)
+    o = torch.empty_like(x)
+    blob = torch.empty(L.emavfi_packed_bytes(3, 64, 3, lib.F32), dtype=torch.uint8, device=DEV)
+    small = torch.empty(1024, dtype=torch.uint8, device=DEV)
+    rc = L.emavfi_forward(3, 64, 3, blob.data_ptr(), x.data_ptr(), x.data_ptr(), o.data_ptr(), small.data_ptr(), small.numel(),
+                          1, 16, 16, lib.F32, None, None)
+    assert rc == -3 and "workspace" in lib.last_error()
+    rc = L.emavfi_forward(3, 64, 3, blob.data_ptr(), x.data_ptr() + 4, x.data_ptr(), o.data_ptr(), small.data_ptr(),
+                          small.numel(), 1, 16, 16, lib.F32, None, None)
+    assert rc == -1 and "aligned" in lib.last_error()
+    with pytest.raises(RuntimeError, match="inference-only"):
+        EMA_VFI(mid_channels=8).to(DEV)(x, x)
+    with pytest.raises(RuntimeError, match="no kernel instantiation"):
+        lib.conv3x3(torch.zeros(1, 100, 8, 8, device=DEV), torch.zeros(8, 100, 3, 3, device=DEV), None)
+
+
+def test_reload_state_dict_repacks():
+    sd_a, sd_b = synth.synthetic_state_dict(seed=1, mid_channels=8), synth.synthetic_state_dict(seed=2, mid_channels=8)
+    f1, f2 = synth.synthetic_frames(9, 1, 24, 32, "natural")
+    m = make_model(sd_a, mid=8)
+    with torch.no_grad():
+        a = m(f1.to(DEV), f2.to(DEV)).cpu()
+        m.load_state_dict(sd_b)
+        b = m(f1.to(DEV), f2.to(DEV)).cpu()
+    assert (a - oracle.forward(sd_a, f1, f2)).abs().max().item() <= 1e-3
+    assert (b - oracle.forward(sd_b, f1, f2)).abs().max().item() <= 1e-3

@@ -1,0 +1,105 @@
+// Shared device-side types for libemavfi (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// Activations live in HBM pixel-major / channel-minor ("channels-last"):
+// element (b, y, x, c) at ((b*H + y)*W + x) * pstride + c, with the channel
+// count padded to a multiple of 16 and the pad channels holding exact zeros.
+// One pixel's channels are then one contiguous run, which is what both the
+// MFMA operand fetch (8 bf16 / 4 fp32 consecutive channels per lane = 16 B) and
+// the bilinear / deformable gathers (all channels of one tap) want.
+
+// One "k-group" = what one 16-byte operand load per lane feeds to the matrix core:
+//   bf16: 16 input channels -> one v_mfma_f32_32x32x16_bf16
+//         (lane (r, h) holds channels 8h..8h+7 of row/col r)
+//   fp32:  8 input channels -> four v_mfma_f32_32x32x2_f32
+//         (lane (r, h) holds channels 4h..4h+3; MFMA j contracts channels {j, 4+j})
+template <typename T> struct DT;
+template <> struct DT<float> {
+    static constexpr int CHKG = 8;  // channels per k-group
+    static constexpr int EPV = 4;   // elements per 16-byte vector
+    using vec = f32x4;
+};
+template <> struct DT<bf16_t> {
+    static constexpr int CHKG = 16;
+    static constexpr int EPV = 8;
+    using vec = bf16x8;
+};
+
+// D[cout][pixel] += W[cout][k] * X[k][pixel] for one k-group.  Orientation: weights are the
+// A operand (rows = output channels), pixels are the B operand (cols), so each lane ends up
+// holding 4 consecutive output channels of ONE pixel per register quad - contiguous in the
+// channels-last output.
+__device__ __forceinline__ void mma_kg(f32x16 &acc, const bf16x8 &w, const bf16x8 &x)
+{
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma_kg(f32x16 &acc, const f32x4 &w, const f32x4 &x)
+{
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], x[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1], x[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2], x[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[3], x[3], acc, 0, 0, 0);
+}
+
+// Accumulator register i of lane (r, h) is output channel (i&3) + 8*(i>>2) + 4*h of the
+// 32-channel fragment, pixel r (C/D map of the 32x32 MFMA, cdna_hip_programming.md section 3).
+__device__ __forceinline__ int acc_channel(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+__device__ __forceinline__ void store4(float *p, float a, float b, float c, float d)
+{
+    *reinterpret_cast<f32x4 *>(p) = f32x4{a, b, c, d};
+}
+__device__ __forceinline__ void store4(bf16_t *p, float a, float b, float c, float d)
+{
+    *reinterpret_cast<bf16x4 *>(p) = bf16x4{(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
+}
+
+// LDS pixel stride for CK channels of T: one 16-byte slot of padding makes the stride an odd
+// number of slots, so the 16 lanes of a ds_read_b128 group (consecutive pixels, same channel
+// offset) fall on 16 different slots of the 256-byte bank row: conflict-free.
+template <typename T, int CK> struct LdsPix {
+    static constexpr int BYTES = CK * (int)sizeof(T) + 16;
+    static_assert(((BYTES / 16) & 1) == 1, "LDS pixel stride must be an odd number of 16-B slots");
+};
+
+// ---- kernel parameter blocks (host fills, passed by value) ----
+enum { EPI_NONE = 0, EPI_RELU = 1, EPI_OM = 2, EPI_PLANAR = 3, EPI_PLANAR_TANH01 = 4 };
+
+struct ConvParams {
+    const void *in;     // channels-last T
+    void *out;          // channels-last T (EPI_NONE/RELU) or fp32 [px][32] (EPI_OM)
+    float *out_planar;  // NCHW fp32 (EPI_PLANAR*)
+    const void *w;      // packed [pass][chunk][tap][kg][nf][lane][16 B]
+    const float *bias;  // [npass*NF*32] or, bias_mode 1, [B][16][npass*NF*32]
+    int in_ps, out_ps, out_coff;  // pixel strides / channel offset, in elements
+    int Hin, Win, Hout, Wout, B;
+    int nchunk, npass;
+    int cstore;   // channels to store across all passes (multiple of 4)
+    int epi, nplanes, bias_mode;
+    int ck, nf, stride;  // host-side template selectors
+};
+
+struct DeformParams {
+    const void *x;     // channels-last T, CK channels used
+    const float *om;   // [px][32] fp32: 18 offsets (dy,dx per tap), 9 masks, 5 pad
+    void *out;         // channels-last T
+    const void *w;     // packed [tap][kg][nf][lane][16 B]
+    const float *bias; // [NF*32]
+    int x_ps, out_ps;
+    int H, W, B;
+    int cstore;
+    int ck, nf;  // host-side template selectors
+};
+
+int launch_conv3x3_f32(const ConvParams &p, hipStream_t s);
+int launch_conv3x3_bf16(const ConvParams &p, hipStream_t s);
+int launch_deform_f32(const DeformParams &p, hipStream_t s);
+int launch_deform_bf16(const DeformParams &p, hipStream_t s);

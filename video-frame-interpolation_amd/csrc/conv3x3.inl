@@ -1,0 +1,208 @@
+// 3x3 convolution (pad 1, stride 1 or 2) as an implicit GEMM on the CDNA4 matrix cores.
+// Replaces nn.Conv2d at /root/reference/src/models/ema_vfi.py:7-14 (every conv / conv_block on
+// the forward path: :73-76, :80-82, :90-92, :35-41, :103-105).
+//
+// One 256-thread workgroup (4 waves, one per SIMD) produces a tile of 4*MF rows x 32 columns of
+// output pixels for NF*32 output channels:
+//   * the input tile + 1-pixel halo for CK input channels is staged ONCE in LDS (zero-filled
+//     outside the image = the conv's zero padding) and re-read by all 9 taps, so HBM sees each
+//     input element about once ((TH+2)(TW+2)/(TH*TW) = 1.33x for the 8x32 tile);
+//   * the packed weights of one tap (KG*NF KiB, already in MFMA fragment order) are double
+//     buffered in LDS; the next tap's weights are fetched into registers while the current
+//     tap's MFMAs run and written behind them (one barrier per tap);
+//   * a wave owns MF rows of 32 pixels (MF pixel fragments) x NF channel fragments:
+//     D[cout][pixel] accumulates in MF*NF 32x32 fp32 tiles.
+// LDS pixel stride is an odd number of 16-byte slots (LdsPix), so the ds_read_b128 operand
+// fetches of 32 consecutive pixels are bank-conflict free for stride 1.
+#include "common.h"
+
+template <typename T, int CK, int NF, int S> struct ConvCfg {
+    using D = DT<T>;
+    static constexpr int MF = (S == 1) ? 2 : 1;
+    static constexpr int TH = 4 * MF, TW = 32;
+    static constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
+    static constexpr int PSTR = LdsPix<T, CK>::BYTES;
+    static constexpr int PIECES = CK * (int)sizeof(T) / 16;
+    static constexpr int KG = CK / D::CHKG;
+    static constexpr int WTAP = KG * NF * 1024;  // bytes of packed weights per tap
+    static constexpr int WVEC = KG * NF * 64;    // 16-byte vectors per tap
+    static constexpr int WPT = (WVEC + 255) / 256;
+    static constexpr int LDS_IN = IH * IW * PSTR;
+    static constexpr int LDS_BYTES = LDS_IN + 2 * WTAP;
+    static_assert(CK % D::CHKG == 0, "CK must be a whole number of k-groups");
+    static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the 160 KiB LDS");
+};
+
+template <typename T, int CK, int NF, int S>
+__global__ __launch_bounds__(256) void conv3x3_kernel(const ConvParams p)
+{
+    using C = ConvCfg<T, CK, NF, S>;
+    using vec = typename DT<T>::vec;
+    constexpr int MF = C::MF, IW = C::IW, PSTR = C::PSTR;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *lds_in = smem;
+    char *lds_w = smem + C::LDS_IN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int tx = blockIdx.x, ty = blockIdx.y;
+    const int b = blockIdx.z / p.npass, pass = blockIdx.z - b * p.npass;
+    const int coutpad = p.npass * NF * 32;
+
+    // ---- accumulators start at the bias ----
+    f32x16 acc[MF][NF];
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+        const float *bp = p.bias + pass * NF * 32;
+        if (p.bias_mode == 1) {
+            // motion_estimation.0: the spatially constant context half of the concatenated input
+            // (ema_vfi.py:124) is folded into a bias that depends only on which taps fall inside
+            // the image; the table is indexed by that border class (see ctx_finish_kernel).
+            const int y = ty * C::TH + wave * MF + m, x = tx * 32 + r;
+            const int ym = (y >= 1 ? 1 : 0) | (y <= p.Hout - 2 ? 2 : 0);
+            const int xm = (x >= 1 ? 1 : 0) | (x <= p.Wout - 2 ? 2 : 0);
+            bp += ((size_t)b * 16 + ym * 4 + xm) * coutpad;
+        }
+#pragma unroll
+        for (int n = 0; n < NF; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][n][i] = bp[n * 32 + acc_channel(i, h)];
+    }
+
+    const int iy0 = ty * C::TH * S - 1, ix0 = tx * 32 * S - 1;
+    const char *gin = (const char *)p.in + (size_t)b * p.Hin * p.Win * p.in_ps * sizeof(T);
+    const char *wpass = (const char *)p.w + (size_t)pass * p.nchunk * 9 * C::WTAP;
+
+    for (int chunk = 0; chunk < p.nchunk; ++chunk) {
+        if (chunk) __syncthreads();
+        // ---- stage the input tile (+halo) for this channel chunk ----
+        for (int it = tid; it < C::IH * IW * C::PIECES; it += 256) {
+            const int pix = it / C::PIECES, pc = it - pix * C::PIECES;
+            const int ly = pix / IW, lx = pix - ly * IW;
+            const int gy = iy0 + ly, gx = ix0 + lx;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win)
+                v = *reinterpret_cast<const uint4 *>(
+                    gin + ((size_t)gy * p.Win + gx) * p.in_ps * sizeof(T) + (size_t)chunk * CK * sizeof(T) + pc * 16);
+            *reinterpret_cast<uint4 *>(lds_in + pix * PSTR + pc * 16) = v;
+        }
+        const char *wc = wpass + (size_t)chunk * 9 * C::WTAP;
+#pragma unroll
+        for (int i = 0; i < C::WPT; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < C::WVEC)
+                *reinterpret_cast<uint4 *>(lds_w + idx * 16) = *reinterpret_cast<const uint4 *>(wc + idx * 16);
+        }
+        __syncthreads();
+
+        int cur = 0;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            uint4 wr[C::WPT];
+            if (tap < 8) {
+#pragma unroll
+                for (int i = 0; i < C::WPT; ++i) {
+                    const int idx = tid + i * 256;
+                    if (idx < C::WVEC) wr[i] = *reinterpret_cast<const uint4 *>(wc + (tap + 1) * C::WTAP + idx * 16);
+                }
+            }
+            const int dy = tap / 3, dx = tap - 3 * dy;
+            const char *xb[MF];
+#pragma unroll
+            for (int m = 0; m < MF; ++m)
+                xb[m] = lds_in + (((wave * MF + m) * S + dy) * IW + r * S + dx) * PSTR + h * 16;
+            const char *wb = lds_w + cur * C::WTAP + lane * 16;
+#pragma unroll
+            for (int kg = 0; kg < C::KG; ++kg) {
+                vec xv[MF];
+#pragma unroll
+                for (int m = 0; m < MF; ++m) xv[m] = *reinterpret_cast<const vec *>(xb[m] + kg * 32);
+#pragma unroll
+                for (int n = 0; n < NF; ++n) {
+                    const vec wv = *reinterpret_cast<const vec *>(wb + (kg * NF + n) * 1024);
+#pragma unroll
+                    for (int m = 0; m < MF; ++m) mma_kg(acc[m][n], wv, xv[m]);
+                }
+            }
+            if (tap < 8) {
+#pragma unroll
+                for (int i = 0; i < C::WPT; ++i) {
+                    const int idx = tid + i * 256;
+                    if (idx < C::WVEC) *reinterpret_cast<uint4 *>(lds_w + (cur ^ 1) * C::WTAP + idx * 16) = wr[i];
+                }
+                __syncthreads();
+                cur ^= 1;
+            }
+        }
+    }
+
+    // ---- epilogue: lane (r, h) holds pixel r, 4 consecutive channels per register quad ----
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+        const int y = ty * C::TH + wave * MF + m, x = tx * 32 + r;
+        if (y >= p.Hout || x >= p.Wout) continue;
+        const size_t pix = ((size_t)b * p.Hout + y) * p.Wout + x;
+        if (p.epi == EPI_PLANAR || p.epi == EPI_PLANAR_TANH01) {
+            // flow head / reconstruction tail: <= 4 real channels, written as NCHW fp32 planes
+            if (h == 0 && pass == 0) {
+                const size_t plane = (size_t)p.Hout * p.Wout;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < p.nplanes) {
+                        float v = acc[m][0][c];
+                        if (p.epi == EPI_PLANAR_TANH01) v = (tanhf(v) + 1.0f) / 2.0f;  // ema_vfi.py:106,146
+                        p.out_planar[((size_t)b * p.nplanes + c) * plane + (size_t)y * p.Wout + x] = v;
+                    }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int n = 0; n < NF; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = pass * NF * 32 + n * 32 + 8 * g + 4 * h;
+                if (c0 >= p.cstore) continue;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = acc[m][n][4 * g + j];
+                    if (p.epi == EPI_RELU) v[j] = fmaxf(v[j], 0.0f);
+                    // mask = sigmoid(second chunk), ema_vfi.py:59; routed to channels 18..26 at pack time
+                    if (p.epi == EPI_OM && c0 + j >= 18 && c0 + j < 27) v[j] = 1.0f / (1.0f + expf(-v[j]));
+                }
+                if (p.epi == EPI_OM)
+                    store4(reinterpret_cast<float *>(p.out) + pix * p.out_ps + c0, v[0], v[1], v[2], v[3]);
+                else
+                    store4(reinterpret_cast<T *>(p.out) + pix * p.out_ps + p.out_coff + c0, v[0], v[1], v[2], v[3]);
+            }
+    }
+}
+
+template <typename T, int CK, int NF, int S> static int launch_conv_inst(const ConvParams &p, hipStream_t s)
+{
+    using C = ConvCfg<T, CK, NF, S>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_kernel<T, CK, NF, S>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    dim3 grid((p.Wout + 31) / 32, (p.Hout + C::TH - 1) / C::TH, p.B * p.npass);
+    conv3x3_kernel<T, CK, NF, S><<<grid, 256, C::LDS_BYTES, s>>>(p);
+    return (int)hipGetLastError();
+}
+
+// (CK, NF, stride) instantiations: what mid_channels in {8, 16, 32, 64} need (see plan.cpp).
+#define EMAVFI_CONV_INSTANCES(X) \
+    X(16, 1, 1) X(16, 2, 1) X(32, 1, 1) X(48, 1, 1) X(64, 1, 1) X(64, 2, 1) X(64, 4, 1) X(80, 1, 1) X(80, 2, 1) \
+    X(16, 1, 2) X(32, 2, 2) X(32, 4, 2)
+
+template <typename T> static int launch_conv_any(const ConvParams &p, hipStream_t s)
+{
+#define X(CK_, NF_, ST_) \
+    if (p.ck == CK_ && p.nf == NF_ && p.stride == ST_) return launch_conv_inst<T, CK_, NF_, ST_>(p, s);
+    EMAVFI_CONV_INSTANCES(X)
+#undef X
+    return -2;  // no instantiation
+}

@@ -1,0 +1,488 @@
+// libemavfi.so host side: the C-ABI of include/emavfi.h, the layer plan (which kernel
+// instantiation serves which reference layer), weight packing and workspace carving.
+// No device allocation, no synchronisation, no retained pointers.
+#include "../../include/emavfi.h"
+#include "common.h"
+#include "misc_kernels.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+inline int rup(int v, int m) { return (v + m - 1) / m * m; }
+inline size_t rup256(size_t v) { return (v + 255) & ~(size_t)255; }
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---- which (CK, NF, stride) / (CK, NF) instantiations exist (keep in sync with the .inl lists) ----
+const int kConvInst[][3] = {{16, 1, 1}, {16, 2, 1}, {32, 1, 1}, {48, 1, 1}, {64, 1, 1}, {64, 2, 1},
+                            {64, 4, 1}, {80, 1, 1}, {80, 2, 1}, {16, 1, 2}, {32, 2, 2}, {32, 4, 2}};
+const int kDeformInst[][2] = {{16, 1}, {32, 1}, {48, 2}, {80, 3}};
+
+bool conv_inst_exists(int ck, int nf, int st)
+{
+    for (auto &i : kConvInst)
+        if (i[0] == ck && i[1] == nf && i[2] == st) return true;
+    return false;
+}
+
+struct Layer {
+    // raw tensor
+    int cout = 0, cin_raw = 0, cin_off = 0, cin_take = 0, stride = 1, perm = 0, param = 0;
+    // packed geometry
+    int cin_pad = 0, ck = 0, nchunk = 0, nf = 0, npass = 0, coutpad = 0;
+    size_t w_off = 0, b_off = 0, w_bytes = 0;
+    bool deform = false;
+};
+
+bool conv_geometry(Layer &L, int esize)
+{
+    L.cin_pad = rup(L.cin_take, 16);
+    if (L.stride == 2) L.ck = (L.cin_pad % 32 == 0) ? 32 : 16;
+    else if (L.cin_pad <= 80) L.ck = L.cin_pad;
+    else if (L.cin_pad % 64 == 0) L.ck = 64;
+    else return false;
+    L.nchunk = L.cin_pad / L.ck;
+    const int frags = (L.cout + 31) / 32;
+    L.nf = (frags % 4 == 0) ? 4 : (frags % 2 == 0) ? 2 : 1;
+    if (L.stride == 2 && L.ck == 16) L.nf = 1;
+    if (L.stride == 2 && L.ck == 32 && L.nf == 1) { L.ck = 16; L.nchunk = L.cin_pad / 16; }
+    L.npass = frags / L.nf;
+    L.coutpad = frags * 32;
+    // fall back to narrower fragments if the preferred width has no instantiation
+    while (!conv_inst_exists(L.ck, L.nf, L.stride) && L.nf > 1) { L.nf /= 2; L.npass = frags / L.nf; }
+    if (!conv_inst_exists(L.ck, L.nf, L.stride)) return false;
+    L.w_bytes = (size_t)L.npass * L.nchunk * 9 * (L.ck * esize / 32) * L.nf * 1024;
+    return true;
+}
+
+bool deform_geometry(Layer &L, int esize)
+{
+    const int cpad = rup(L.cin_take, 16), frags = (L.cout + 31) / 32;
+    for (auto &i : kDeformInst)
+        if (i[0] >= cpad && i[1] >= frags) {
+            L.cin_pad = L.ck = i[0];
+            L.nchunk = 1;
+            L.nf = i[1];
+            L.npass = 1;
+            L.coutpad = L.nf * 32;
+            L.w_bytes = (size_t)9 * (L.ck * esize / 32) * L.nf * 1024;
+            L.deform = true;
+            return true;
+        }
+    return false;
+}
+
+constexpr int kMaxBlocks = 8;
+
+struct Plan {
+    int in_ch, mid, nb, dtype, esize;
+    int fpad, p_mid;  // padded fusion / feature widths
+    Layer conv1, blk[kMaxBlocks], c0, c1, c2, m0, m1, m2, off[kMaxBlocks], dcn[kMaxBlocks], r0, r1, r2;
+    int lin_param;
+    size_t ctx_off, total;
+    const char *why;
+};
+
+Layer mk(int param, int cout, int cin_raw, int stride = 1, int cin_off = 0, int cin_take = -1, int perm = 0)
+{
+    Layer L;
+    L.param = param; L.cout = cout; L.cin_raw = cin_raw; L.stride = stride;
+    L.cin_off = cin_off; L.cin_take = cin_take < 0 ? cin_raw : cin_take; L.perm = perm;
+    return L;
+}
+
+bool build_plan(Plan &P, int in_ch, int mid, int nb, int dtype)
+{
+    P.why = "";
+    if (dtype != EMAVFI_F32 && dtype != EMAVFI_BF16) { P.why = "dtype must be EMAVFI_F32 or EMAVFI_BF16"; return false; }
+    if (in_ch < 1 || in_ch > 4) { P.why = "in_channels must be 1..4"; return false; }
+    if (nb < 1 || nb > kMaxBlocks) { P.why = "num_blocks must be 1..8"; return false; }
+    if (mid < 8 || mid % 8 != 0) { P.why = "mid_channels must be a positive multiple of 8"; return false; }
+    P.in_ch = in_ch; P.mid = mid; P.nb = nb; P.dtype = dtype; P.esize = dtype == EMAVFI_F32 ? 4 : 2;
+    const int f = mid + 3;  // ema_vfi.py:97 (the +3 is literal in the reference)
+    P.fpad = rup(f, 16); P.p_mid = rup(mid, 16);
+    int q = 0;  // running index into the state_dict tensor list (weight, bias pairs)
+    P.conv1 = mk(q, mid, 2 * in_ch); q += 2;
+    for (int i = 0; i < nb; ++i) { P.blk[i] = mk(q, mid, mid); q += 2; }
+    P.c0 = mk(q, 2 * mid, mid, 2); q += 2;
+    P.c1 = mk(q, 4 * mid, 2 * mid, 2); q += 2;
+    P.c2 = mk(q, 4 * mid, 4 * mid); q += 2;
+    P.lin_param = q; q += 2;
+    P.m0 = mk(q, mid, 2 * mid, 1, 0, mid); q += 2;  // feat half only; ctx half is folded into the bias table
+    P.m1 = mk(q, mid, mid); q += 2;
+    P.m2 = mk(q, 2, mid); q += 2;
+    for (int i = 0; i < nb; ++i) {
+        P.off[i] = mk(q, 27, f, 1, 0, -1, 1); q += 2;
+        P.dcn[i] = mk(q, f, f); q += 2;
+    }
+    P.r0 = mk(q, mid, f); q += 2;
+    P.r1 = mk(q, mid / 2, mid); q += 2;
+    P.r2 = mk(q, in_ch, mid / 2); q += 2;
+
+    size_t o = 0;
+    auto place = [&](Layer &L, bool deform) {
+        const bool ok = deform ? deform_geometry(L, P.esize) : conv_geometry(L, P.esize);
+        if (!ok) return false;
+        L.w_off = o; o = rup256(o + L.w_bytes);
+        L.b_off = o; o = rup256(o + (size_t)L.coutpad * sizeof(float));
+        return true;
+    };
+    bool ok = place(P.conv1, false);
+    for (int i = 0; i < nb && ok; ++i) ok = place(P.blk[i], false);
+    ok = ok && place(P.c0, false) && place(P.c1, false) && place(P.c2, false);
+    ok = ok && place(P.m0, false) && place(P.m1, false) && place(P.m2, false);
+    for (int i = 0; i < nb && ok; ++i) ok = place(P.off[i], false) && place(P.dcn[i], true);
+    ok = ok && place(P.r0, false) && place(P.r1, false) && place(P.r2, false);
+    if (!ok) { P.why = "no kernel instantiation for these channel widths (built: mid_channels 8, 16, 32, 64)"; return false; }
+    if (256 % rup(4 * mid, 16) != 0) { P.why = "4*mid_channels must divide 256 for the pooling kernel"; return false; }
+    P.ctx_off = o;
+    o = rup256(o + ((size_t)mid * 4 * mid + mid + (size_t)mid * mid * 9 + mid) * sizeof(float));
+    P.total = o;
+    return true;
+}
+
+int run_conv(const Plan &P, const Layer &L, const void *packed, const void *in, int in_ps, int Hin, int Win, void *out,
+             int out_ps, int out_coff, int cstore, int epi, int B, hipStream_t s, const float *bias_table = nullptr,
+             float *planar = nullptr, int nplanes = 0)
+{
+    ConvParams c{};
+    c.in = in; c.out = out; c.out_planar = planar;
+    c.w = (const char *)packed + L.w_off;
+    c.bias = bias_table ? bias_table : (const float *)((const char *)packed + L.b_off);
+    c.in_ps = in_ps; c.out_ps = out_ps; c.out_coff = out_coff;
+    c.Hin = Hin; c.Win = Win;
+    c.Hout = (Hin + L.stride - 1) / L.stride; c.Wout = (Win + L.stride - 1) / L.stride;
+    c.B = B; c.nchunk = L.nchunk; c.npass = L.npass; c.cstore = cstore;
+    c.epi = epi; c.nplanes = nplanes; c.bias_mode = bias_table ? 1 : 0;
+    c.ck = L.ck; c.nf = L.nf; c.stride = L.stride;
+    return P.dtype == EMAVFI_F32 ? launch_conv3x3_f32(c, s) : launch_conv3x3_bf16(c, s);
+}
+
+int run_deform(const Plan &P, const Layer &L, const void *packed, const void *x, int x_ps, const float *om, void *out,
+               int out_ps, int cstore, int B, int H, int W, hipStream_t s)
+{
+    DeformParams d{};
+    d.x = x; d.om = om; d.out = out;
+    d.w = (const char *)packed + L.w_off;
+    d.bias = (const float *)((const char *)packed + L.b_off);
+    d.x_ps = x_ps; d.out_ps = out_ps; d.H = H; d.W = W; d.B = B; d.cstore = cstore; d.ck = L.ck; d.nf = L.nf;
+    return P.dtype == EMAVFI_F32 ? launch_deform_f32(d, s) : launch_deform_bf16(d, s);
+}
+
+int pack_layer(const Layer &L, const void *const *params, void *packed, int dtype, hipStream_t s)
+{
+    PackDesc d{L.cout, L.cin_raw, L.cin_off, L.cin_take, L.ck, L.nchunk, L.nf, L.npass, L.perm};
+    return launch_pack_conv((const float *)params[L.param], (const float *)params[L.param + 1], (char *)packed + L.w_off,
+                            (float *)((char *)packed + L.b_off), d, dtype, s);
+}
+
+struct Workspace {
+    char *base; size_t cap, used;
+    void *take(size_t bytes) { void *p = base ? base + used : nullptr; used = rup256(used + bytes); return p; }
+};
+
+struct FwdBuffers {
+    void *in16, *fA, *fB, *fu0, *fu1, *c1, *c2, *c3;
+    float *part, *ctx, *table, *flow, *om;
+    int nparts, H2, W2, H4, W4, p2, p4, p_half;
+};
+
+void carve_forward(const Plan &P, Workspace &ws, FwdBuffers &f, int B, int H, int W)
+{
+    const size_t px = (size_t)B * H * W, e = P.esize;
+    f.H2 = (H + 1) / 2; f.W2 = (W + 1) / 2; f.H4 = (f.H2 + 1) / 2; f.W4 = (f.W2 + 1) / 2;
+    f.p2 = rup(2 * P.mid, 16); f.p4 = rup(4 * P.mid, 16); f.p_half = rup(P.mid / 2, 16);
+    const int npix4 = f.H4 * f.W4;
+    f.nparts = npix4 >= 64 * 64 ? 64 : (npix4 >= 64 ? npix4 / 64 : 1);
+    f.in16 = ws.take(px * 16 * e);
+    f.fA = ws.take(px * P.p_mid * e);
+    f.fB = ws.take(px * P.p_mid * e);
+    f.fu0 = ws.take(px * P.fpad * e);
+    f.fu1 = ws.take(px * P.fpad * e);
+    f.c1 = ws.take((size_t)B * f.H2 * f.W2 * f.p2 * e);
+    f.c2 = ws.take((size_t)B * npix4 * f.p4 * e);
+    f.c3 = ws.take((size_t)B * npix4 * f.p4 * e);
+    f.part = (float *)ws.take((size_t)B * f.nparts * f.p4 * sizeof(float));
+    f.ctx = (float *)ws.take((size_t)B * P.mid * sizeof(float));
+    f.table = (float *)ws.take((size_t)B * 16 * P.m0.coutpad * sizeof(float));
+    f.flow = (float *)ws.take(px * 2 * sizeof(float));
+    f.om = (float *)ws.take(px * 32 * sizeof(float));
+}
+
+#define EMAVFI_TRY(expr, what)                                                                       \
+    do {                                                                                             \
+        const int e_ = (expr);                                                                       \
+        if (e_ == -2) return fail(EMAVFI_E_UNSUPPORTED, "%s: no kernel instantiation", what);        \
+        if (e_ != 0) return fail(EMAVFI_E_LAUNCH, "%s: %s", what, hipGetErrorString((hipError_t)e_)); \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int emavfi_version(void) { return EMAVFI_VERSION; }
+const char *emavfi_last_error(void) { return g_err; }
+int emavfi_param_count(int num_blocks) { return 2 * (11 + 3 * num_blocks); }
+
+int emavfi_supported(int in_channels, int mid_channels, int num_blocks, int dtype)
+{
+    Plan P;
+    if (!build_plan(P, in_channels, mid_channels, num_blocks, dtype)) return fail(EMAVFI_E_UNSUPPORTED, "%s", P.why);
+    return EMAVFI_OK;
+}
+
+size_t emavfi_packed_bytes(int in_channels, int mid_channels, int num_blocks, int dtype)
+{
+    Plan P;
+    if (!build_plan(P, in_channels, mid_channels, num_blocks, dtype)) { fail(EMAVFI_E_UNSUPPORTED, "%s", P.why); return 0; }
+    return P.total;
+}
+
+int emavfi_pack_weights(int in_channels, int mid_channels, int num_blocks, const void *const *params, int n_params,
+                        void *packed, size_t packed_bytes, int dtype, void *stream)
+{
+    Plan P;
+    if (!build_plan(P, in_channels, mid_channels, num_blocks, dtype)) return fail(EMAVFI_E_UNSUPPORTED, "%s", P.why);
+    if (!params || !packed) return fail(EMAVFI_E_ARG, "pack_weights: null pointer");
+    if (n_params != emavfi_param_count(num_blocks))
+        return fail(EMAVFI_E_ARG, "pack_weights: expected %d tensors, got %d", emavfi_param_count(num_blocks), n_params);
+    for (int i = 0; i < n_params; ++i)
+        if (!params[i]) return fail(EMAVFI_E_ARG, "pack_weights: params[%d] is null", i);
+    if (packed_bytes < P.total) return fail(EMAVFI_E_WORKSPACE, "pack_weights: need %zu bytes, got %zu", P.total, packed_bytes);
+    if (!aligned16(packed)) return fail(EMAVFI_E_ARG, "pack_weights: packed buffer must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    EMAVFI_TRY(pack_layer(P.conv1, params, packed, dtype, s), "pack conv1");
+    for (int i = 0; i < P.nb; ++i) EMAVFI_TRY(pack_layer(P.blk[i], params, packed, dtype, s), "pack feat block");
+    EMAVFI_TRY(pack_layer(P.c0, params, packed, dtype, s), "pack ctx0");
+    EMAVFI_TRY(pack_layer(P.c1, params, packed, dtype, s), "pack ctx1");
+    EMAVFI_TRY(pack_layer(P.c2, params, packed, dtype, s), "pack ctx2");
+    EMAVFI_TRY(pack_layer(P.m0, params, packed, dtype, s), "pack motion0");
+    EMAVFI_TRY(pack_layer(P.m1, params, packed, dtype, s), "pack motion1");
+    EMAVFI_TRY(pack_layer(P.m2, params, packed, dtype, s), "pack motion2");
+    for (int i = 0; i < P.nb; ++i) {
+        EMAVFI_TRY(pack_layer(P.off[i], params, packed, dtype, s), "pack offset_conv");
+        EMAVFI_TRY(pack_layer(P.dcn[i], params, packed, dtype, s), "pack dcn_v2");
+    }
+    EMAVFI_TRY(pack_layer(P.r0, params, packed, dtype, s), "pack recon0");
+    EMAVFI_TRY(pack_layer(P.r1, params, packed, dtype, s), "pack recon1");
+    EMAVFI_TRY(pack_layer(P.r2, params, packed, dtype, s), "pack recon2");
+    EMAVFI_TRY(launch_pack_ctx((const float *)params[P.lin_param], (const float *)params[P.lin_param + 1],
+                               (const float *)params[P.m0.param], (const float *)params[P.m0.param + 1],
+                               (float *)((char *)packed + P.ctx_off), P.mid, s),
+               "pack context");
+    return EMAVFI_OK;
+}
+
+size_t emavfi_workspace_bytes(int in_channels, int mid_channels, int num_blocks, int B, int H, int W, int dtype)
+{
+    Plan P;
+    if (!build_plan(P, in_channels, mid_channels, num_blocks, dtype)) { fail(EMAVFI_E_UNSUPPORTED, "%s", P.why); return 0; }
+    if (B < 1 || H < 1 || W < 1) { fail(EMAVFI_E_ARG, "workspace_bytes: B, H, W must be >= 1"); return 0; }
+    Workspace ws{nullptr, 0, 0};
+    FwdBuffers f;
+    carve_forward(P, ws, f, B, H, W);
+    return ws.used;
+}
+
+int emavfi_forward(int in_channels, int mid_channels, int num_blocks, const void *packed, const float *frame1,
+                   const float *frame2, float *out, void *workspace, size_t workspace_bytes, int B, int H, int W, int dtype,
+                   float *const *taps, void *stream)
+{
+    Plan P;
+    if (!build_plan(P, in_channels, mid_channels, num_blocks, dtype)) return fail(EMAVFI_E_UNSUPPORTED, "%s", P.why);
+    if (!packed || !frame1 || !frame2 || !out || !workspace) return fail(EMAVFI_E_ARG, "forward: null pointer");
+    if (B < 1 || H < 1 || W < 1) return fail(EMAVFI_E_ARG, "forward: B, H, W must be >= 1 (got %d, %d, %d)", B, H, W);
+    if ((size_t)B * H * W >= ((size_t)1 << 31) / 128) return fail(EMAVFI_E_ARG, "forward: B*H*W too large for 32-bit pixel indexing");
+    if (!aligned16(packed) || !aligned16(workspace) || !aligned16(frame1) || !aligned16(frame2) || !aligned16(out))
+        return fail(EMAVFI_E_ARG, "forward: pointers must be 16-byte aligned");
+    Workspace ws{(char *)workspace, workspace_bytes, 0};
+    FwdBuffers f;
+    carve_forward(P, ws, f, B, H, W);
+    if (ws.used > workspace_bytes) return fail(EMAVFI_E_WORKSPACE, "forward: workspace needs %zu bytes, got %zu", ws.used, workspace_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    const int mid = P.mid, C = P.in_ch;
+    const size_t px = (size_t)B * H * W;
+
+    // --- feature extraction: cat + conv + ReLU, then num_blocks x (conv + ReLU)  (ema_vfi.py:112-116)
+    EMAVFI_TRY(launch_pack_input(frame1, frame2, f.in16, B, C, H, W, 16, dtype, s), "pack_input");
+    EMAVFI_TRY(run_conv(P, P.conv1, packed, f.in16, 16, H, W, f.fA, P.p_mid, 0, P.p_mid, EPI_RELU, B, s), "feat_ext_conv1");
+    void *cur = f.fA, *nxt = f.fB;
+    for (int i = 0; i < P.nb; ++i) {
+        const bool last = i == P.nb - 1;  // the last block writes feat straight into the fusion buffer
+        void *dst = last ? f.fu0 : nxt;
+        EMAVFI_TRY(run_conv(P, P.blk[i], packed, cur, P.p_mid, H, W, dst, last ? P.fpad : P.p_mid, 0, P.p_mid, EPI_RELU, B, s),
+                   "feat_ext_blocks");
+        if (!last) { void *t = cur; cur = nxt; nxt = t; }
+    }
+    if (taps && taps[0]) EMAVFI_TRY(launch_cl_to_nchw(f.fu0, taps[0], B, mid, H, W, P.fpad, 0, dtype, s), "tap feat");
+
+    // --- context encoding (ema_vfi.py:120): two stride-2 convs, one conv, global mean, linear
+    EMAVFI_TRY(run_conv(P, P.c0, packed, f.fu0, P.fpad, H, W, f.c1, f.p2, 0, f.p2, EPI_RELU, B, s), "context_encoding.0");
+    EMAVFI_TRY(run_conv(P, P.c1, packed, f.c1, f.p2, f.H2, f.W2, f.c2, f.p4, 0, f.p4, EPI_RELU, B, s), "context_encoding.1");
+    EMAVFI_TRY(run_conv(P, P.c2, packed, f.c2, f.p4, f.H4, f.W4, f.c3, f.p4, 0, f.p4, EPI_RELU, B, s), "context_encoding.2");
+    EMAVFI_TRY(launch_pool_partial(f.c3, f.part, B, f.H4 * f.W4, f.p4, f.p4, f.nparts, dtype, s), "avg-pool");
+    EMAVFI_TRY(launch_ctx_finish(f.part, (const float *)((const char *)packed + P.ctx_off), f.ctx, f.table, B, mid, f.p4,
+                                 f.nparts, f.H4 * f.W4, P.m0.coutpad, s),
+               "context linear");
+    if (taps && taps[1])
+        if (hipMemcpyAsync(taps[1], f.ctx, (size_t)B * mid * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return fail(EMAVFI_E_LAUNCH, "tap ctx copy failed");
+
+    // --- motion estimation (ema_vfi.py:124-126); the broadcast-context concat is a per-border-class bias
+    EMAVFI_TRY(run_conv(P, P.m0, packed, f.fu0, P.fpad, H, W, f.fA, P.p_mid, 0, P.p_mid, EPI_RELU, B, s, f.table), "motion_estimation.0");
+    EMAVFI_TRY(run_conv(P, P.m1, packed, f.fA, P.p_mid, H, W, f.fB, P.p_mid, 0, P.p_mid, EPI_RELU, B, s), "motion_estimation.1");
+    EMAVFI_TRY(run_conv(P, P.m2, packed, f.fB, P.p_mid, H, W, nullptr, 0, 0, 0, EPI_PLANAR, B, s, nullptr, f.flow, 2), "motion_estimation.2");
+    if (taps && taps[2])
+        if (hipMemcpyAsync(taps[2], f.flow, px * 2 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return fail(EMAVFI_E_LAUNCH, "tap flow copy failed");
+
+    // --- warp frame2 by the flow into channels [mid, fpad) of the fusion buffer (ema_vfi.py:130,134)
+    EMAVFI_TRY(launch_warp_fused(frame2, f.flow, f.fu0, B, C, H, W, P.fpad, mid, dtype, s), "warp");
+    if (taps && taps[3]) EMAVFI_TRY(launch_cl_to_nchw(f.fu0, taps[3], B, C, H, W, P.fpad, mid, dtype, s), "tap warped");
+
+    // --- multi-attention fusion: num_blocks x ModulatedDeformConvPack, no activation (ema_vfi.py:136-138)
+    void *x = f.fu0, *y = f.fu1;
+    for (int i = 0; i < P.nb; ++i) {
+        EMAVFI_TRY(run_conv(P, P.off[i], packed, x, P.fpad, H, W, f.om, 32, 0, 32, EPI_OM, B, s), "offset_conv");
+        EMAVFI_TRY(run_deform(P, P.dcn[i], packed, x, P.fpad, f.om, y, P.fpad, P.fpad, B, H, W, s), "dcn_v2");
+        if (taps && taps[5 + i]) EMAVFI_TRY(launch_cl_to_nchw(y, taps[5 + i], B, mid + 3, H, W, P.fpad, 0, dtype, s), "tap fused");
+        void *t = x; x = y; y = t;
+    }
+
+    // --- reconstruction (ema_vfi.py:144-146)
+    EMAVFI_TRY(run_conv(P, P.r0, packed, x, P.fpad, H, W, f.fA, P.p_mid, 0, P.p_mid, EPI_RELU, B, s), "reconstruction.0");
+    EMAVFI_TRY(run_conv(P, P.r1, packed, f.fA, P.p_mid, H, W, f.fB, f.p_half, 0, f.p_half, EPI_RELU, B, s), "reconstruction.1");
+    EMAVFI_TRY(run_conv(P, P.r2, packed, f.fB, f.p_half, H, W, nullptr, 0, 0, 0, EPI_PLANAR_TANH01, B, s, nullptr, out, C), "reconstruction.2");
+    return EMAVFI_OK;
+}
+
+int emavfi_warp(const float *frame2, const float *flow, float *out, int B, int C, int H, int W, void *stream)
+{
+    if (!frame2 || !flow || !out) return fail(EMAVFI_E_ARG, "warp: null pointer");
+    if (B < 1 || C < 1 || H < 1 || W < 1) return fail(EMAVFI_E_ARG, "warp: B, C, H, W must be >= 1");
+    if ((size_t)H * W >= ((size_t)1 << 31)) return fail(EMAVFI_E_ARG, "warp: H*W too large");
+    if (!aligned16(frame2) || !aligned16(flow) || !aligned16(out)) return fail(EMAVFI_E_ARG, "warp: pointers must be 16-byte aligned");
+    EMAVFI_TRY(launch_warp_nchw(frame2, flow, out, B, C, H, W, (hipStream_t)stream), "warp");
+    return EMAVFI_OK;
+}
+
+// ---- stage-level entries (diagnostics / parity tests of single operators) ----
+static bool single_conv_layer(Layer &L, int Cin, int Cout, int stride, int esize)
+{
+    L = mk(0, Cout, Cin, stride);
+    return conv_geometry(L, esize);
+}
+
+size_t emavfi_conv3x3_workspace_bytes(int B, int Cin, int Cout, int H, int W, int stride, int dtype)
+{
+    Layer L;
+    const int e = dtype == EMAVFI_F32 ? 4 : 2;
+    if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || (stride != 1 && stride != 2) || !single_conv_layer(L, Cin, Cout, stride, e)) {
+        fail(EMAVFI_E_UNSUPPORTED, "conv3x3: no kernel instantiation for Cin=%d Cout=%d stride=%d", Cin, Cout, stride);
+        return 0;
+    }
+    const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+    Workspace ws{nullptr, 0, 0};
+    ws.take((size_t)B * H * W * L.cin_pad * e);
+    ws.take(L.w_bytes);
+    ws.take((size_t)L.coutpad * sizeof(float));
+    ws.take((size_t)B * Ho * Wo * rup(Cout, 16) * e);
+    return ws.used;
+}
+
+int emavfi_conv3x3(const float *x, const float *weight, const float *bias, float *y, int B, int Cin, int Cout, int H, int W,
+                   int stride, int act, int dtype, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (dtype != EMAVFI_F32 && dtype != EMAVFI_BF16) return fail(EMAVFI_E_ARG, "conv3x3: bad dtype %d", dtype);
+    if (!x || !weight || !y || !workspace) return fail(EMAVFI_E_ARG, "conv3x3: null pointer");
+    if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || (stride != 1 && stride != 2)) return fail(EMAVFI_E_ARG, "conv3x3: bad shape");
+    if (act < EMAVFI_ACT_NONE || act > EMAVFI_ACT_TANH01) return fail(EMAVFI_E_ARG, "conv3x3: bad activation %d", act);
+    if (act == EMAVFI_ACT_TANH01 && Cout > 4) return fail(EMAVFI_E_UNSUPPORTED, "conv3x3: TANH01 epilogue needs Cout <= 4");
+    Plan P{};
+    P.dtype = dtype; P.esize = dtype == EMAVFI_F32 ? 4 : 2;
+    Layer L;
+    if (!single_conv_layer(L, Cin, Cout, stride, P.esize))
+        return fail(EMAVFI_E_UNSUPPORTED, "conv3x3: no kernel instantiation for Cin=%d Cout=%d stride=%d", Cin, Cout, stride);
+    const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride, ops = rup(Cout, 16);
+    Workspace ws{(char *)workspace, workspace_bytes, 0};
+    void *xcl = ws.take((size_t)B * H * W * L.cin_pad * P.esize);
+    void *wp = ws.take(L.w_bytes);
+    float *bp = (float *)ws.take((size_t)L.coutpad * sizeof(float));
+    void *ycl = ws.take((size_t)B * Ho * Wo * ops * P.esize);
+    if (ws.used > workspace_bytes) return fail(EMAVFI_E_WORKSPACE, "conv3x3: workspace needs %zu bytes, got %zu", ws.used, workspace_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    L.w_off = (char *)wp - (char *)workspace;
+    L.b_off = (char *)bp - (char *)workspace;
+    PackDesc d{L.cout, L.cin_raw, 0, L.cin_take, L.ck, L.nchunk, L.nf, L.npass, 0};
+    EMAVFI_TRY(launch_pack_conv(weight, bias, wp, bp, d, dtype, s), "conv3x3 pack");
+    EMAVFI_TRY(launch_nchw_to_cl(x, xcl, B, Cin, H, W, L.cin_pad, dtype, s), "conv3x3 layout in");
+    if (act == EMAVFI_ACT_TANH01) {
+        EMAVFI_TRY(run_conv(P, L, workspace, xcl, L.cin_pad, H, W, nullptr, 0, 0, 0, EPI_PLANAR_TANH01, B, s, nullptr, y, Cout), "conv3x3");
+    } else {
+        EMAVFI_TRY(run_conv(P, L, workspace, xcl, L.cin_pad, H, W, ycl, ops, 0, ops, act == EMAVFI_ACT_RELU ? EPI_RELU : EPI_NONE, B, s), "conv3x3");
+        EMAVFI_TRY(launch_cl_to_nchw(ycl, y, B, Cout, Ho, Wo, ops, 0, dtype, s), "conv3x3 layout out");
+    }
+    return EMAVFI_OK;
+}
+
+size_t emavfi_deform_conv2d_workspace_bytes(int B, int C, int O, int H, int W, int dtype)
+{
+    const int e = dtype == EMAVFI_F32 ? 4 : 2;
+    Layer L = mk(0, O, C);
+    if (B < 1 || C < 1 || O < 1 || H < 1 || W < 1 || !deform_geometry(L, e)) {
+        fail(EMAVFI_E_UNSUPPORTED, "deform_conv2d: no kernel instantiation for C=%d O=%d", C, O);
+        return 0;
+    }
+    Workspace ws{nullptr, 0, 0};
+    const size_t px = (size_t)B * H * W;
+    ws.take(px * L.ck * e); ws.take(px * 32 * sizeof(float)); ws.take(L.w_bytes);
+    ws.take((size_t)L.coutpad * sizeof(float)); ws.take(px * rup(O, 16) * e);
+    return ws.used;
+}
+
+int emavfi_deform_conv2d(const float *x, const float *offset, const float *mask, const float *weight, const float *bias,
+                         float *y, int B, int C, int O, int H, int W, int dtype, void *workspace, size_t workspace_bytes,
+                         void *stream)
+{
+    if (dtype != EMAVFI_F32 && dtype != EMAVFI_BF16) return fail(EMAVFI_E_ARG, "deform_conv2d: bad dtype %d", dtype);
+    if (!x || !offset || !mask || !weight || !y || !workspace) return fail(EMAVFI_E_ARG, "deform_conv2d: null pointer");
+    if (B < 1 || C < 1 || O < 1 || H < 1 || W < 1) return fail(EMAVFI_E_ARG, "deform_conv2d: bad shape");
+    Plan P{};
+    P.dtype = dtype; P.esize = dtype == EMAVFI_F32 ? 4 : 2;
+    Layer L = mk(0, O, C);
+    if (!deform_geometry(L, P.esize)) return fail(EMAVFI_E_UNSUPPORTED, "deform_conv2d: no kernel instantiation for C=%d O=%d", C, O);
+    const size_t px = (size_t)B * H * W;
+    const int ops = rup(O, 16);
+    Workspace ws{(char *)workspace, workspace_bytes, 0};
+    void *xcl = ws.take(px * L.ck * P.esize);
+    float *om = (float *)ws.take(px * 32 * sizeof(float));
+    void *wp = ws.take(L.w_bytes);
+    float *bp = (float *)ws.take((size_t)L.coutpad * sizeof(float));
+    void *ycl = ws.take(px * ops * P.esize);
+    if (ws.used > workspace_bytes) return fail(EMAVFI_E_WORKSPACE, "deform_conv2d: workspace needs %zu bytes, got %zu", ws.used, workspace_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    L.w_off = (char *)wp - (char *)workspace;
+    L.b_off = (char *)bp - (char *)workspace;
+    PackDesc d{L.cout, L.cin_raw, 0, L.cin_take, L.ck, 1, L.nf, 1, 0};
+    EMAVFI_TRY(launch_pack_conv(weight, bias, wp, bp, d, dtype, s), "deform pack");
+    EMAVFI_TRY(launch_nchw_to_cl(x, xcl, B, C, H, W, L.ck, dtype, s), "deform layout in");
+    EMAVFI_TRY(launch_om_from_nchw(offset, mask, om, B, H, W, s), "deform offsets");
+    EMAVFI_TRY(run_deform(P, L, workspace, xcl, L.ck, om, ycl, ops, ops, B, H, W, s), "deform_conv2d");
+    EMAVFI_TRY(launch_cl_to_nchw(ycl, y, B, O, H, W, ops, 0, dtype, s), "deform layout out");
+    return EMAVFI_OK;
+}
+
+}  // extern "C"

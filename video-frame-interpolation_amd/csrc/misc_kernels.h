@@ -1,0 +1,24 @@
+// Host-callable launchers of misc_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <stddef.h>
+
+struct PackDesc {
+    int cout, cin_raw, cin_off, cin_take;  // raw OIHW tensor: take input channels [cin_off, cin_off + cin_take)
+    int ck, nchunk, nf, npass;             // packed geometry
+    int perm;                              // 0 = identity, 1 = offset_conv routing (offsets | mask)
+};
+
+int launch_pack_conv(const float *w, const float *bias, void *wp, float *bp, const PackDesc &d, int dtype, hipStream_t s);
+int launch_pack_ctx(const float *lin_w, const float *lin_b, const float *w9, const float *b9, float *dst, int m, hipStream_t s);
+int launch_pack_input(const float *f1, const float *f2, void *dst, int B, int C, int H, int W, int cpad, int dtype, hipStream_t s);
+int launch_nchw_to_cl(const float *src, void *dst, int B, int C, int H, int W, int ps, int dtype, hipStream_t s);
+int launch_cl_to_nchw(const void *src, float *dst, int B, int C, int H, int W, int ps, int coff, int dtype, hipStream_t s);
+int launch_om_from_nchw(const float *off, const float *msk, float *om, int B, int H, int W, hipStream_t s);
+int launch_pool_partial(const void *src, float *part, int B, int npix, int cp, int ps, int nparts, int dtype, hipStream_t s);
+int launch_ctx_finish(const float *part, const float *ctxw, float *ctx_out, float *table, int B, int m, int cp, int nparts,
+                      int npix, int coutpad, hipStream_t s);
+int launch_warp_nchw(const float *frame2, const float *flow, float *out, int B, int C, int H, int W, hipStream_t s);
+int launch_warp_fused(const float *frame2, const float *flow, void *dst, int B, int C, int H, int W, int ps, int coff, int dtype,
+                      hipStream_t s);

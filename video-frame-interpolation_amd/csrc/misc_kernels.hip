@@ -1,0 +1,374 @@
+// HBM-bound helper kernels of libemavfi: weight packing, layout conversion at the NCHW
+// boundary, global-average-pool + context folding, and the backward bilinear warp.
+#include "common.h"
+#include "misc_kernels.h"
+
+// ------------------------------------------------------------------------------------------
+// Weight packing: OIHW fp32 -> [pass][chunk][tap][kg][nf][lane][16 B] in MFMA operand order.
+// Lane (r, h) of fragment nf holds output channel pass*NF*32 + nf*32 + r and input channels
+// chunk*CK + kg*CHKG + h*EPV + e (e < EPV).  Everything outside the real tensor packs as 0,
+// which is what keeps the pad channels of every activation exactly zero.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int route_cout(int pos, int perm)
+{
+    // perm 1 = ModulatedDeformConvPack routing (ema_vfi.py:57-59): the 27 raw channels are
+    // chunked (static offsets | mask | dynamic offsets); packed channel order is
+    // [18 offsets = cat(first, third)] [9 mask].
+    if (perm == 0) return pos;
+    if (pos < 9) return pos;
+    if (pos < 18) return pos + 9;
+    if (pos < 27) return pos - 9;
+    return 1 << 30;
+}
+
+template <typename T>
+__global__ void pack_conv_kernel(const float *__restrict__ w, const float *__restrict__ bias, T *__restrict__ wp,
+                                 float *__restrict__ bp, PackDesc d)
+{
+    constexpr int CHKG = DT<T>::CHKG, EPV = DT<T>::EPV;
+    const int KG = d.ck / CHKG;
+    const size_t total = (size_t)d.npass * d.nchunk * 9 * KG * d.nf * 64 * EPV;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        size_t t = idx;
+        const int e = t % EPV; t /= EPV;
+        const int lane = t % 64; t /= 64;
+        const int n = t % d.nf; t /= d.nf;
+        const int kg = t % KG; t /= KG;
+        const int tap = t % 9; t /= 9;
+        const int chunk = t % d.nchunk; t /= d.nchunk;
+        const int pass = (int)t;
+        const int co = route_cout(pass * d.nf * 32 + n * 32 + (lane & 31), d.perm);
+        const int ci = chunk * d.ck + kg * CHKG + (lane >> 5) * EPV + e;
+        float v = 0.0f;
+        if (co < d.cout && ci < d.cin_take) v = w[((size_t)co * d.cin_raw + d.cin_off + ci) * 9 + tap];
+        wp[idx] = (T)v;
+    }
+    const int coutpad = d.npass * d.nf * 32;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < coutpad; i += gridDim.x * blockDim.x) {
+        const int co = route_cout(i, d.perm);
+        bp[i] = (co < d.cout && bias) ? bias[co] : 0.0f;
+    }
+}
+
+int launch_pack_conv(const float *w, const float *bias, void *wp, float *bp, const PackDesc &d, int dtype, hipStream_t s)
+{
+    if (dtype == 0)
+        pack_conv_kernel<float><<<256, 256, 0, s>>>(w, bias, (float *)wp, bp, d);
+    else
+        pack_conv_kernel<bf16_t><<<256, 256, 0, s>>>(w, bias, (bf16_t *)wp, bp, d);
+    return (int)hipGetLastError();
+}
+
+// raw fp32 copies the context kernels need: Linear weight/bias, the context half of
+// motion_estimation.0.0.weight as [o][c][tap], its bias.
+__global__ void pack_ctx_kernel(const float *__restrict__ lin_w, const float *__restrict__ lin_b,
+                                const float *__restrict__ w9, const float *__restrict__ b9, float *__restrict__ dst, int m)
+{
+    float *o_lw = dst, *o_lb = o_lw + (size_t)m * 4 * m, *o_w9 = o_lb + m, *o_b9 = o_w9 + (size_t)m * m * 9;
+    const int n_lw = m * 4 * m, n_w9 = m * m * 9;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_lw + n_w9 + 2 * m; i += gridDim.x * blockDim.x) {
+        if (i < n_lw) o_lw[i] = lin_w[i];
+        else if (i < n_lw + m) o_lb[i - n_lw] = lin_b[i - n_lw];
+        else if (i < n_lw + m + n_w9) {
+            const int k = i - n_lw - m, o = k / (m * 9), rem = k - o * m * 9, c = rem / 9, tap = rem - c * 9;
+            o_w9[k] = w9[((size_t)o * 2 * m + m + c) * 9 + tap];
+        } else o_b9[i - n_lw - m - n_w9] = b9[i - n_lw - m - n_w9];
+    }
+}
+int launch_pack_ctx(const float *lin_w, const float *lin_b, const float *w9, const float *b9, float *dst, int m, hipStream_t s)
+{
+    pack_ctx_kernel<<<64, 256, 0, s>>>(lin_w, lin_b, w9, b9, dst, m);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Layout conversion at the boundary.
+// ------------------------------------------------------------------------------------------
+// torch.cat([frame1, frame2], dim=1) (ema_vfi.py:112) fused with the NCHW -> channels-last pack.
+template <typename T>
+__global__ void pack_input_kernel(const float *__restrict__ f1, const float *__restrict__ f2, T *__restrict__ dst,
+                                  int B, int C, int H, int W, int cpad)
+{
+    const size_t plane = (size_t)H * W, total = (size_t)B * plane;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / plane, pix = i - b * plane;
+        T *o = dst + i * cpad;
+        for (int c = 0; c < cpad; ++c) {
+            float v = 0.0f;
+            if (c < C) v = f1[(b * C + c) * plane + pix];
+            else if (c < 2 * C) v = f2[(b * C + (c - C)) * plane + pix];
+            o[c] = (T)v;
+        }
+    }
+}
+int launch_pack_input(const float *f1, const float *f2, void *dst, int B, int C, int H, int W, int cpad, int dtype, hipStream_t s)
+{
+    const int grid = (int)std::min<size_t>(((size_t)B * H * W + 255) / 256, 65535 * 4);
+    if (dtype == 0) pack_input_kernel<float><<<grid, 256, 0, s>>>(f1, f2, (float *)dst, B, C, H, W, cpad);
+    else pack_input_kernel<bf16_t><<<grid, 256, 0, s>>>(f1, f2, (bf16_t *)dst, B, C, H, W, cpad);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+__global__ void nchw_to_cl_kernel(const float *__restrict__ src, T *__restrict__ dst, int B, int C, int H, int W, int ps)
+{
+    const size_t plane = (size_t)H * W, total = (size_t)B * plane;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / plane, pix = i - b * plane;
+        T *o = dst + i * ps;
+        for (int c = 0; c < ps; ++c) o[c] = (T)(c < C ? src[(b * C + c) * plane + pix] : 0.0f);
+    }
+}
+template <typename T>
+__global__ void cl_to_nchw_kernel(const T *__restrict__ src, float *__restrict__ dst, int B, int C, int H, int W, int ps, int coff)
+{
+    const size_t plane = (size_t)H * W, total = (size_t)B * plane;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / plane, pix = i - b * plane;
+        const T *o = src + i * ps + coff;
+        for (int c = 0; c < C; ++c) dst[(b * C + c) * plane + pix] = (float)o[c];
+    }
+}
+int launch_nchw_to_cl(const float *src, void *dst, int B, int C, int H, int W, int ps, int dtype, hipStream_t s)
+{
+    const int grid = (int)std::min<size_t>(((size_t)B * H * W + 255) / 256, 65535 * 4);
+    if (dtype == 0) nchw_to_cl_kernel<float><<<grid, 256, 0, s>>>(src, (float *)dst, B, C, H, W, ps);
+    else nchw_to_cl_kernel<bf16_t><<<grid, 256, 0, s>>>(src, (bf16_t *)dst, B, C, H, W, ps);
+    return (int)hipGetLastError();
+}
+int launch_cl_to_nchw(const void *src, float *dst, int B, int C, int H, int W, int ps, int coff, int dtype, hipStream_t s)
+{
+    const int grid = (int)std::min<size_t>(((size_t)B * H * W + 255) / 256, 65535 * 4);
+    if (dtype == 0) cl_to_nchw_kernel<float><<<grid, 256, 0, s>>>((const float *)src, dst, B, C, H, W, ps, coff);
+    else cl_to_nchw_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t *)src, dst, B, C, H, W, ps, coff);
+    return (int)hipGetLastError();
+}
+
+// offset [B,18,H,W] + mask [B,9,H,W] (torchvision argument layout) -> om [px][32]
+__global__ void om_from_nchw_kernel(const float *__restrict__ off, const float *__restrict__ msk, float *__restrict__ om,
+                                    int B, int H, int W)
+{
+    const size_t plane = (size_t)H * W, total = (size_t)B * plane;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / plane, pix = i - b * plane;
+        float *o = om + i * 32;
+        for (int c = 0; c < 18; ++c) o[c] = off[(b * 18 + c) * plane + pix];
+        for (int c = 0; c < 9; ++c) o[18 + c] = msk[(b * 9 + c) * plane + pix];
+        for (int c = 27; c < 32; ++c) o[c] = 0.0f;
+    }
+}
+int launch_om_from_nchw(const float *off, const float *msk, float *om, int B, int H, int W, hipStream_t s)
+{
+    const int grid = (int)std::min<size_t>(((size_t)B * H * W + 255) / 256, 65535 * 4);
+    om_from_nchw_kernel<<<grid, 256, 0, s>>>(off, msk, om, B, H, W);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// AdaptiveAvgPool2d(1) -> Flatten -> Linear (ema_vfi.py:83-85) and the folding of the
+// broadcast context into motion_estimation.0's bias (ema_vfi.py:124 concat eliminated).
+// Deterministic: fixed partition, fixed summation order, no atomics - shards of a batch give
+// bit-identical results on any GPU.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pool_partial_kernel(const T *__restrict__ src, float *__restrict__ part, int npix,
+                                                           int cp, int ps, int nparts)
+{
+    __shared__ float red[256];
+    const int b = blockIdx.y, part_i = blockIdx.x;
+    const int nl = 256 / cp;  // pixel lanes
+    const int c = threadIdx.x % cp, pl = threadIdx.x / cp;
+    const int per = (npix + nparts - 1) / nparts;
+    const int p0 = part_i * per, p1 = min(npix, p0 + per);
+    float s = 0.0f;
+    for (int px = p0 + pl; px < p1; px += nl) s += (float)src[((size_t)b * npix + px) * ps + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (pl == 0) {
+        for (int l = 1; l < nl; ++l) s += red[l * cp + c];
+        part[((size_t)b * nparts + part_i) * cp + c] = s;
+    }
+}
+int launch_pool_partial(const void *src, float *part, int B, int npix, int cp, int ps, int nparts, int dtype, hipStream_t s)
+{
+    dim3 grid(nparts, B);
+    if (dtype == 0) pool_partial_kernel<float><<<grid, 256, 0, s>>>((const float *)src, part, npix, cp, ps, nparts);
+    else pool_partial_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t *)src, part, npix, cp, ps, nparts);
+    return (int)hipGetLastError();
+}
+
+// One block per sample.  ctxw = [lin_w m x 4m][lin_b m][w9c m x m x 9][b9 m] (pack_ctx_kernel).
+// Writes ctx[b][m] and the border-class bias table R[b][16][coutpad]:
+//   R[cls][o] = b9[o] + sum over taps (ky,kx) inside the image for that class of
+//               sum_c W9[o, m + c, ky, kx] * ctx[c]
+// cls = ym*4 + xm; bit0 of ym: row y-1 exists, bit1: row y+1 exists (same for xm / columns).
+__global__ __launch_bounds__(256) void ctx_finish_kernel(const float *__restrict__ part, const float *__restrict__ ctxw,
+                                                         float *__restrict__ ctx_out, float *__restrict__ table,
+                                                         int m, int cp, int nparts, int npix, int coutpad)
+{
+    extern __shared__ float sm[];
+    float *mean = sm, *ctx = sm + 4 * m, *tsum = ctx + m;  // tsum [m][9]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float *lw = ctxw, *lb = lw + (size_t)m * 4 * m, *w9 = lb + m, *b9 = w9 + (size_t)m * m * 9;
+    for (int c = tid; c < 4 * m; c += 256) {
+        float s = 0.0f;
+        for (int q = 0; q < nparts; ++q) s += part[((size_t)b * nparts + q) * cp + c];
+        mean[c] = s / (float)npix;
+    }
+    __syncthreads();
+    for (int o = tid; o < m; o += 256) {
+        float s = lb[o];
+        for (int c = 0; c < 4 * m; ++c) s = fmaf(lw[(size_t)o * 4 * m + c], mean[c], s);
+        ctx[o] = s;
+        ctx_out[(size_t)b * m + o] = s;
+    }
+    __syncthreads();
+    for (int k = tid; k < m * 9; k += 256) {
+        const int o = k / 9, tap = k - o * 9;
+        float s = 0.0f;
+        for (int c = 0; c < m; ++c) s = fmaf(w9[((size_t)o * m + c) * 9 + tap], ctx[c], s);
+        tsum[k] = s;
+    }
+    __syncthreads();
+    for (int k = tid; k < 16 * coutpad; k += 256) {
+        const int cls = k / coutpad, o = k - cls * coutpad;
+        float s = 0.0f;
+        if (o < m) {
+            const int ym = cls >> 2, xm = cls & 3;
+            s = b9[o];
+            for (int ky = 0; ky < 3; ++ky) {
+                if ((ky == 0 && !(ym & 1)) || (ky == 2 && !(ym & 2))) continue;
+                for (int kx = 0; kx < 3; ++kx) {
+                    if ((kx == 0 && !(xm & 1)) || (kx == 2 && !(xm & 2))) continue;
+                    s += tsum[o * 9 + ky * 3 + kx];
+                }
+            }
+        }
+        table[((size_t)b * 16 + cls) * coutpad + o] = s;
+    }
+}
+int launch_ctx_finish(const float *part, const float *ctxw, float *ctx_out, float *table, int B, int m, int cp, int nparts,
+                      int npix, int coutpad, hipStream_t s)
+{
+    const size_t sh = (size_t)(4 * m + m + 9 * m) * sizeof(float);
+    ctx_finish_kernel<<<B, 256, sh, s>>>(part, ctxw, ctx_out, table, m, cp, nparts, npix, coutpad);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward bilinear warp = EMA_VFI.warp (ema_vfi.py:149-171).  The grid the reference builds on
+// the host (:153-160), the add (:162), the normalisation (:165-166, true fp32 division) and
+// ATen's grid_sampler_2d (un-normalise, floor, four masked taps) are one kernel; the operation
+// order of the coordinate math is kept exactly, because sampling directly at x+flow differs from
+// the reference by up to 5e-4 at 720p.  Compiled without fast-math.
+// ------------------------------------------------------------------------------------------
+struct WarpTap { int o00, o01, o10, o11; float nw, ne, sw, se; };
+
+__device__ __forceinline__ WarpTap warp_tap(int x, int y, float fx, float fy, int H, int W, float wden, float hden)
+{
+    const float vx = (float)x + fx, vy = (float)y + fy;
+    const float gx = 2.0f * vx / wden - 1.0f;
+    const float gy = 2.0f * vy / hden - 1.0f;
+    const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
+    const float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
+    const float xw = floorf(ix), yn = floorf(iy);
+    const float w = ix - xw, e = 1.0f - w, n = iy - yn, s = 1.0f - n;
+    // range tests in float: NaN / inf coordinates fail all of them -> 0
+    const bool x0 = xw >= 0.0f && xw <= (float)(W - 1), x1 = xw + 1.0f >= 0.0f && xw + 1.0f <= (float)(W - 1);
+    const bool y0 = yn >= 0.0f && yn <= (float)(H - 1), y1 = yn + 1.0f >= 0.0f && yn + 1.0f <= (float)(H - 1);
+    const int xi = x0 ? (int)xw : (x1 ? (int)xw : 0), yi = y0 ? (int)yn : (y1 ? (int)yn : 0);
+    const int xa = max(xi, 0), xb = min(xi + 1, W - 1), ya = max(yi, 0), yb = min(yi + 1, H - 1);
+    WarpTap t;
+    t.o00 = ya * W + xa; t.o01 = ya * W + xb; t.o10 = yb * W + xa; t.o11 = yb * W + xb;
+    t.nw = (y0 && x0) ? s * e : 0.0f;
+    t.ne = (y0 && x1) ? s * w : 0.0f;
+    t.sw = (y1 && x0) ? n * e : 0.0f;
+    t.se = (y1 && x1) ? n * w : 0.0f;
+    return t;
+}
+__device__ __forceinline__ float warp_sample(const float *__restrict__ p, const WarpTap &t)
+{
+    // accumulation order nw, ne, sw, se as ATen's CPU kernel
+    float a = p[t.o00] * t.nw;
+    a += p[t.o01] * t.ne;
+    a += p[t.o10] * t.sw;
+    a += p[t.o11] * t.se;
+    return a;
+}
+
+// NCHW -> NCHW (the C-ABI emavfi_warp; 32 algorithmic bytes per pixel at C = 3).
+// One thread = 4 consecutive pixels of a row: 16-byte flow loads and output stores.
+template <bool VEC4>
+__global__ __launch_bounds__(256) void warp_nchw_kernel(const float *__restrict__ frame2, const float *__restrict__ flow,
+                                                        float *__restrict__ out, int B, int C, int H, int W)
+{
+    const size_t plane = (size_t)H * W;
+    const float wden = (float)max(W - 1, 1), hden = (float)max(H - 1, 1);
+    constexpr int V = VEC4 ? 4 : 1;
+    const size_t nitem = (size_t)B * plane / V;
+    for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < nitem; it += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = it * V;
+        const size_t b = i / plane, pix = i - b * plane;
+        const int y = (int)(pix / W), x = (int)(pix - (size_t)y * W);
+        float fx[V], fy[V];
+        if (VEC4) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(flow + (b * 2) * plane + pix);
+            const f32x4 c = *reinterpret_cast<const f32x4 *>(flow + (b * 2 + 1) * plane + pix);
+#pragma unroll
+            for (int k = 0; k < V; ++k) { fx[k] = a[k]; fy[k] = c[k]; }
+        } else {
+            fx[0] = flow[(b * 2) * plane + pix];
+            fy[0] = flow[(b * 2 + 1) * plane + pix];
+        }
+        WarpTap t[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) t[k] = warp_tap(x + k, y, fx[k], fy[k], H, W, wden, hden);
+        for (int c = 0; c < C; ++c) {
+            const float *p = frame2 + (b * C + c) * plane;
+            float v[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) v[k] = warp_sample(p, t[k]);
+            float *o = out + (b * C + c) * plane + pix;
+            if (VEC4) *reinterpret_cast<f32x4 *>(o) = f32x4{v[0], v[1], v[2], v[3]};
+            else o[0] = v[0];
+        }
+    }
+}
+int launch_warp_nchw(const float *frame2, const float *flow, float *out, int B, int C, int H, int W, hipStream_t s)
+{
+    const size_t n = (size_t)B * H * W;
+    if ((W & 3) == 0) {
+        const int grid = (int)std::min<size_t>((n / 4 + 255) / 256, 256 * 32);
+        warp_nchw_kernel<true><<<grid, 256, 0, s>>>(frame2, flow, out, B, C, H, W);
+    } else {
+        const int grid = (int)std::min<size_t>((n + 255) / 256, 256 * 32);
+        warp_nchw_kernel<false><<<grid, 256, 0, s>>>(frame2, flow, out, B, C, H, W);
+    }
+    return (int)hipGetLastError();
+}
+
+// Forward-path variant: writes the warped RGB straight into channels [coff, ps) of the
+// channels-last fusion buffer (the torch.cat of ema_vfi.py:134 never materialises); channels
+// past coff + C are the zero padding.
+template <typename T>
+__global__ __launch_bounds__(256) void warp_fused_kernel(const float *__restrict__ frame2, const float *__restrict__ flow,
+                                                         T *__restrict__ dst, int B, int C, int H, int W, int ps, int coff)
+{
+    const size_t plane = (size_t)H * W, total = (size_t)B * plane;
+    const float wden = (float)max(W - 1, 1), hden = (float)max(H - 1, 1);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / plane, pix = i - b * plane;
+        const int y = (int)(pix / W), x = (int)(pix - (size_t)y * W);
+        const WarpTap t = warp_tap(x, y, flow[(b * 2) * plane + pix], flow[(b * 2 + 1) * plane + pix], H, W, wden, hden);
+        T *o = dst + i * ps + coff;
+        for (int c = 0; c < ps - coff; ++c) o[c] = (T)(c < C ? warp_sample(frame2 + (b * C + c) * plane, t) : 0.0f);
+    }
+}
+int launch_warp_fused(const float *frame2, const float *flow, void *dst, int B, int C, int H, int W, int ps, int coff, int dtype,
+                      hipStream_t s)
+{
+    const int grid = (int)std::min<size_t>(((size_t)B * H * W + 255) / 256, 256 * 64);
+    if (dtype == 0) warp_fused_kernel<float><<<grid, 256, 0, s>>>(frame2, flow, (float *)dst, B, C, H, W, ps, coff);
+    else warp_fused_kernel<bf16_t><<<grid, 256, 0, s>>>(frame2, flow, (bf16_t *)dst, B, C, H, W, ps, coff);
+    return (int)hipGetLastError();
+}

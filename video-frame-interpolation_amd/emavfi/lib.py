@@ -1,0 +1,173 @@
+"""ctypes binding of libemavfi.so (C-ABI: include/emavfi.h).
+
+There is deliberately no fallback: if the shared library is missing or a call
+fails, a RuntimeError is raised.  Nothing here imports the oracle.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from ctypes import c_int, c_size_t, c_void_p, c_char_p, POINTER
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_TANH01 = 0, 1, 2
+DTYPES = {"fp32": F32, "f32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16}
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("EMAVFI_LIB", os.path.join(_HERE, "lib", "libemavfi.so"))
+
+# every symbol include/emavfi.h declares: (restype, argtypes)
+_PROTOTYPES = {
+    "emavfi_version": (c_int, []),
+    "emavfi_last_error": (c_char_p, []),
+    "emavfi_supported": (c_int, [c_int] * 4),
+    "emavfi_param_count": (c_int, [c_int]),
+    "emavfi_packed_bytes": (c_size_t, [c_int] * 4),
+    "emavfi_pack_weights": (c_int, [c_int] * 3 + [POINTER(c_void_p), c_int, c_void_p, c_size_t, c_int, c_void_p]),
+    "emavfi_workspace_bytes": (c_size_t, [c_int] * 7),
+    "emavfi_forward": (c_int, [c_int] * 3 + [c_void_p] * 5 + [c_size_t] + [c_int] * 4 + [POINTER(c_void_p), c_void_p]),
+    "emavfi_warp": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
+    "emavfi_conv3x3_workspace_bytes": (c_size_t, [c_int] * 7),
+    "emavfi_conv3x3": (c_int, [c_void_p] * 4 + [c_int] * 8 + [c_void_p, c_size_t, c_void_p]),
+    "emavfi_deform_conv2d_workspace_bytes": (c_size_t, [c_int] * 6),
+    "emavfi_deform_conv2d": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
+}
+SYMBOLS = tuple(_PROTOTYPES)
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load() -> ctypes.CDLL:
+    """Load libemavfi.so once; raise loudly if it is not built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        f"libemavfi.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; "
+                        "g.build()'` or `make -C video-frame-interpolation_amd/csrc` (hipcc, gfx950). "
+                        "There is no CPU or PyTorch fallback for this path.")
+                lib = ctypes.CDLL(LIB_PATH)
+                for name, (res, args) in _PROTOTYPES.items():
+                    fn = getattr(lib, name)
+                    fn.restype, fn.argtypes = res, args
+                _lib = lib
+    return _lib
+
+
+def last_error() -> str:
+    return (load().emavfi_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        raise RuntimeError(f"{what} failed ({code}): {last_error()}")
+
+
+def dtype_code(name) -> int:
+    if isinstance(name, int):
+        return name
+    try:
+        return DTYPES[str(name).lower()]
+    except KeyError:
+        raise ValueError(f"compute dtype must be one of {sorted(DTYPES)}, got {name!r}") from None
+
+
+def _stream():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("emavfi: tensors must live on a ROCm device (MI355X); "
+                               "this build has no CPU path - use the reference or the oracle for CPU runs")
+
+
+def _f32c(t):
+    import torch
+    return t.detach().to(torch.float32).contiguous()
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes: int, device):
+    """Grow-only per-device scratch buffer (caller-owned memory, as the C-ABI requires)."""
+    import torch
+    key = (device.type, device.index)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        _ws_cache.pop(key, None)
+        buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def release_workspaces():
+    _ws_cache.clear()
+
+
+# ---------------------------------------------------------------- operator-level wrappers
+def warp(frame2, flow):
+    """EMA_VFI.warp (reference ema_vfi.py:149-171) on the GPU."""
+    import torch
+    _require_cuda(frame2, flow)
+    f2, fl = _f32c(frame2), _f32c(flow)
+    B, C, H, W = f2.shape
+    if fl.shape != (B, 2, H, W):
+        raise ValueError(f"flow must be [B,2,H,W] = {(B, 2, H, W)}, got {tuple(fl.shape)}")
+    out = torch.empty_like(f2)
+    with torch.cuda.device(f2.device):
+        check(load().emavfi_warp(f2.data_ptr(), fl.data_ptr(), out.data_ptr(), B, C, H, W, _stream()), "emavfi_warp")
+    return out
+
+
+def conv3x3(x, weight, bias, stride=1, act=ACT_NONE, dtype="fp32"):
+    """One conv / conv_block of the reference (ema_vfi.py:7-14)."""
+    import torch
+    _require_cuda(x, weight, bias)
+    dt = dtype_code(dtype)
+    x, w = _f32c(x), _f32c(weight)
+    b = _f32c(bias) if bias is not None else torch.zeros(w.shape[0], device=x.device)
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    if tuple(w.shape) != (Cout, Cin, 3, 3):
+        raise ValueError(f"weight must be [Cout,{Cin},3,3], got {tuple(w.shape)}")
+    L = load()
+    n = L.emavfi_conv3x3_workspace_bytes(B, Cin, Cout, H, W, stride, dt)
+    if n == 0:
+        raise RuntimeError(f"emavfi_conv3x3: {last_error()}")
+    ws = workspace(n, x.device)
+    y = torch.empty(B, Cout, (H + stride - 1) // stride, (W + stride - 1) // stride, device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        check(L.emavfi_conv3x3(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), B, Cin, Cout, H, W, stride, act, dt,
+                               ws.data_ptr(), ws.numel(), _stream()), "emavfi_conv3x3")
+    return y
+
+
+def deform_conv2d(x, offset, mask, weight, bias, dtype="fp32"):
+    """torchvision.ops.deform_conv2d as configured at reference ema_vfi.py:45-51."""
+    import torch
+    _require_cuda(x, offset, mask, weight, bias)
+    dt = dtype_code(dtype)
+    x, off, msk, w = _f32c(x), _f32c(offset), _f32c(mask), _f32c(weight)
+    B, C, H, W = x.shape
+    O = w.shape[0]
+    b = _f32c(bias) if bias is not None else torch.zeros(O, device=x.device)
+    if tuple(off.shape) != (B, 18, H, W) or tuple(msk.shape) != (B, 9, H, W) or tuple(w.shape) != (O, C, 3, 3):
+        raise ValueError("deform_conv2d: offset [B,18,H,W], mask [B,9,H,W], weight [O,C,3,3] expected")
+    L = load()
+    n = L.emavfi_deform_conv2d_workspace_bytes(B, C, O, H, W, dt)
+    if n == 0:
+        raise RuntimeError(f"emavfi_deform_conv2d: {last_error()}")
+    ws = workspace(n, x.device)
+    y = torch.empty(B, O, H, W, device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        check(L.emavfi_deform_conv2d(x.data_ptr(), off.data_ptr(), msk.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(),
+                                     B, C, O, H, W, dt, ws.data_ptr(), ws.numel(), _stream()), "emavfi_deform_conv2d")
+    return y

@@ -1,0 +1,202 @@
+"""Drop-in mirror of the reference model API (reference ``src/models/ema_vfi.py``).
+
+Same names, constructor arguments, parameter names / shapes (so reference
+checkpoints load with ``strict=True``) and call signatures as the reference:
+
+* ``conv`` / ``conv_block``                      (ema_vfi.py:7-14)
+* ``ModulatedDeformConvPack``                     (ema_vfi.py:23-60)
+* ``EMA_VFI(in_channels=3, mid_channels=64, num_blocks=3)`` with
+  ``forward(frame1, frame2)`` and ``warp(frame2, feature, flow)``  (ema_vfi.py:63-171)
+
+The modules below only HOLD parameters (``nn.Conv2d`` gives the reference's
+initialisation and state_dict keys for free); every operator on the forward
+path executes in ``libemavfi.so``.  Inference only.  There is no CPU or
+PyTorch fallback: CPU tensors or a missing library raise ``RuntimeError``.
+"""
+from __future__ import annotations
+
+import math
+import os
+from collections import OrderedDict
+from ctypes import POINTER, c_void_p, cast
+
+import torch
+import torch.nn as nn
+
+from . import lib as _lib
+
+
+def conv(in_channels, out_channels, kernel_size=3, stride=1, padding=1, dilation=1, groups=1, bias=True,
+         padding_mode='zeros'):
+    """Same signature as the reference helper (ema_vfi.py:7-8)."""
+    return nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, padding_mode)
+
+
+def conv_block(in_channels, out_channels, kernel_size=3, stride=1, padding=1, dilation=1, groups=1, bias=True,
+               padding_mode='zeros', act=None):
+    """Same signature as the reference helper (ema_vfi.py:10-14): Sequential(conv, act)."""
+    return nn.Sequential(
+        conv(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding, dilation=dilation,
+             groups=groups, bias=bias, padding_mode=padding_mode),
+        act if act is not None else nn.ReLU())
+
+
+class DeformConv2d(nn.Module):
+    """Parameter holder with ``torchvision.ops.DeformConv2d``'s constructor and
+    initialisation (the class the reference imports at ema_vfi.py:18);
+    ``forward(x, offset, mask)`` runs the HIP kernel."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=1, dilation=1, groups=1, bias=True):
+        super().__init__()
+        if (kernel_size, stride, padding, dilation, groups) != (3, 1, 1, 1, 1):
+            raise NotImplementedError("emavfi DeformConv2d: only the reference's configuration "
+                                      "(3x3, stride 1, padding 1, dilation 1, groups 1) is built")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, 3, 3))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            bound = 1 / math.sqrt(in_channels * 9)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x, offset, mask=None, dtype="fp32"):
+        if mask is None:
+            mask = torch.ones(x.shape[0], 9, x.shape[2], x.shape[3], device=x.device, dtype=x.dtype)
+        return _lib.deform_conv2d(x, offset, mask, self.weight, self.bias, dtype=dtype).to(x.dtype)
+
+
+class ModulatedDeformConvPack(nn.Module):
+    """Mirror of ema_vfi.py:23-60 (note the reference ignores ``out_channels``, :27)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=1, dilation=1, groups=1, bias=True):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = in_channels
+        self.kernel_size, self.stride, self.padding, self.dilation = kernel_size, stride, padding, dilation
+        self.groups, self.bias = groups, bias
+        self.offset_conv = nn.Conv2d(self.in_channels, self.groups * 3 * kernel_size * kernel_size,
+                                     kernel_size=kernel_size, stride=stride, padding=padding, dilation=dilation, bias=True)
+        nn.init.constant_(self.offset_conv.weight, 0.)
+        nn.init.constant_(self.offset_conv.bias, 0.)
+        self.dcn_v2 = DeformConv2d(self.in_channels, self.out_channels, kernel_size=kernel_size, stride=stride,
+                                   padding=padding, dilation=dilation, bias=bias)
+
+    def forward(self, x, dtype="fp32"):
+        raw = _lib.conv3x3(x, self.offset_conv.weight, self.offset_conv.bias, dtype=dtype)
+        offset_static, mask, offset_dynamic = torch.chunk(raw, 3, dim=1)
+        offset = torch.cat((offset_static, offset_dynamic), dim=1)
+        return self.dcn_v2(x, offset, torch.sigmoid(mask), dtype=dtype)
+
+
+class EMA_VFI(nn.Module):
+    """MI355X-native EMA-VFI.  ``compute_dtype``: ``"fp32"`` (parity mode: exact-fp32 MFMA,
+    <= 1e-3 max-abs vs the reference CPU forward), ``"bf16"`` (bf16 convs, fp32 warp / offsets /
+    accumulation) or ``None`` = fp32 unless autocast is active (the reference runs its convs in
+    half precision under ``torch.cuda.amp.autocast()``, inference.py:159)."""
+
+    def __init__(self, in_channels=3, mid_channels=64, num_blocks=3, compute_dtype=None):
+        super().__init__()
+        self.in_channels = in_channels
+        self.mid_channels = mid_channels
+        self.num_blocks = num_blocks
+        self.deformable_groups = 8  # present but unused in the reference too (ema_vfi.py:70)
+        self.compute_dtype = compute_dtype if compute_dtype is not None else os.environ.get("EMAVFI_DTYPE")
+        m = mid_channels
+        self.feat_ext_conv1 = conv_block(in_channels * 2, m)
+        self.feat_ext_blocks = nn.Sequential(OrderedDict(
+            [(f'conv_block_{i}', conv_block(m, m)) for i in range(num_blocks)]))
+        self.context_encoding = nn.Sequential(
+            conv_block(m, m * 2, stride=2), conv_block(m * 2, m * 4, stride=2), conv_block(m * 4, m * 4),
+            nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(m * 4, m))
+        self.motion_estimation = nn.Sequential(conv_block(m * 2, m), conv_block(m, m), conv(m, 2))
+        self.attention_blocks = nn.ModuleList(
+            [ModulatedDeformConvPack(m + 3, m + 3, kernel_size=3, padding=1, groups=1) for _ in range(num_blocks)])
+        self.reconstruction = nn.Sequential(conv_block(m + 3, m), conv_block(m, m // 2), conv(m // 2, in_channels), nn.Tanh())
+        self._packed = {}      # dtype code -> (key, packed uint8 tensor)
+        self.last_taps = None
+
+    # ------------------------------------------------------------------ weights
+    def _ordered_params(self):
+        """Tensors in the order emavfi_pack_weights expects = the reference's registration order."""
+        return [p for _, p in self.named_parameters()]
+
+    def _weights_key(self, device):
+        return (str(device),) + tuple((p.data_ptr(), p._version) for p in self._ordered_params())
+
+    def packed_weights(self, dt: int, device):
+        """Packed blob for this dtype, re-packed lazily after load_state_dict / .to() / in-place edits."""
+        key = self._weights_key(device)
+        hit = self._packed.get(dt)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        L = _lib.load()
+        nbytes = L.emavfi_packed_bytes(self.in_channels, self.mid_channels, self.num_blocks, dt)
+        if nbytes == 0:
+            raise RuntimeError(f"EMA_VFI: {_lib.last_error()}")
+        params = [p.detach().to(device=device, dtype=torch.float32).contiguous() for p in self._ordered_params()]
+        n = L.emavfi_param_count(self.num_blocks)
+        if len(params) != n:
+            raise RuntimeError(f"EMA_VFI: expected {n} parameter tensors, module has {len(params)}")
+        blob = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        arr = (c_void_p * n)(*[p.data_ptr() for p in params])
+        with torch.cuda.device(device):
+            _lib.check(L.emavfi_pack_weights(self.in_channels, self.mid_channels, self.num_blocks,
+                                             cast(arr, POINTER(c_void_p)), n, blob.data_ptr(), nbytes, dt, _lib._stream()),
+                       "emavfi_pack_weights")
+        self._packed[dt] = (key, blob)
+        return blob
+
+    def load_packed_weights(self, dt, blob):
+        """Install an already-packed blob (e.g. received by an RCCL broadcast from rank 0)."""
+        self._packed[_lib.dtype_code(dt)] = (self._weights_key(blob.device), blob)
+
+    def _resolve_dtype(self) -> int:
+        if self.compute_dtype is not None:
+            return _lib.dtype_code(self.compute_dtype)
+        return _lib.BF16 if torch.is_autocast_enabled() else _lib.F32
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, frame1, frame2, return_taps=False):
+        if frame1.shape != frame2.shape or frame1.dim() != 4 or frame1.shape[1] != self.in_channels:
+            raise ValueError(f"EMA_VFI.forward: two [B,{self.in_channels},H,W] tensors expected, got "
+                             f"{tuple(frame1.shape)} and {tuple(frame2.shape)}")
+        if frame1.device != frame2.device:
+            raise ValueError("EMA_VFI.forward: frame1 and frame2 are on different devices")
+        _lib._require_cuda(frame1, frame2)
+        if torch.is_grad_enabled() and (frame1.requires_grad or frame2.requires_grad
+                                        or any(p.requires_grad for p in self.parameters())):
+            raise RuntimeError("EMA_VFI (MI355X-native) is inference-only: call it under torch.no_grad() "
+                               "as the reference's inference.py:158 does")
+        dev, dt = frame1.device, self._resolve_dtype()
+        f1, f2 = _lib._f32c(frame1), _lib._f32c(frame2)
+        B, C, H, W = f1.shape
+        L = _lib.load()
+        packed = self.packed_weights(dt, dev)
+        nws = L.emavfi_workspace_bytes(C, self.mid_channels, self.num_blocks, B, H, W, dt)
+        if nws == 0:
+            raise RuntimeError(f"EMA_VFI: {_lib.last_error()}")
+        ws = _lib.workspace(nws, dev)
+        out = torch.empty_like(f1)
+        taps_arg, taps = None, None
+        if return_taps:
+            m = self.mid_channels
+            taps = OrderedDict(feat=torch.empty(B, m, H, W, device=dev), ctx=torch.empty(B, m, device=dev),
+                               flow=torch.empty(B, 2, H, W, device=dev), warped=torch.empty(B, C, H, W, device=dev))
+            ptrs = [taps["feat"].data_ptr(), taps["ctx"].data_ptr(), taps["flow"].data_ptr(), taps["warped"].data_ptr(), None]
+            for i in range(self.num_blocks):
+                taps[f"fused_{i}"] = torch.empty(B, m + 3, H, W, device=dev)
+                ptrs.append(taps[f"fused_{i}"].data_ptr())
+            taps_arg = cast((c_void_p * len(ptrs))(*ptrs), POINTER(c_void_p))
+        with torch.cuda.device(dev):
+            _lib.check(L.emavfi_forward(C, self.mid_channels, self.num_blocks, packed.data_ptr(), f1.data_ptr(), f2.data_ptr(),
+                                        out.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, dt, taps_arg, _lib._stream()),
+                       "emavfi_forward")
+        out = out.to(frame1.dtype)
+        if return_taps:
+            taps["out"] = out
+            return out, taps
+        return out
+
+    def warp(self, frame2, feature, flow):
+        """Same signature as the reference (ema_vfi.py:149); ``feature`` is only a device hint there."""
+        return _lib.warp(frame2, flow).to(frame2.dtype)
