@@ -124,6 +124,23 @@ def test_deform_known_answers_on_gpu():
         assert abs(v.item() - want) <= 1e-6, (dy, y, v.item())
 
 
+def test_deform_bf16_is_deterministic_at_two_workgroups_per_cu():
+    """Regression: at 1280x720 the bf16 kernel runs two workgroups per CU; an earlier version lost
+    corner weights intermittently there (see the header of csrc/deform.inl)."""
+    g = torch.Generator().manual_seed(0)
+    H, W = 720, 1280
+    x = torch.randn(1, 67, H, W, generator=g).to(DEV)
+    off = (torch.randn(1, 18, H, W, generator=g) * 2).to(DEV)
+    msk = torch.rand(1, 9, H, W, generator=g).to(DEV)
+    w = (torch.randn(67, 67, 3, 3, generator=g) / math.sqrt(67 * 9)).to(DEV)
+    b = torch.randn(67, generator=g).to(DEV)
+    ref = lib.deform_conv2d(x, off, msk, w, b, dtype="fp32")
+    runs = [lib.deform_conv2d(x, off, msk, w, b, dtype="bf16").clone() for _ in range(4)]
+    for r in runs:
+        assert torch.equal(r, runs[0])
+        assert (r - ref).abs().max().item() <= 0.05
+
+
 def test_pack_module_matches_oracle_block():
     sd = synth.synthetic_state_dict(seed=4, mid_channels=8)
     m = make_model(sd, mid=8)

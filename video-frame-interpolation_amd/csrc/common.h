@@ -49,6 +49,15 @@ __device__ __forceinline__ void mma_kg(f32x16 &acc, const f32x4 &w, const f32x4 
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[3], x[3], acc, 0, 0, 0);
 }
 
+// Retire the MFMA chain that produces `acc` before the code that follows.  Reading one element
+// makes hipcc emit v_accvgpr_read behind the required wait states, so the wave's matrix-pipe work
+// has finished when the next instruction issues.  Why it exists: with two waves sharing a SIMD
+// (two workgroups per CU), VALU/predicate-heavy code that ran in the shadow of this wave's
+// still-queued MFMAs intermittently produced wrong values in lanes 48-63 on MI355X (measured on
+// the bf16 deformable-conv kernel: ~1e-5 of the pixels per launch, different every run, never at
+// one wave per SIMD; see DESIGN.md "MFMA shadow").  Cost: one pipeline drain (~64 cycles).
+__device__ __forceinline__ void mfma_retire(const f32x16 &acc) { asm volatile("" ::"v"(acc[0])); }
+
 // Accumulator register i of lane (r, h) is output channel (i&3) + 8*(i>>2) + 4*h of the
 // 32-channel fragment, pixel r (C/D map of the 32x32 MFMA, cdna_hip_programming.md section 3).
 __device__ __forceinline__ int acc_channel(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }

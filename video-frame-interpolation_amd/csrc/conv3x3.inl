@@ -74,7 +74,14 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvParams p)
     const char *wpass = (const char *)p.w + (size_t)pass * p.nchunk * 9 * C::WTAP;
 
     for (int chunk = 0; chunk < p.nchunk; ++chunk) {
-        if (chunk) __syncthreads();
+        if (chunk) {
+            // the staging loop below is predicate-heavy: retire the previous chunk's MFMAs first
+#pragma unroll
+            for (int m = 0; m < MF; ++m)
+#pragma unroll
+                for (int n = 0; n < NF; ++n) mfma_retire(acc[m][n]);
+            __syncthreads();
+        }
         // ---- stage the input tile (+halo) for this channel chunk ----
         for (int it = tid; it < C::IH * IW * C::PIECES; it += 256) {
             const int pix = it / C::PIECES, pc = it - pix * C::PIECES;

@@ -9,12 +9,17 @@
 // One 256-thread workgroup owns an 8x32 tile of output pixels.  Per tap:
 //   A  one thread per pixel turns (dy, dx, mask) into four clamped corner pixel indices and four
 //      corner weights (bilinear weight x mask, 0 for an invalid corner) in an LDS table -
-//      coordinates, floor and weights are fp32 in both dtypes;
+//      coordinates, floor and weights are fp32 in both dtypes.  This phase is written WITHOUT
+//      comparisons: positions are clamped with v_max/v_min and corner validity is an integer
+//      clamp to {0,1} (no lane masks live in SGPRs across the mask load's wait);
 //   B  all threads gather: one item = (pixel, 16-byte channel piece); four 16-byte loads from
 //      the channels-last input (all channels of a corner are contiguous), fp32 blend, and the
 //      blended piece goes to the LDS "deformed im2col" tile [pixel][CK];
 //   C  the tile is contracted with the tap's packed weights on the matrix cores
-//      (D[cout][pixel], same fragment scheme as conv3x3.inl).
+//      (D[cout][pixel], same fragment scheme as conv3x3.inl); the accumulator chains are
+//      retired (mfma_retire, common.h) before the next tap's phase A so that code never runs in
+//      the shadow of queued MFMAs - regression test:
+//      tests/test_gpu_parity.py::test_deform_bf16_is_deterministic_at_two_workgroups_per_cu.
 // The gather reads global memory through L1/L2 (each input pixel is re-read by ~36 corner
 // fetches of neighbouring pixels/taps; HBM sees it about once).
 #include "common.h"
@@ -99,22 +104,32 @@ __global__ __launch_bounds__(256) void deform_kernel(const DeformParams p)
             float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
             if (a_in) {
                 const float dy = om[2 * tap], dx = om[2 * tap + 1], mk = om[18 + tap];
-                const float py = (float)(ay - 1 + i) + dy;
-                const float px = (float)(ax - 1 + j) + dx;
-                if (py > -1.0f && py < (float)H && px > -1.0f && px < (float)W) {
-                    const float fy = floorf(py), fx = floorf(px);
-                    const int hl = (int)fy, wl = (int)fx, hh = hl + 1, wh = wl + 1;
-                    const float lh = py - fy, lw = px - fx, uh = 1.0f - lh, uw = 1.0f - lw;
-                    const int hlc = max(hl, 0), wlc = max(wl, 0), hhc = min(hh, H - 1), whc = min(wh, W - 1);
-                    o1 = hlc * W + wlc; o2 = hlc * W + whc; o3 = hhc * W + wlc; o4 = hhc * W + whc;
-                    w1 = (hl >= 0 && wl >= 0) ? mk * (uh * uw) : 0.f;
-                    w2 = (hl >= 0 && wh <= W - 1) ? mk * (uh * lw) : 0.f;
-                    w3 = (hh <= H - 1 && wl >= 0) ? mk * (lh * uw) : 0.f;
-                    w4 = (hh <= H - 1 && wh <= W - 1) ? mk * (lh * lw) : 0.f;
-                }
+                // Compare-free formulation: positions are clamped to [-2, size+1] (NaN -> -2), so the
+                // int conversions cannot overflow, and corner validity is an integer clamp to {0,1}.
+                // A position <= -1 or >= size makes both of its corners invalid or zero-weighted,
+                // which is exactly the operator's "outside -> 0" rule.
+                const float py = fminf(fmaxf((float)(ay - 1 + i) + dy, -2.0f), (float)(H + 1));
+                const float px = fminf(fmaxf((float)(ax - 1 + j) + dx, -2.0f), (float)(W + 1));
+                const float fy = floorf(py), fx = floorf(px);
+                const int hl = (int)fy, wl = (int)fx, hh = hl + 1, wh = wl + 1;
+                const float lh = py - fy, lw = px - fx, uh = 1.0f - lh, uw = 1.0f - lw;
+                const int hlc = min(max(hl, 0), H - 1), wlc = min(max(wl, 0), W - 1);
+                const int hhc = min(max(hh, 0), H - 1), whc = min(max(wh, 0), W - 1);
+                o1 = hlc * W + wlc; o2 = hlc * W + whc; o3 = hhc * W + wlc; o4 = hhc * W + whc;
+                const int vhl = min(max(hl + 1, 0), 1) * min(max(H - hl, 0), 1);   // 0 <= hl <= H-1
+                const int vhh = min(max(hh + 1, 0), 1) * min(max(H - hh, 0), 1);
+                const int vwl = min(max(wl + 1, 0), 1) * min(max(W - wl, 0), 1);
+                const int vwh = min(max(wh + 1, 0), 1) * min(max(W - wh, 0), 1);
+                w1 = mk * (uh * uw) * (float)(vhl * vwl);
+                w2 = mk * (uh * lw) * (float)(vhl * vwh);
+                w3 = mk * (lh * uw) * (float)(vhh * vwl);
+                w4 = mk * (lh * lw) * (float)(vhh * vwh);
             }
-            *reinterpret_cast<int4 *>(tab_i + tid * 4) = make_int4(o1, o2, o3, o4);
-            *reinterpret_cast<float4 *>(tab_w + tid * 4) = make_float4(w1, w2, w3, w4);
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            const i32x4 ti = {o1, o2, o3, o4};
+            const f32x4 tw = {w1, w2, w3, w4};
+            *reinterpret_cast<i32x4 *>(tab_i + tid * 4) = ti;
+            *reinterpret_cast<f32x4 *>(tab_w + tid * 4) = tw;
         }
         // ---- this tap's packed weights ----
         for (int idx = tid; idx < C::WVEC; idx += 256)
@@ -127,11 +142,11 @@ __global__ __launch_bounds__(256) void deform_kernel(const DeformParams p)
             const int pix = it / C::PIECES, pc = it - pix * C::PIECES;
             const int4 o = *reinterpret_cast<const int4 *>(tab_i + pix * 4);
             const float4 w = *reinterpret_cast<const float4 *>(tab_w + pix * 4);
-            const size_t ps = (size_t)p.x_ps * sizeof(T);
-            const uint4 v1 = *reinterpret_cast<const uint4 *>(gx + o.x * ps + pc * 16);
-            const uint4 v2 = *reinterpret_cast<const uint4 *>(gx + o.y * ps + pc * 16);
-            const uint4 v3 = *reinterpret_cast<const uint4 *>(gx + o.z * ps + pc * 16);
-            const uint4 v4 = *reinterpret_cast<const uint4 *>(gx + o.w * ps + pc * 16);
+            const unsigned ps = (unsigned)p.x_ps * (unsigned)sizeof(T);  // per-sample plane < 4 GiB (checked on host)
+            const uint4 v1 = *reinterpret_cast<const uint4 *>(gx + ((unsigned)o.x * ps + (unsigned)pc * 16u));
+            const uint4 v2 = *reinterpret_cast<const uint4 *>(gx + ((unsigned)o.y * ps + (unsigned)pc * 16u));
+            const uint4 v3 = *reinterpret_cast<const uint4 *>(gx + ((unsigned)o.z * ps + (unsigned)pc * 16u));
+            const uint4 v4 = *reinterpret_cast<const uint4 *>(gx + ((unsigned)o.w * ps + (unsigned)pc * 16u));
             f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
             blend_piece(lo, hi, v1, w.x, T{});
             blend_piece(lo, hi, v2, w.y, T{});
@@ -155,6 +170,12 @@ __global__ __launch_bounds__(256) void deform_kernel(const DeformParams p)
                 mma_kg(acc[0][n], wv, x0);
                 mma_kg(acc[1][n], wv, x1);
             }
+        }
+        // the next tap's phase A/B is VALU- and predicate-heavy: do not run it in the MFMA shadow
+#pragma unroll
+        for (int n = 0; n < NF; ++n) {
+            mfma_retire(acc[0][n]);
+            mfma_retire(acc[1][n]);
         }
         __syncthreads();
     }
