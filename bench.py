@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the MI355X-native EMA-VFI forward (BASELINE.json metric).
+
+One "step" = one forward pass of the hot path over one batch of synthetic frame pairs already
+resident in HBM.  Workload at any N: BASELINE.json configs[2] per GPU - batch 8 of 1280x720
+pairs, bf16 convolutions + fp32 warp (weak scaling: every rank gets its own 8 pairs; the only
+collective is one RCCL broadcast of the packed weights before the timed region).
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (largest share of device
+time), measured with HIP events recorded around every launch on the launch stream during the
+timed steps; `cpu_baseline` times the CPU oracle on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "video-frame-interpolation_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA TFLOP/s (MI355X_MICROARCH.md, chip-level table)
+PEAK_HBM_GBS = 8000.0                     # HBM3E spec peak (same table)
+FLOP_PER_PX = 1054908.0                   # whole forward, unfolded
+
+
+class Hip:
+    """hipEvent_* from the HIP runtime already loaded into this process (torch's)."""
+
+    def __init__(self):
+        path = None
+        for line in open("/proc/self/maps"):
+            if "libamdhip64" in line:
+                path = line.split()[-1]
+                break
+        self.lib = ctypes.CDLL(path or "libamdhip64.so")
+        self.lib.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        self.lib.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+        self.lib.hipEventDestroy.argtypes = [ctypes.c_void_p]
+        self.lib.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+
+    def events(self, n):
+        arr = (ctypes.c_void_p * n)()
+        for i in range(n):
+            e = ctypes.c_void_p()
+            rc = self.lib.hipEventCreate(ctypes.byref(e))
+            if rc != 0:
+                raise RuntimeError(f"hipEventCreate failed ({rc})")
+            arr[i] = e
+        return arr
+
+    def elapsed_ms(self, a, b):
+        ms = ctypes.c_float()
+        rc = self.lib.hipEventElapsedTime(ctypes.byref(ms), a, b)
+        if rc != 0:
+            raise RuntimeError(f"hipEventElapsedTime failed ({rc})")
+        return ms.value
+
+    def destroy(self, arr):
+        for e in arr:
+            self.lib.hipEventDestroy(e)
+
+
+def cpu_baseline(sd, rows, width):
+    """The oracle (CPU restatement, kind "port") on a bounded strip of the 720p workload."""
+    from emavfi import synth
+    from oracle import emavfi_oracle as oracle
+    # the GPU box exposes every host core but this job's share is 16 (gpurun process guard)
+    threads = min(os.cpu_count() or 1, int(os.environ.get("EMAVFI_CPU_THREADS", "16")))
+    torch.set_num_threads(threads)
+    f1, f2 = synth.synthetic_frames(7, 1, rows, width, "natural")
+    cpu_sd = {k: v.float().cpu() for k, v in sd.items()}
+    t0 = time.perf_counter()
+    oracle.forward(cpu_sd, f1, f2)
+    dt = time.perf_counter() - t0
+    frac = rows / 720.0
+    return {"value": round(frac / dt, 5), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"1 pair, {width}x{rows} strip ({frac:.3f} of a 1280x720 frame), fp32, oracle.forward once "
+                      f"({dt:.1f} s); value = strip fraction / time; restated deform conv, not torchvision's C++ kernel",
+            "torch": torch.__version__}
+
+
+def warp_roofline(hip, B, H, W, steps=20):
+    """The C-ABI warp kernel alone (NCHW fp32, 32 algorithmic bytes per pixel)."""
+    from emavfi import lib
+    g = torch.Generator().manual_seed(0)
+    f2 = torch.randn(B, 3, H, W, generator=g).cuda()
+    flow = (torch.randn(B, 2, H, W, generator=g) * 4).cuda()
+    for _ in range(3):
+        lib.warp(f2, flow)
+    ev = hip.events(2 * steps)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out = torch.empty_like(f2)
+    L = lib.load()
+    for i in range(steps):
+        hip.lib.hipEventRecord(ev[2 * i], stream)
+        L.emavfi_warp(f2.data_ptr(), flow.data_ptr(), out.data_ptr(), B, 3, H, W, stream)
+        hip.lib.hipEventRecord(ev[2 * i + 1], stream)
+    torch.cuda.synchronize()
+    ms = sorted(hip.elapsed_ms(ev[2 * i], ev[2 * i + 1]) for i in range(steps))[steps // 2]
+    hip.destroy(ev)
+    gbs = 32.0 * B * H * W / (ms * 1e-3) / 1e9
+    return {"kernel": "warp_nchw_kernel (emavfi_warp)", "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
+            "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "median_us": round(ms * 1e3, 2),
+            "algorithmic_bytes_per_px": 32, "pixels": B * H * W}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="frame pairs per GPU (configs[2]: 8)")
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--cpu-rows", type=int, default=360, help="rows of the 720p strip the CPU baseline runs (0 = skip)")
+    ap.add_argument("--no-events", action="store_true", help="time the plain entry point (no per-launch events)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from emavfi import EMA_VFI, lib, synth
+    B, H, W = args.batch, args.height, args.width
+    dt = lib.dtype_code(args.dtype)
+    model = EMA_VFI(compute_dtype=args.dtype).to(dev).eval()
+    sd = synth.synthetic_state_dict(seed=0)
+    nbytes = lib.load().emavfi_packed_bytes(3, 64, 3, dt)
+    if rank == 0:
+        model.load_state_dict(sd, strict=True)
+        blob = model.packed_weights(dt, dev)
+    else:
+        blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    if world > 1:  # the path's one collective: RCCL broadcast of the packed weights over xGMI
+        dist.broadcast(blob, src=0)
+        model.load_packed_weights(dt, blob)
+
+    f1, f2 = synth.fast_frames(100 + rank, B, H, W, device=dev)
+    launches = lib.forward_launches(3, 64, 3, B, H, W, args.dtype)
+    nl = len(launches)
+    hip = Hip()
+    use_events = not args.no_events
+    ev = hip.events(2 * nl * args.steps) if use_events else None
+
+    def step(i):
+        with torch.no_grad():
+            if use_events:
+                off = ctypes.cast(ctypes.addressof(ev) + 2 * nl * i * ctypes.sizeof(ctypes.c_void_p), ctypes.c_void_p)
+                return model(f1, f2, _events=(off, 2 * nl))
+            return model(f1, f2)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        with torch.no_grad():
+            model(f1, f2)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    assert torch.isfinite(out).all()
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        frames = world * B * args.steps
+        value = frames / elapsed
+        res = {"metric": "interpolated_frames_per_sec_720p_2x", "value": round(value, 2), "unit": "frames/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype if args.dtype != "fp32" else "f32",
+               "data": "synthetic",
+               "config": {"workload": f"BASELINE configs[2]: batch {B} x {W}x{H} frame pairs per GPU, "
+                                      f"{'bf16 convs + fp32 warp' if args.dtype == 'bf16' else 'fp32 MFMA convs + fp32 warp'}, "
+                                      "EMA_VFI(3,64,3), synthetic non-degenerate weights",
+                          "pairs_per_gpu": B, "height": H, "width": W, "parallelism": f"replica-dp{world}",
+                          "collectives": "one RCCL broadcast of packed weights before timing" if world > 1 else "none"},
+               "frames_per_sec_per_gpu": round(value / world, 2),
+               "forward_passes_per_sec": round(value, 2),
+               "whole_forward": {"tflops_algorithmic": round(FLOP_PER_PX * B * H * W / (ms_step * 1e-3) / 1e12, 2),
+                                 "frac_of_mfma_peak": round(FLOP_PER_PX * B * H * W / (ms_step * 1e-3) / 1e12 / PEAK[args.dtype], 4),
+                                 "flop_per_px": FLOP_PER_PX}}
+        if use_events:
+            agg = {}
+            for i in range(args.steps):
+                for j, (name, fl, by) in enumerate(launches):
+                    k = name.split(" ")[0]
+                    a = agg.setdefault(k, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0})
+                    base = 2 * (nl * i + j)
+                    a["ms"] += hip.elapsed_ms(ev[base], ev[base + 1])
+                    a["flops"] += fl
+                    a["bytes"] += by
+                    a["n"] += 1
+            total_ms = sum(a["ms"] for a in agg.values())
+            table = []
+            for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+                table.append({"kernel": k, "launches_per_step": a["n"] // args.steps, "avg_us": round(a["ms"] / a["n"] * 1e3, 1),
+                              "share": round(a["ms"] / total_ms, 4),
+                              "tflops": round(a["flops"] / (a["ms"] * 1e-3) / 1e12, 2) if a["flops"] else 0.0,
+                              "gbs": round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1)})
+            dom = table[0]
+            a = agg[dom["kernel"]]
+            is_mfma = a["flops"] / max(a["bytes"], 1.0) > PEAK[args.dtype] * 1e12 / (PEAK_HBM_GBS * 1e9)
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get(dom["kernel"])
+            if is_mfma:
+                res["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"], "peak": PEAK[args.dtype],
+                                   "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK[args.dtype], 4), "traffic": traffic,
+                                   "avg_launch_us": dom["avg_us"], "share_of_device_time": dom["share"],
+                                   "algorithmic_flops_per_launch": a["flops"] / a["n"]}
+            else:
+                res["roofline"] = {"kernel": dom["kernel"], "bound": "hbm", "achieved": dom["gbs"], "peak": PEAK_HBM_GBS,
+                                   "unit": "GB/s", "frac": round(dom["gbs"] / PEAK_HBM_GBS, 4), "traffic": traffic,
+                                   "avg_launch_us": dom["avg_us"], "share_of_device_time": dom["share"],
+                                   "algorithmic_bytes_per_launch": a["bytes"] / a["n"]}
+            res["kernels"] = table
+            res["device_ms_per_step_sum_of_kernels"] = round(total_ms / args.steps, 3)
+        if world == 1:
+            res["roofline_warp"] = warp_roofline(hip, B, H, W)
+            if args.cpu_rows > 0:
+                res["cpu_baseline"] = cpu_baseline(sd, args.cpu_rows, W)
+        print(json.dumps(res), flush=True)
+    if ev is not None:
+        hip.destroy(ev)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

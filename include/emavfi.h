@@ -93,6 +93,20 @@ int emavfi_forward(int in_channels, int mid_channels, int num_blocks, const void
                    void *workspace, size_t workspace_bytes,
                    int B, int H, int W, int dtype, float *const *taps, void *stream);
 
+/* Measurement hooks (no reference counterpart: the reference has no profiling).
+ * emavfi_forward_launches enumerates the kernel launches one forward enqueues, in order: returns
+ * their number (also when capacity == 0), and for capacity >= that number fills `names`
+ * (newline-separated, "kernel<instantiation> reference-layer"), and each launch's ALGORITHMIC
+ * flops and bytes (real, unpadded channels; every tensor touched once).
+ * emavfi_forward_profiled is emavfi_forward with launch i bracketed by hipEventRecord on
+ * events[2i] / events[2i+1] (caller-created hipEvent_t, timing enabled) on `stream`. */
+int emavfi_forward_launches(int in_channels, int mid_channels, int num_blocks, int B, int H, int W, int dtype,
+                            char *names, size_t names_bytes, double *flops, double *bytes, int capacity);
+int emavfi_forward_profiled(int in_channels, int mid_channels, int num_blocks, const void *packed,
+                            const float *frame1, const float *frame2, float *out,
+                            void *workspace, size_t workspace_bytes,
+                            int B, int H, int W, int dtype, void *const *events, int n_events, void *stream);
+
 /* EMA_VFI.warp(frame2, feature, flow), ema_vfi.py:149-171 (grid build + normalise +
  * F.grid_sample bilinear/zeros/align_corners=True), fused into one HBM-bound kernel.
  * frame2 [B,C,H,W], flow [B,2,H,W] (channel 0 = dx, 1 = dy, pixels), out [B,C,H,W]; fp32. */

@@ -8,6 +8,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <string>
+#include <vector>
 
 namespace {
 
@@ -222,12 +224,164 @@ void carve_forward(const Plan &P, Workspace &ws, FwdBuffers &f, int B, int H, in
     f.om = (float *)ws.take(px * 32 * sizeof(float));
 }
 
+// ---- launch recorder: names every kernel launch of a forward, its algorithmic work, and can
+// bracket each launch with caller-owned hipEvents on the launch stream (bench.py's roofline leg).
+struct LaunchRec { std::string name; double flops, bytes; };
+struct Recorder {
+    std::vector<LaunchRec> *recs = nullptr;  // filled when enumerating
+    void *const *events = nullptr;           // 2 per launch: start, stop
+    int n_events = 0, idx = 0;
+    bool dry = false;                        // enumerate only, launch nothing
+};
+
+const char *dtype_name(int dtype) { return dtype == EMAVFI_F32 ? "f32" : "bf16"; }
+
+std::string conv_name(const Plan &P, const Layer &L)
+{
+    char b[96];
+    snprintf(b, sizeof b, "conv3x3<%s,ck=%d,nf=%d,s=%d>", dtype_name(P.dtype), L.ck, L.nf, L.stride);
+    return b;
+}
+std::string deform_name(const Plan &P, const Layer &L)
+{
+    char b[96];
+    snprintf(b, sizeof b, "deform<%s,ck=%d,nf=%d>", dtype_name(P.dtype), L.ck, L.nf);
+    return b;
+}
+// algorithmic work of one conv launch: real (unpadded) channels, every tensor touched once
+void conv_work(const Plan &P, const Layer &L, int B, int Hin, int Win, double out_esize, double &flops, double &bytes)
+{
+    const double Ho = (Hin + L.stride - 1) / L.stride, Wo = (Win + L.stride - 1) / L.stride;
+    flops = 2.0 * 9.0 * L.cin_take * L.cout * Ho * Wo * B;
+    bytes = (double)P.esize * L.cin_take * Hin * Win * B + out_esize * L.cout * Ho * Wo * B + 9.0 * L.cin_take * L.cout * P.esize;
+}
+
 #define EMAVFI_TRY(expr, what)                                                                       \
     do {                                                                                             \
         const int e_ = (expr);                                                                       \
         if (e_ == -2) return fail(EMAVFI_E_UNSUPPORTED, "%s: no kernel instantiation", what);        \
         if (e_ != 0) return fail(EMAVFI_E_LAUNCH, "%s: %s", what, hipGetErrorString((hipError_t)e_)); \
     } while (0)
+
+#define EMAVFI_STEP(rec, label, fl, by, expr)                                                          \
+    do {                                                                                               \
+        if ((rec).recs) (rec).recs->push_back(LaunchRec{(label), (double)(fl), (double)(by)});         \
+        if (!(rec).dry) {                                                                              \
+            const bool ev_ = (rec).events && 2 * (rec).idx + 1 < (rec).n_events;                       \
+            if (ev_ && hipEventRecord((hipEvent_t)(rec).events[2 * (rec).idx], s) != hipSuccess)       \
+                return fail(EMAVFI_E_LAUNCH, "hipEventRecord failed");                                 \
+            EMAVFI_TRY(expr, "forward");                                                               \
+            if (ev_ && hipEventRecord((hipEvent_t)(rec).events[2 * (rec).idx + 1], s) != hipSuccess)   \
+                return fail(EMAVFI_E_LAUNCH, "hipEventRecord failed");                                 \
+        }                                                                                              \
+        (rec).idx++;                                                                                   \
+    } while (0)
+
+int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *packed, const float *frame1,
+                 const float *frame2, float *out, void *workspace, size_t workspace_bytes, int B, int H, int W, int dtype,
+                 float *const *taps, void *stream, Recorder &rec)
+{
+    Plan P;
+    if (!build_plan(P, in_channels, mid_channels, num_blocks, dtype)) return fail(EMAVFI_E_UNSUPPORTED, "%s", P.why);
+    if (B < 1 || H < 1 || W < 1) return fail(EMAVFI_E_ARG, "forward: B, H, W must be >= 1 (got %d, %d, %d)", B, H, W);
+    if ((size_t)B * H * W >= ((size_t)1 << 31)) return fail(EMAVFI_E_ARG, "forward: B*H*W must be < 2^31");
+    if ((size_t)H * W * P.fpad * P.esize >= ((size_t)1 << 32)) return fail(EMAVFI_E_ARG, "forward: one sample's activation plane must be < 4 GiB");
+    Workspace ws{(char *)workspace, workspace_bytes, 0};
+    FwdBuffers f;
+    carve_forward(P, ws, f, B, H, W);
+    if (!rec.dry) {
+        if (!packed || !frame1 || !frame2 || !out || !workspace) return fail(EMAVFI_E_ARG, "forward: null pointer");
+        if (!aligned16(packed) || !aligned16(workspace) || !aligned16(frame1) || !aligned16(frame2) || !aligned16(out))
+            return fail(EMAVFI_E_ARG, "forward: pointers must be 16-byte aligned");
+        if (ws.used > workspace_bytes) return fail(EMAVFI_E_WORKSPACE, "forward: workspace needs %zu bytes, got %zu", ws.used, workspace_bytes);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int mid = P.mid, C = P.in_ch;
+    const double px = (double)B * H * W, e = P.esize;
+    const size_t npx = (size_t)B * H * W;
+    double fl, by;
+
+    // --- feature extraction: cat + conv + ReLU, then num_blocks x (conv + ReLU)  (ema_vfi.py:112-116)
+    EMAVFI_STEP(rec, "pack_input", 0, px * (8.0 * C + 2.0 * C * e), launch_pack_input(frame1, frame2, f.in16, B, C, H, W, 16, dtype, s));
+    conv_work(P, P.conv1, B, H, W, e, fl, by);
+    EMAVFI_STEP(rec, conv_name(P, P.conv1) + " feat_ext_conv1", fl, by,
+                run_conv(P, P.conv1, packed, f.in16, 16, H, W, f.fA, P.p_mid, 0, P.p_mid, EPI_RELU, B, s));
+    void *cur = f.fA, *nxt = f.fB;
+    for (int i = 0; i < P.nb; ++i) {
+        const bool last = i == P.nb - 1;  // the last block writes feat straight into the fusion buffer
+        void *dst = last ? f.fu0 : nxt;
+        conv_work(P, P.blk[i], B, H, W, e, fl, by);
+        EMAVFI_STEP(rec, conv_name(P, P.blk[i]) + " feat_ext_blocks", fl, by,
+                    run_conv(P, P.blk[i], packed, cur, P.p_mid, H, W, dst, last ? P.fpad : P.p_mid, 0, P.p_mid, EPI_RELU, B, s));
+        if (!last) { void *t = cur; cur = nxt; nxt = t; }
+    }
+    if (!rec.dry && taps && taps[0]) EMAVFI_TRY(launch_cl_to_nchw(f.fu0, taps[0], B, mid, H, W, P.fpad, 0, dtype, s), "tap feat");
+
+    // --- context encoding (ema_vfi.py:120): two stride-2 convs, one conv, global mean, linear
+    conv_work(P, P.c0, B, H, W, e, fl, by);
+    EMAVFI_STEP(rec, conv_name(P, P.c0) + " context_encoding.0", fl, by,
+                run_conv(P, P.c0, packed, f.fu0, P.fpad, H, W, f.c1, f.p2, 0, f.p2, EPI_RELU, B, s));
+    conv_work(P, P.c1, B, f.H2, f.W2, e, fl, by);
+    EMAVFI_STEP(rec, conv_name(P, P.c1) + " context_encoding.1", fl, by,
+                run_conv(P, P.c1, packed, f.c1, f.p2, f.H2, f.W2, f.c2, f.p4, 0, f.p4, EPI_RELU, B, s));
+    conv_work(P, P.c2, B, f.H4, f.W4, e, fl, by);
+    EMAVFI_STEP(rec, conv_name(P, P.c2) + " context_encoding.2", fl, by,
+                run_conv(P, P.c2, packed, f.c2, f.p4, f.H4, f.W4, f.c3, f.p4, 0, f.p4, EPI_RELU, B, s));
+    EMAVFI_STEP(rec, "avg_pool_partial", 0, (double)B * f.H4 * f.W4 * 4 * mid * e,
+                launch_pool_partial(f.c3, f.part, B, f.H4 * f.W4, f.p4, f.p4, f.nparts, dtype, s));
+    EMAVFI_STEP(rec, "context_linear_fold", 0, (double)B * f.nparts * 4 * mid * 4,
+                launch_ctx_finish(f.part, (const float *)((const char *)packed + P.ctx_off), f.ctx, f.table, B, mid, f.p4,
+                                  f.nparts, f.H4 * f.W4, P.m0.coutpad, s));
+    if (!rec.dry && taps && taps[1])
+        if (hipMemcpyAsync(taps[1], f.ctx, (size_t)B * mid * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return fail(EMAVFI_E_LAUNCH, "tap ctx copy failed");
+
+    // --- motion estimation (ema_vfi.py:124-126); the broadcast-context concat is a per-border-class bias
+    conv_work(P, P.m0, B, H, W, e, fl, by);
+    EMAVFI_STEP(rec, conv_name(P, P.m0) + " motion_estimation.0(ctx folded)", fl, by,
+                run_conv(P, P.m0, packed, f.fu0, P.fpad, H, W, f.fA, P.p_mid, 0, P.p_mid, EPI_RELU, B, s, f.table));
+    conv_work(P, P.m1, B, H, W, e, fl, by);
+    EMAVFI_STEP(rec, conv_name(P, P.m1) + " motion_estimation.1", fl, by,
+                run_conv(P, P.m1, packed, f.fA, P.p_mid, H, W, f.fB, P.p_mid, 0, P.p_mid, EPI_RELU, B, s));
+    conv_work(P, P.m2, B, H, W, 4.0, fl, by);
+    EMAVFI_STEP(rec, conv_name(P, P.m2) + " motion_estimation.2(flow)", fl, by,
+                run_conv(P, P.m2, packed, f.fB, P.p_mid, H, W, nullptr, 0, 0, 0, EPI_PLANAR, B, s, nullptr, f.flow, 2));
+    if (!rec.dry && taps && taps[2])
+        if (hipMemcpyAsync(taps[2], f.flow, npx * 2 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return fail(EMAVFI_E_LAUNCH, "tap flow copy failed");
+
+    // --- warp frame2 by the flow into channels [mid, fpad) of the fusion buffer (ema_vfi.py:130,134)
+    EMAVFI_STEP(rec, std::string("warp_fused<") + dtype_name(dtype) + ">", 24.0 * px, px * (8.0 + 4.0 * C + C * e),
+                launch_warp_fused(frame2, f.flow, f.fu0, B, C, H, W, P.fpad, mid, dtype, s));
+    if (!rec.dry && taps && taps[3]) EMAVFI_TRY(launch_cl_to_nchw(f.fu0, taps[3], B, C, H, W, P.fpad, mid, dtype, s), "tap warped");
+
+    // --- multi-attention fusion: num_blocks x ModulatedDeformConvPack, no activation (ema_vfi.py:136-138)
+    void *x = f.fu0, *y = f.fu1;
+    for (int i = 0; i < P.nb; ++i) {
+        conv_work(P, P.off[i], B, H, W, 4.0, fl, by);
+        EMAVFI_STEP(rec, conv_name(P, P.off[i]) + " offset_conv", fl, by,
+                    run_conv(P, P.off[i], packed, x, P.fpad, H, W, f.om, 32, 0, 32, EPI_OM, B, s));
+        const double cf = mid + 3;
+        EMAVFI_STEP(rec, deform_name(P, P.dcn[i]) + " dcn_v2", 2.0 * 9.0 * cf * cf * px,
+                    px * (2.0 * cf * e + 27.0 * 4.0) + 9.0 * cf * cf * e,
+                    run_deform(P, P.dcn[i], packed, x, P.fpad, f.om, y, P.fpad, P.fpad, B, H, W, s));
+        if (!rec.dry && taps && taps[5 + i])
+            EMAVFI_TRY(launch_cl_to_nchw(y, taps[5 + i], B, mid + 3, H, W, P.fpad, 0, dtype, s), "tap fused");
+        void *t = x; x = y; y = t;
+    }
+
+    // --- reconstruction (ema_vfi.py:144-146)
+    conv_work(P, P.r0, B, H, W, e, fl, by);
+    EMAVFI_STEP(rec, conv_name(P, P.r0) + " reconstruction.0", fl, by,
+                run_conv(P, P.r0, packed, x, P.fpad, H, W, f.fA, P.p_mid, 0, P.p_mid, EPI_RELU, B, s));
+    conv_work(P, P.r1, B, H, W, e, fl, by);
+    EMAVFI_STEP(rec, conv_name(P, P.r1) + " reconstruction.1", fl, by,
+                run_conv(P, P.r1, packed, f.fA, P.p_mid, H, W, f.fB, f.p_half, 0, f.p_half, EPI_RELU, B, s));
+    conv_work(P, P.r2, B, H, W, 4.0, fl, by);
+    EMAVFI_STEP(rec, conv_name(P, P.r2) + " reconstruction.2(tanh)", fl, by,
+                run_conv(P, P.r2, packed, f.fB, f.p_half, H, W, nullptr, 0, 0, 0, EPI_PLANAR_TANH01, B, s, nullptr, out, C));
+    return EMAVFI_OK;
+}
 
 }  // namespace
 
@@ -301,72 +455,47 @@ int emavfi_forward(int in_channels, int mid_channels, int num_blocks, const void
                    const float *frame2, float *out, void *workspace, size_t workspace_bytes, int B, int H, int W, int dtype,
                    float *const *taps, void *stream)
 {
-    Plan P;
-    if (!build_plan(P, in_channels, mid_channels, num_blocks, dtype)) return fail(EMAVFI_E_UNSUPPORTED, "%s", P.why);
-    if (!packed || !frame1 || !frame2 || !out || !workspace) return fail(EMAVFI_E_ARG, "forward: null pointer");
-    if (B < 1 || H < 1 || W < 1) return fail(EMAVFI_E_ARG, "forward: B, H, W must be >= 1 (got %d, %d, %d)", B, H, W);
-    if ((size_t)B * H * W >= ((size_t)1 << 31) / 128) return fail(EMAVFI_E_ARG, "forward: B*H*W too large for 32-bit pixel indexing");
-    if (!aligned16(packed) || !aligned16(workspace) || !aligned16(frame1) || !aligned16(frame2) || !aligned16(out))
-        return fail(EMAVFI_E_ARG, "forward: pointers must be 16-byte aligned");
-    Workspace ws{(char *)workspace, workspace_bytes, 0};
-    FwdBuffers f;
-    carve_forward(P, ws, f, B, H, W);
-    if (ws.used > workspace_bytes) return fail(EMAVFI_E_WORKSPACE, "forward: workspace needs %zu bytes, got %zu", ws.used, workspace_bytes);
-    hipStream_t s = (hipStream_t)stream;
-    const int mid = P.mid, C = P.in_ch;
-    const size_t px = (size_t)B * H * W;
+    Recorder rec;
+    return forward_impl(in_channels, mid_channels, num_blocks, packed, frame1, frame2, out, workspace, workspace_bytes, B, H, W,
+                        dtype, taps, stream, rec);
+}
 
-    // --- feature extraction: cat + conv + ReLU, then num_blocks x (conv + ReLU)  (ema_vfi.py:112-116)
-    EMAVFI_TRY(launch_pack_input(frame1, frame2, f.in16, B, C, H, W, 16, dtype, s), "pack_input");
-    EMAVFI_TRY(run_conv(P, P.conv1, packed, f.in16, 16, H, W, f.fA, P.p_mid, 0, P.p_mid, EPI_RELU, B, s), "feat_ext_conv1");
-    void *cur = f.fA, *nxt = f.fB;
-    for (int i = 0; i < P.nb; ++i) {
-        const bool last = i == P.nb - 1;  // the last block writes feat straight into the fusion buffer
-        void *dst = last ? f.fu0 : nxt;
-        EMAVFI_TRY(run_conv(P, P.blk[i], packed, cur, P.p_mid, H, W, dst, last ? P.fpad : P.p_mid, 0, P.p_mid, EPI_RELU, B, s),
-                   "feat_ext_blocks");
-        if (!last) { void *t = cur; cur = nxt; nxt = t; }
+int emavfi_forward_profiled(int in_channels, int mid_channels, int num_blocks, const void *packed, const float *frame1,
+                            const float *frame2, float *out, void *workspace, size_t workspace_bytes, int B, int H, int W,
+                            int dtype, void *const *events, int n_events, void *stream)
+{
+    if (!events || n_events < 2) return fail(EMAVFI_E_ARG, "forward_profiled: events array required");
+    Recorder rec;
+    rec.events = events; rec.n_events = n_events;
+    return forward_impl(in_channels, mid_channels, num_blocks, packed, frame1, frame2, out, workspace, workspace_bytes, B, H, W,
+                        dtype, nullptr, stream, rec);
+}
+
+int emavfi_forward_launches(int in_channels, int mid_channels, int num_blocks, int B, int H, int W, int dtype,
+                            char *names, size_t names_bytes, double *flops, double *bytes, int capacity)
+{
+    std::vector<LaunchRec> recs;
+    Recorder rec;
+    rec.recs = &recs; rec.dry = true;
+    const int rc = forward_impl(in_channels, mid_channels, num_blocks, nullptr, nullptr, nullptr, nullptr, nullptr, 0, B, H, W,
+                                dtype, nullptr, nullptr, rec);
+    if (rc != EMAVFI_OK) return rc;
+    const int n = (int)recs.size();
+    if (capacity <= 0) return n;
+    if (capacity < n) return fail(EMAVFI_E_ARG, "forward_launches: capacity %d < %d launches", capacity, n);
+    size_t used = 0;
+    for (int i = 0; i < n; ++i) {
+        if (flops) flops[i] = recs[i].flops;
+        if (bytes) bytes[i] = recs[i].bytes;
+        if (names) {
+            if (used + recs[i].name.size() + 2 > names_bytes) return fail(EMAVFI_E_ARG, "forward_launches: names buffer too small");
+            memcpy(names + used, recs[i].name.c_str(), recs[i].name.size());
+            used += recs[i].name.size();
+            names[used++] = '\n';
+            names[used] = 0;
+        }
     }
-    if (taps && taps[0]) EMAVFI_TRY(launch_cl_to_nchw(f.fu0, taps[0], B, mid, H, W, P.fpad, 0, dtype, s), "tap feat");
-
-    // --- context encoding (ema_vfi.py:120): two stride-2 convs, one conv, global mean, linear
-    EMAVFI_TRY(run_conv(P, P.c0, packed, f.fu0, P.fpad, H, W, f.c1, f.p2, 0, f.p2, EPI_RELU, B, s), "context_encoding.0");
-    EMAVFI_TRY(run_conv(P, P.c1, packed, f.c1, f.p2, f.H2, f.W2, f.c2, f.p4, 0, f.p4, EPI_RELU, B, s), "context_encoding.1");
-    EMAVFI_TRY(run_conv(P, P.c2, packed, f.c2, f.p4, f.H4, f.W4, f.c3, f.p4, 0, f.p4, EPI_RELU, B, s), "context_encoding.2");
-    EMAVFI_TRY(launch_pool_partial(f.c3, f.part, B, f.H4 * f.W4, f.p4, f.p4, f.nparts, dtype, s), "avg-pool");
-    EMAVFI_TRY(launch_ctx_finish(f.part, (const float *)((const char *)packed + P.ctx_off), f.ctx, f.table, B, mid, f.p4,
-                                 f.nparts, f.H4 * f.W4, P.m0.coutpad, s),
-               "context linear");
-    if (taps && taps[1])
-        if (hipMemcpyAsync(taps[1], f.ctx, (size_t)B * mid * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
-            return fail(EMAVFI_E_LAUNCH, "tap ctx copy failed");
-
-    // --- motion estimation (ema_vfi.py:124-126); the broadcast-context concat is a per-border-class bias
-    EMAVFI_TRY(run_conv(P, P.m0, packed, f.fu0, P.fpad, H, W, f.fA, P.p_mid, 0, P.p_mid, EPI_RELU, B, s, f.table), "motion_estimation.0");
-    EMAVFI_TRY(run_conv(P, P.m1, packed, f.fA, P.p_mid, H, W, f.fB, P.p_mid, 0, P.p_mid, EPI_RELU, B, s), "motion_estimation.1");
-    EMAVFI_TRY(run_conv(P, P.m2, packed, f.fB, P.p_mid, H, W, nullptr, 0, 0, 0, EPI_PLANAR, B, s, nullptr, f.flow, 2), "motion_estimation.2");
-    if (taps && taps[2])
-        if (hipMemcpyAsync(taps[2], f.flow, px * 2 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
-            return fail(EMAVFI_E_LAUNCH, "tap flow copy failed");
-
-    // --- warp frame2 by the flow into channels [mid, fpad) of the fusion buffer (ema_vfi.py:130,134)
-    EMAVFI_TRY(launch_warp_fused(frame2, f.flow, f.fu0, B, C, H, W, P.fpad, mid, dtype, s), "warp");
-    if (taps && taps[3]) EMAVFI_TRY(launch_cl_to_nchw(f.fu0, taps[3], B, C, H, W, P.fpad, mid, dtype, s), "tap warped");
-
-    // --- multi-attention fusion: num_blocks x ModulatedDeformConvPack, no activation (ema_vfi.py:136-138)
-    void *x = f.fu0, *y = f.fu1;
-    for (int i = 0; i < P.nb; ++i) {
-        EMAVFI_TRY(run_conv(P, P.off[i], packed, x, P.fpad, H, W, f.om, 32, 0, 32, EPI_OM, B, s), "offset_conv");
-        EMAVFI_TRY(run_deform(P, P.dcn[i], packed, x, P.fpad, f.om, y, P.fpad, P.fpad, B, H, W, s), "dcn_v2");
-        if (taps && taps[5 + i]) EMAVFI_TRY(launch_cl_to_nchw(y, taps[5 + i], B, mid + 3, H, W, P.fpad, 0, dtype, s), "tap fused");
-        void *t = x; x = y; y = t;
-    }
-
-    // --- reconstruction (ema_vfi.py:144-146)
-    EMAVFI_TRY(run_conv(P, P.r0, packed, x, P.fpad, H, W, f.fA, P.p_mid, 0, P.p_mid, EPI_RELU, B, s), "reconstruction.0");
-    EMAVFI_TRY(run_conv(P, P.r1, packed, f.fA, P.p_mid, H, W, f.fB, f.p_half, 0, f.p_half, EPI_RELU, B, s), "reconstruction.1");
-    EMAVFI_TRY(run_conv(P, P.r2, packed, f.fB, f.p_half, H, W, nullptr, 0, 0, 0, EPI_PLANAR_TANH01, B, s, nullptr, out, C), "reconstruction.2");
-    return EMAVFI_OK;
+    return n;
 }
 
 int emavfi_warp(const float *frame2, const float *flow, float *out, int B, int C, int H, int W, void *stream)

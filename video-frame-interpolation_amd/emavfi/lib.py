@@ -27,6 +27,8 @@ _PROTOTYPES = {
     "emavfi_pack_weights": (c_int, [c_int] * 3 + [POINTER(c_void_p), c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "emavfi_workspace_bytes": (c_size_t, [c_int] * 7),
     "emavfi_forward": (c_int, [c_int] * 3 + [c_void_p] * 5 + [c_size_t] + [c_int] * 4 + [POINTER(c_void_p), c_void_p]),
+    "emavfi_forward_launches": (c_int, [c_int] * 7 + [c_char_p, c_size_t, POINTER(ctypes.c_double), POINTER(ctypes.c_double), c_int]),
+    "emavfi_forward_profiled": (c_int, [c_int] * 3 + [c_void_p] * 5 + [c_size_t] + [c_int] * 4 + [POINTER(c_void_p), c_int, c_void_p]),
     "emavfi_warp": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
     "emavfi_conv3x3_workspace_bytes": (c_size_t, [c_int] * 7),
     "emavfi_conv3x3": (c_int, [c_void_p] * 4 + [c_int] * 8 + [c_void_p, c_size_t, c_void_p]),
@@ -171,3 +173,18 @@ def deform_conv2d(x, offset, mask, weight, bias, dtype="fp32"):
         check(L.emavfi_deform_conv2d(x.data_ptr(), off.data_ptr(), msk.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(),
                                      B, C, O, H, W, dt, ws.data_ptr(), ws.numel(), _stream()), "emavfi_deform_conv2d")
     return y
+
+
+def forward_launches(in_channels, mid_channels, num_blocks, B, H, W, dtype):
+    """[(name, algorithmic_flops, algorithmic_bytes)] for every kernel launch of one forward."""
+    L = load()
+    dt = dtype_code(dtype)
+    n = L.emavfi_forward_launches(in_channels, mid_channels, num_blocks, B, H, W, dt, None, 0, None, None, 0)
+    if n < 0:
+        raise RuntimeError(f"emavfi_forward_launches: {last_error()}")
+    names = ctypes.create_string_buffer(128 * n)
+    fl, by = (ctypes.c_double * n)(), (ctypes.c_double * n)()
+    check(min(0, L.emavfi_forward_launches(in_channels, mid_channels, num_blocks, B, H, W, dt, names, len(names), fl, by, n)),
+          "emavfi_forward_launches")
+    labels = names.value.decode().strip().split("\n")
+    return [(labels[i], fl[i], by[i]) for i in range(n)]

@@ -156,7 +156,7 @@ class EMA_VFI(nn.Module):
         return _lib.BF16 if torch.is_autocast_enabled() else _lib.F32
 
     # ------------------------------------------------------------------ forward
-    def forward(self, frame1, frame2, return_taps=False):
+    def forward(self, frame1, frame2, return_taps=False, _events=None):
         if frame1.shape != frame2.shape or frame1.dim() != 4 or frame1.shape[1] != self.in_channels:
             raise ValueError(f"EMA_VFI.forward: two [B,{self.in_channels},H,W] tensors expected, got "
                              f"{tuple(frame1.shape)} and {tuple(frame2.shape)}")
@@ -188,9 +188,15 @@ class EMA_VFI(nn.Module):
                 ptrs.append(taps[f"fused_{i}"].data_ptr())
             taps_arg = cast((c_void_p * len(ptrs))(*ptrs), POINTER(c_void_p))
         with torch.cuda.device(dev):
-            _lib.check(L.emavfi_forward(C, self.mid_channels, self.num_blocks, packed.data_ptr(), f1.data_ptr(), f2.data_ptr(),
-                                        out.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, dt, taps_arg, _lib._stream()),
-                       "emavfi_forward")
+            if _events is not None:  # bench.py: (ctypes array of hipEvent_t, count) bracketing every launch
+                _lib.check(L.emavfi_forward_profiled(C, self.mid_channels, self.num_blocks, packed.data_ptr(), f1.data_ptr(),
+                                                     f2.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, dt,
+                                                     cast(_events[0], POINTER(c_void_p)), _events[1], _lib._stream()),
+                           "emavfi_forward_profiled")
+            else:
+                _lib.check(L.emavfi_forward(C, self.mid_channels, self.num_blocks, packed.data_ptr(), f1.data_ptr(),
+                                            f2.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, dt, taps_arg,
+                                            _lib._stream()), "emavfi_forward")
         out = out.to(frame1.dtype)
         if return_taps:
             taps["out"] = out
