@@ -88,6 +88,7 @@ struct ConvParams {
     float *out_planar;  // NCHW fp32 (EPI_PLANAR*)
     const void *w;      // packed [pass][chunk][tap][kg][nf][lane][16 B]
     const float *bias;  // [npass*NF*32] or, bias_mode 1, [B][16][npass*NF*32]
+    const void *zeros;  // >= 16 bytes of zeros (source of padding / out-of-image DMA lanes)
     int in_ps, out_ps, out_coff;  // pixel strides / channel offset, in elements
     int Hin, Win, Hout, Wout, B;
     int nchunk, npass;

@@ -4,12 +4,18 @@
 //
 // One 256-thread workgroup (4 waves, one per SIMD) produces a tile of 4*MF rows x 32 columns of
 // output pixels for NF*32 output channels:
-//   * the input tile + 1-pixel halo for CK input channels is staged ONCE in LDS (zero-filled
-//     outside the image = the conv's zero padding) and re-read by all 9 taps, so HBM sees each
-//     input element about once ((TH+2)(TW+2)/(TH*TW) = 1.33x for the 8x32 tile);
-//   * the packed weights of one tap (KG*NF KiB, already in MFMA fragment order) are double
-//     buffered in LDS; the next tap's weights are fetched into registers while the current
-//     tap's MFMAs run and written behind them (one barrier per tap);
+//   * the input tile + 1-pixel halo for CK input channels is staged ONCE in LDS and re-read by
+//     all 9 taps, so HBM sees each input element about once ((TH+2)(TW+2)/(TH*TW) = 1.33x for
+//     the 8x32 tile).  Staging is direct global->LDS DMA (global_load_lds_dwordx4, 16 B per
+//     lane): the LDS image is slot-linear ([pixel][SP 16-byte slots], the last slot of a pixel
+//     is padding) so a wave-instruction's 64 lanes write 1 KiB contiguously while each lane's
+//     SOURCE address is computed per slot; lanes that map to padding or to pixels outside the
+//     image (the conv's zero padding) read a 16-byte zero page.  All of a wave's DMA
+//     instructions are in flight together (the first version staged through registers with
+//     one load in flight per thread: 11 serialized L2/HBM round trips per tile);
+//   * the packed weights of one tap (KG*NF KiB, already in MFMA fragment order = lane-linear,
+//     exactly what the DMA writes) are double buffered in LDS: the next tap's weights are DMA'd
+//     while the current tap's MFMAs run (one barrier per tap);
 //   * a wave owns MF rows of 32 pixels (MF pixel fragments) x NF channel fragments:
 //     D[cout][pixel] accumulates in MF*NF 32x32 fp32 tiles.
 // LDS pixel stride is an odd number of 16-byte slots (LdsPix), so the ds_read_b128 operand
@@ -25,9 +31,11 @@ template <typename T, int CK, int NF, int S> struct ConvCfg {
     static constexpr int PIECES = CK * (int)sizeof(T) / 16;
     static constexpr int KG = CK / D::CHKG;
     static constexpr int WTAP = KG * NF * 1024;  // bytes of packed weights per tap
-    static constexpr int WVEC = KG * NF * 64;    // 16-byte vectors per tap
-    static constexpr int WPT = (WVEC + 255) / 256;
-    static constexpr int LDS_IN = IH * IW * PSTR;
+    static constexpr int WINST = KG * NF;        // 1-KiB DMA wave-instructions per tap
+    static constexpr int SP = PSTR / 16;         // 16-byte slots per staged pixel (last = padding)
+    static constexpr int NSLOT = IH * IW * SP;
+    static constexpr int NINST = (NSLOT + 63) / 64;  // DMA wave-instructions per input tile
+    static constexpr int LDS_IN = NINST * 1024;
     static constexpr int LDS_BYTES = LDS_IN + 2 * WTAP;
     static_assert(CK % D::CHKG == 0, "CK must be a whole number of k-groups");
     static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the 160 KiB LDS");
@@ -73,44 +81,53 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvParams p)
     const char *gin = (const char *)p.in + (size_t)b * p.Hin * p.Win * p.in_ps * sizeof(T);
     const char *wpass = (const char *)p.w + (size_t)pass * p.nchunk * 9 * C::WTAP;
 
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    const char *zeros = (const char *)p.zeros;
+
     for (int chunk = 0; chunk < p.nchunk; ++chunk) {
         if (chunk) {
-            // the staging loop below is predicate-heavy: retire the previous chunk's MFMAs first
+            // the staging code below is predicate-heavy: retire the previous chunk's MFMAs first
 #pragma unroll
             for (int m = 0; m < MF; ++m)
 #pragma unroll
                 for (int n = 0; n < NF; ++n) mfma_retire(acc[m][n]);
             __syncthreads();
         }
-        // ---- stage the input tile (+halo) for this channel chunk ----
-        for (int it = tid; it < C::IH * IW * C::PIECES; it += 256) {
-            const int pix = it / C::PIECES, pc = it - pix * C::PIECES;
-            const int ly = pix / IW, lx = pix - ly * IW;
-            const int gy = iy0 + ly, gx = ix0 + lx;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win)
-                v = *reinterpret_cast<const uint4 *>(
-                    gin + ((size_t)gy * p.Win + gx) * p.in_ps * sizeof(T) + (size_t)chunk * CK * sizeof(T) + pc * 16);
-            *reinterpret_cast<uint4 *>(lds_in + pix * PSTR + pc * 16) = v;
+        // ---- DMA the input tile (+halo) for this channel chunk, and tap 0's weights ----
+        const char *gchunk = gin + (size_t)chunk * CK * sizeof(T);
+#pragma unroll
+        for (int i = 0; i < (C::NINST + 3) / 4; ++i) {
+            const int j = i * 4 + wave;
+            if (j < C::NINST) {
+                const int sl = j * 64 + lane;
+                const int pix = sl / C::SP, pc = sl - pix * C::SP;
+                const int ly = pix / IW, lx = pix - ly * IW;
+                const int gy = iy0 + ly, gx = ix0 + lx;
+                const bool ok = sl < C::NSLOT && pc < C::PIECES && gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
+                const char *src = ok ? gchunk + ((size_t)gy * p.Win + gx) * p.in_ps * sizeof(T) + pc * 16 : zeros;
+                __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)(lds_in + j * 1024), 16, 0, 0);
+            }
         }
         const char *wc = wpass + (size_t)chunk * 9 * C::WTAP;
 #pragma unroll
-        for (int i = 0; i < C::WPT; ++i) {
-            const int idx = tid + i * 256;
-            if (idx < C::WVEC)
-                *reinterpret_cast<uint4 *>(lds_w + idx * 16) = *reinterpret_cast<const uint4 *>(wc + idx * 16);
+        for (int i = 0; i < (C::WINST + 3) / 4; ++i) {
+            const int j = i * 4 + wave;
+            if (j < C::WINST)
+                __builtin_amdgcn_global_load_lds((gptr_t *)(wc + j * 1024 + lane * 16), (lptr_t *)(lds_w + j * 1024), 16, 0, 0);
         }
-        __syncthreads();
+        __syncthreads();  // hipcc drains the DMA (vmcnt(0)) ahead of the barrier
 
         int cur = 0;
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
-            uint4 wr[C::WPT];
-            if (tap < 8) {
+            if (tap < 8) {  // next tap's weights -> the other buffer, asynchronously
 #pragma unroll
-                for (int i = 0; i < C::WPT; ++i) {
-                    const int idx = tid + i * 256;
-                    if (idx < C::WVEC) wr[i] = *reinterpret_cast<const uint4 *>(wc + (tap + 1) * C::WTAP + idx * 16);
+                for (int i = 0; i < (C::WINST + 3) / 4; ++i) {
+                    const int j = i * 4 + wave;
+                    if (j < C::WINST)
+                        __builtin_amdgcn_global_load_lds((gptr_t *)(wc + (size_t)(tap + 1) * C::WTAP + j * 1024 + lane * 16),
+                                                         (lptr_t *)(lds_w + (cur ^ 1) * C::WTAP + j * 1024), 16, 0, 0);
                 }
             }
             const int dy = tap / 3, dx = tap - 3 * dy;
@@ -132,12 +149,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvParams p)
                 }
             }
             if (tap < 8) {
-#pragma unroll
-                for (int i = 0; i < C::WPT; ++i) {
-                    const int idx = tid + i * 256;
-                    if (idx < C::WVEC) *reinterpret_cast<uint4 *>(lds_w + (cur ^ 1) * C::WTAP + idx * 16) = wr[i];
-                }
-                __syncthreads();
+                __syncthreads();  // drains this tap's weight DMA; everyone is done with buffer `cur`
                 cur ^= 1;
             }
         }

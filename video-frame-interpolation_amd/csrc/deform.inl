@@ -6,80 +6,122 @@
 //   py = y - 1 + i + dy_k(y,x),  px = x - 1 + j + dx_k(y,x)
 //   bilin = 0 when py <= -1 || py >= H || px <= -1 || px >= W; corners outside the image add 0.
 //
-// One 256-thread workgroup owns an 8x32 tile of output pixels.  Per tap:
-//   A  one thread per pixel turns (dy, dx, mask) into four clamped corner pixel indices and four
-//      corner weights (bilinear weight x mask, 0 for an invalid corner) in an LDS table -
-//      coordinates, floor and weights are fp32 in both dtypes.  This phase is written WITHOUT
-//      comparisons: positions are clamped with v_max/v_min and corner validity is an integer
-//      clamp to {0,1} (no lane masks live in SGPRs across the mask load's wait);
-//   B  all threads gather: one item = (pixel, 16-byte channel piece); four 16-byte loads from
-//      the channels-last input (all channels of a corner are contiguous), fp32 blend, and the
-//      blended piece goes to the LDS "deformed im2col" tile [pixel][CK];
-//   C  the tile is contracted with the tap's packed weights on the matrix cores
-//      (D[cout][pixel], same fragment scheme as conv3x3.inl); the accumulator chains are
-//      retired (mfma_retire, common.h) before the next tap's phase A so that code never runs in
-//      the shadow of queued MFMAs - regression test:
-//      tests/test_gpu_parity.py::test_deform_bf16_is_deterministic_at_two_workgroups_per_cu.
+// One 256-thread workgroup owns an 8x32 tile of output pixels; wave w owns rows 2w and 2w+1
+// (two 32-pixel MFMA fragments).  The contraction is D[cout][pixel] += W_k[cout][c] * S_k[c][pixel]
+// with S_k the bilinearly sampled, mask-scaled input of tap k.  The MFMA B operand of lane (r, h)
+// for k-group kg is exactly "pixel r, channels kg*CHKG + h*EPV .. +EPV" - one contiguous 16-byte
+// piece of a channels-last pixel - so every lane GATHERS AND BLENDS ITS OWN OPERAND FRAGMENT in
+// registers: four 16-byte corner loads, an fp32 blend with the corner weights, a pack to T, and
+// the result feeds the matrix core directly.  There is no LDS "deformed im2col" tile and no
+// sampling-table round trip; LDS only holds the tap's packed weights (double buffered, one
+// barrier per tap).  Sampling positions, floor and corner weights are fp32 in both dtypes and
+// are computed without comparisons (clamps), so no lane masks are held across memory waits.
+//
+// Scheduling rule (common.h, mfma_retire): a wave never runs its VALU-heavy gather in the shadow
+// of its own queued MFMAs - each batch's accumulator chains are retired before the next gather
+// starts.  The overlap of VALU (gather/blend) with the matrix pipe comes from the partner wave
+// on the SIMD (two workgroups per CU).  Regression test for the failure this prevents:
+// tests/test_gpu_parity.py::test_deform_bf16_is_deterministic_at_two_workgroups_per_cu.
+//
 // The gather reads global memory through L1/L2 (each input pixel is re-read by ~36 corner
-// fetches of neighbouring pixels/taps; HBM sees it about once).
+// fetches of neighbouring pixels / taps; HBM sees it about once).
 #include "common.h"
 
 template <typename T, int CK, int NF> struct DeformCfg {
     using D = DT<T>;
-    static constexpr int NPIX = 256;
-    static constexpr int PSTR = LdsPix<T, CK>::BYTES;
-    static constexpr int PIECES = CK * (int)sizeof(T) / 16;
     static constexpr int KG = CK / D::CHKG;
     static constexpr int WTAP = KG * NF * 1024;
     static constexpr int WVEC = KG * NF * 64;
-    static constexpr int LDS_S = NPIX * PSTR;
-    static constexpr int LDS_TAB = NPIX * 32;  // 4 int + 4 float per pixel
-    static constexpr int LDS_BYTES = LDS_S + LDS_TAB + WTAP;
-    static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the 160 KiB LDS");
+    static constexpr int WPT = (WVEC + 255) / 256;
+    static constexpr int LDS_BYTES = 2 * WTAP;
+    // prefetch the next tap's weights through registers only while that costs <= 16 VGPRs
+    static constexpr bool PREFETCH = WPT <= 4;
+    // k-groups gathered per batch: bounds the registers holding loads in flight (16 per k-group)
+    static constexpr int KB = (KG % 5 == 0) ? 5 : ((KG % 4 == 0) ? 4 : ((KG % 3 == 0) ? 3 : ((KG % 2 == 0) ? 2 : 1)));
+    static_assert(KG % KB == 0, "k-group batch must divide KG");
+    static_assert(LDS_BYTES <= 160 * 1024, "weights do not fit the 160 KiB LDS");
 };
 
-__device__ __forceinline__ void blend_piece(f32x4 &lo, f32x4 &hi, const uint4 &raw, float w, bf16_t)
+struct SampleTap {
+    unsigned o[4];  // byte offsets of the four (clamped) corner pixels inside this sample's plane
+    float w[4];     // bilinear weight x mask, 0 for a corner outside the image
+};
+
+// Compare-free: positions are clamped to [-2, size+1] (NaN -> -2), so the int conversions cannot
+// overflow, and corner validity is an integer clamp to {0,1}.  A position <= -1 or >= size makes
+// both of its corners invalid or zero-weighted = the operator's "outside -> 0" rule.
+__device__ __forceinline__ SampleTap sample_tap(const float *__restrict__ om, int tap, int y, int x, int H, int W,
+                                                unsigned ps_bytes, bool in_image, int *yc0 = nullptr, int *yc1 = nullptr,
+                                                int *xc0 = nullptr, int *xc1 = nullptr)
 {
-    const bf16x8 v = __builtin_bit_cast(bf16x8, raw);
+    SampleTap t;
+    const int i = tap / 3, j = tap - 3 * i;
+    const float dy = om[2 * tap], dx = om[2 * tap + 1], mk = in_image ? om[18 + tap] : 0.0f;
+    const float py = fminf(fmaxf((float)(y - 1 + i) + dy, -2.0f), (float)(H + 1));
+    const float px = fminf(fmaxf((float)(x - 1 + j) + dx, -2.0f), (float)(W + 1));
+    const float fy = floorf(py), fx = floorf(px);
+    const int hl = (int)fy, wl = (int)fx, hh = hl + 1, wh = wl + 1;
+    const float lh = py - fy, lw = px - fx, uh = 1.0f - lh, uw = 1.0f - lw;
+    const int hlc = min(max(hl, 0), H - 1), wlc = min(max(wl, 0), W - 1);
+    const int hhc = min(max(hh, 0), H - 1), whc = min(max(wh, 0), W - 1);
+    if (yc0) { *yc0 = hlc; *yc1 = hhc; *xc0 = wlc; *xc1 = whc; }  // clamped corner coordinates
+    t.o[0] = (unsigned)(hlc * W + wlc) * ps_bytes;
+    t.o[1] = (unsigned)(hlc * W + whc) * ps_bytes;
+    t.o[2] = (unsigned)(hhc * W + wlc) * ps_bytes;
+    t.o[3] = (unsigned)(hhc * W + whc) * ps_bytes;
+    const int vhl = min(max(hl + 1, 0), 1) * min(max(H - hl, 0), 1);  // 0 <= hl <= H-1
+    const int vhh = min(max(hh + 1, 0), 1) * min(max(H - hh, 0), 1);
+    const int vwl = min(max(wl + 1, 0), 1) * min(max(W - wl, 0), 1);
+    const int vwh = min(max(wh + 1, 0), 1) * min(max(W - wh, 0), 1);
+    t.w[0] = mk * (uh * uw) * (float)(vhl * vwl);
+    t.w[1] = mk * (uh * lw) * (float)(vhl * vwh);
+    t.w[2] = mk * (lh * uw) * (float)(vhh * vwl);
+    t.w[3] = mk * (lh * lw) * (float)(vhh * vwh);
+    return t;
+}
+
+// fp32 blend of four 16-byte corner pieces -> one MFMA operand fragment
+__device__ __forceinline__ bf16x8 blend4(const uint4 (&v)[4], const float (&w)[4], bf16_t)
+{
+    float a[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        lo[j] = fmaf(w, (float)v[j], lo[j]);
-        hi[j] = fmaf(w, (float)v[4 + j], hi[j]);
+    for (int j = 0; j < 8; ++j) a[j] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const unsigned d[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {  // a dword holds channels 2q (low half) and 2q+1 (high half)
+            a[2 * q] = fmaf(w[c], __uint_as_float(d[q] << 16), a[2 * q]);
+            a[2 * q + 1] = fmaf(w[c], __uint_as_float(d[q] & 0xffff0000u), a[2 * q + 1]);
+        }
     }
+    return bf16x8{(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)a[4], (bf16_t)a[5], (bf16_t)a[6], (bf16_t)a[7]};
 }
-__device__ __forceinline__ void blend_piece(f32x4 &lo, f32x4 &, const uint4 &raw, float w, float)
+__device__ __forceinline__ f32x4 blend4(const uint4 (&v)[4], const float (&w)[4], float)
 {
-    const f32x4 v = __builtin_bit_cast(f32x4, raw);
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) lo[j] = fmaf(w, v[j], lo[j]);
-}
-__device__ __forceinline__ uint4 pack_piece(const f32x4 &lo, const f32x4 &hi, bf16_t)
-{
-    const bf16x8 v = {(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3],
-                      (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
-    return __builtin_bit_cast(uint4, v);
-}
-__device__ __forceinline__ uint4 pack_piece(const f32x4 &lo, const f32x4 &, float)
-{
-    return __builtin_bit_cast(uint4, lo);
+    for (int c = 0; c < 4; ++c) {
+        const f32x4 x = __builtin_bit_cast(f32x4, v[c]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = fmaf(w[c], x[j], a[j]);
+    }
+    return a;
 }
 
 template <typename T, int CK, int NF>
-__global__ __launch_bounds__(256) void deform_kernel(const DeformParams p)
+__global__ __launch_bounds__(256, 2) void deform_kernel(const DeformParams p)
 {
     using C = DeformCfg<T, CK, NF>;
     using vec = typename DT<T>::vec;
-    constexpr int PSTR = C::PSTR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *lds_s = smem;
-    int *tab_i = reinterpret_cast<int *>(smem + C::LDS_S);
-    float *tab_w = reinterpret_cast<float *>(smem + C::LDS_S + C::NPIX * 16);
-    char *lds_w = smem + C::LDS_S + C::LDS_TAB;
+    char *lds_w = smem;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int b = blockIdx.z;
     const int H = p.H, W = p.W;
+    const unsigned ps_bytes = (unsigned)p.x_ps * (unsigned)sizeof(T);  // one sample's plane is < 4 GiB (host check)
 
     f32x16 acc[2][NF];
 #pragma unroll
@@ -89,103 +131,82 @@ __global__ __launch_bounds__(256) void deform_kernel(const DeformParams p)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[m][n][i] = p.bias[n * 32 + acc_channel(i, h)];
 
-    // this thread's pixel for phase A
-    const int ay = blockIdx.y * 8 + (tid >> 5), ax = blockIdx.x * 32 + (tid & 31);
-    const bool a_in = ay < H && ax < W;
-    const float *om = p.om + (((size_t)b * H + (a_in ? ay : 0)) * W + (a_in ? ax : 0)) * 32;
-    const char *gx = (const char *)p.x + (size_t)b * H * W * p.x_ps * sizeof(T);
+    // this lane's two pixels (fragment rows m = 0, 1), shared by its h = 0 / h = 1 partner lanes
+    const int px_x = blockIdx.x * 32 + r;
+    int py_y[2];
+    bool in_img[2];
+    const float *om[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        py_y[m] = blockIdx.y * 8 + wave * 2 + m;
+        in_img[m] = py_y[m] < H && px_x < W;
+        om[m] = p.om + (((size_t)b * H + (in_img[m] ? py_y[m] : 0)) * W + (in_img[m] ? px_x : 0)) * 32;
+    }
+    const char *gx = (const char *)p.x + (size_t)b * H * W * ps_bytes + h * 16;
 
+    // tap 0 weights -> LDS buffer 0
+    for (int idx = tid; idx < C::WVEC; idx += 256)
+        *reinterpret_cast<uint4 *>(lds_w + idx * 16) = *reinterpret_cast<const uint4 *>((const char *)p.w + idx * 16);
+    __syncthreads();
+
+    int cur = 0;
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
-        // ---- A: sampling table ----
-        {
-            const int i = tap / 3, j = tap - 3 * i;
-            int o1 = 0, o2 = 0, o3 = 0, o4 = 0;
-            float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
-            if (a_in) {
-                const float dy = om[2 * tap], dx = om[2 * tap + 1], mk = om[18 + tap];
-                // Compare-free formulation: positions are clamped to [-2, size+1] (NaN -> -2), so the
-                // int conversions cannot overflow, and corner validity is an integer clamp to {0,1}.
-                // A position <= -1 or >= size makes both of its corners invalid or zero-weighted,
-                // which is exactly the operator's "outside -> 0" rule.
-                const float py = fminf(fmaxf((float)(ay - 1 + i) + dy, -2.0f), (float)(H + 1));
-                const float px = fminf(fmaxf((float)(ax - 1 + j) + dx, -2.0f), (float)(W + 1));
-                const float fy = floorf(py), fx = floorf(px);
-                const int hl = (int)fy, wl = (int)fx, hh = hl + 1, wh = wl + 1;
-                const float lh = py - fy, lw = px - fx, uh = 1.0f - lh, uw = 1.0f - lw;
-                const int hlc = min(max(hl, 0), H - 1), wlc = min(max(wl, 0), W - 1);
-                const int hhc = min(max(hh, 0), H - 1), whc = min(max(wh, 0), W - 1);
-                o1 = hlc * W + wlc; o2 = hlc * W + whc; o3 = hhc * W + wlc; o4 = hhc * W + whc;
-                const int vhl = min(max(hl + 1, 0), 1) * min(max(H - hl, 0), 1);   // 0 <= hl <= H-1
-                const int vhh = min(max(hh + 1, 0), 1) * min(max(H - hh, 0), 1);
-                const int vwl = min(max(wl + 1, 0), 1) * min(max(W - wl, 0), 1);
-                const int vwh = min(max(wh + 1, 0), 1) * min(max(W - wh, 0), 1);
-                w1 = mk * (uh * uw) * (float)(vhl * vwl);
-                w2 = mk * (uh * lw) * (float)(vhl * vwh);
-                w3 = mk * (lh * uw) * (float)(vhh * vwl);
-                w4 = mk * (lh * lw) * (float)(vhh * vwh);
-            }
-            typedef int i32x4 __attribute__((ext_vector_type(4)));
-            const i32x4 ti = {o1, o2, o3, o4};
-            const f32x4 tw = {w1, w2, w3, w4};
-            *reinterpret_cast<i32x4 *>(tab_i + tid * 4) = ti;
-            *reinterpret_cast<f32x4 *>(tab_w + tid * 4) = tw;
-        }
-        // ---- this tap's packed weights ----
-        for (int idx = tid; idx < C::WVEC; idx += 256)
-            *reinterpret_cast<uint4 *>(lds_w + idx * 16) =
-                *reinterpret_cast<const uint4 *>((const char *)p.w + (size_t)tap * C::WTAP + idx * 16);
-        __syncthreads();
-
-        // ---- B: gather + blend into the deformed-im2col tile ----
-        for (int it = tid; it < C::NPIX * C::PIECES; it += 256) {
-            const int pix = it / C::PIECES, pc = it - pix * C::PIECES;
-            const int4 o = *reinterpret_cast<const int4 *>(tab_i + pix * 4);
-            const float4 w = *reinterpret_cast<const float4 *>(tab_w + pix * 4);
-            const unsigned ps = (unsigned)p.x_ps * (unsigned)sizeof(T);  // per-sample plane < 4 GiB (checked on host)
-            const uint4 v1 = *reinterpret_cast<const uint4 *>(gx + ((unsigned)o.x * ps + (unsigned)pc * 16u));
-            const uint4 v2 = *reinterpret_cast<const uint4 *>(gx + ((unsigned)o.y * ps + (unsigned)pc * 16u));
-            const uint4 v3 = *reinterpret_cast<const uint4 *>(gx + ((unsigned)o.z * ps + (unsigned)pc * 16u));
-            const uint4 v4 = *reinterpret_cast<const uint4 *>(gx + ((unsigned)o.w * ps + (unsigned)pc * 16u));
-            f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-            blend_piece(lo, hi, v1, w.x, T{});
-            blend_piece(lo, hi, v2, w.y, T{});
-            blend_piece(lo, hi, v3, w.z, T{});
-            blend_piece(lo, hi, v4, w.w, T{});
-            *reinterpret_cast<uint4 *>(lds_s + pix * PSTR + pc * 16) = pack_piece(lo, hi, T{});
-        }
-        __syncthreads();
-
-        // ---- C: contraction ----
-        const char *xb0 = lds_s + ((wave * 2 + 0) * 32 + r) * PSTR + h * 16;
-        const char *xb1 = lds_s + ((wave * 2 + 1) * 32 + r) * PSTR + h * 16;
-        const char *wb = lds_w + lane * 16;
+        // prefetch the next tap's packed weights into registers (written to LDS behind the MFMAs)
+        uint4 wr[C::WPT];
+        if (C::PREFETCH && tap < 8) {
 #pragma unroll
-        for (int kg = 0; kg < C::KG; ++kg) {
-            const vec x0 = *reinterpret_cast<const vec *>(xb0 + kg * 32);
-            const vec x1 = *reinterpret_cast<const vec *>(xb1 + kg * 32);
-#pragma unroll
-            for (int n = 0; n < NF; ++n) {
-                const vec wv = *reinterpret_cast<const vec *>(wb + (kg * NF + n) * 1024);
-                mma_kg(acc[0][n], wv, x0);
-                mma_kg(acc[1][n], wv, x1);
+            for (int i = 0; i < C::WPT; ++i) {
+                const int idx = tid + i * 256;
+                if (idx < C::WVEC) wr[i] = *reinterpret_cast<const uint4 *>((const char *)p.w + (size_t)(tap + 1) * C::WTAP + idx * 16);
             }
         }
-        // the next tap's phase A/B is VALU- and predicate-heavy: do not run it in the MFMA shadow
+        const char *wb = lds_w + cur * C::WTAP + lane * 16;
 #pragma unroll
-        for (int n = 0; n < NF; ++n) {
-            mfma_retire(acc[0][n]);
-            mfma_retire(acc[1][n]);
+        for (int m = 0; m < 2; ++m) {
+            const SampleTap st = sample_tap(om[m], tap, py_y[m], px_x, H, W, ps_bytes, in_img[m]);
+#pragma unroll
+            for (int k0 = 0; k0 < C::KG; k0 += C::KB) {
+                uint4 v[C::KB][4];
+#pragma unroll
+                for (int kk = 0; kk < C::KB; ++kk)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        v[kk][c] = *reinterpret_cast<const uint4 *>(gx + st.o[c] + (unsigned)((k0 + kk) * 32));
+                vec xf[C::KB];
+#pragma unroll
+                for (int kk = 0; kk < C::KB; ++kk) xf[kk] = blend4(v[kk], st.w, T{});
+#pragma unroll
+                for (int kk = 0; kk < C::KB; ++kk)
+#pragma unroll
+                    for (int n = 0; n < NF; ++n) {
+                        const vec wv = *reinterpret_cast<const vec *>(wb + ((k0 + kk) * NF + n) * 1024);
+                        mma_kg(acc[m][n], wv, xf[kk]);
+                    }
+                // do not start the next gather/blend in the shadow of this batch's MFMAs
+#pragma unroll
+                for (int n = 0; n < NF; ++n) mfma_retire(acc[m][n]);
+            }
         }
-        __syncthreads();
+        if (tap < 8) {
+#pragma unroll
+            for (int i = 0; i < C::WPT; ++i) {
+                const int idx = tid + i * 256;
+                if (idx < C::WVEC)
+                    *reinterpret_cast<uint4 *>(lds_w + (cur ^ 1) * C::WTAP + idx * 16) =
+                        C::PREFETCH ? wr[i]
+                                    : *reinterpret_cast<const uint4 *>((const char *)p.w + (size_t)(tap + 1) * C::WTAP + idx * 16);
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
     }
 
     // ---- epilogue (no activation: ema_vfi.py:136-138 chains the blocks directly) ----
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-        const int y = blockIdx.y * 8 + wave * 2 + m, x = blockIdx.x * 32 + r;
-        if (y >= H || x >= W) continue;
-        T *op = reinterpret_cast<T *>(p.out) + (((size_t)b * H + y) * W + x) * p.out_ps;
+        if (!in_img[m]) continue;
+        T *op = reinterpret_cast<T *>(p.out) + (((size_t)b * H + py_y[m]) * W + px_x) * p.out_ps;
 #pragma unroll
         for (int n = 0; n < NF; ++n)
 #pragma unroll

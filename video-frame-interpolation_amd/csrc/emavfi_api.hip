@@ -94,7 +94,7 @@ struct Plan {
     int fpad, p_mid;  // padded fusion / feature widths
     Layer conv1, blk[kMaxBlocks], c0, c1, c2, m0, m1, m2, off[kMaxBlocks], dcn[kMaxBlocks], r0, r1, r2;
     int lin_param;
-    size_t ctx_off, total;
+    size_t ctx_off, zero_off, total;
     const char *why;
 };
 
@@ -152,15 +152,18 @@ bool build_plan(Plan &P, int in_ch, int mid, int nb, int dtype)
     if (256 % rup(4 * mid, 16) != 0) { P.why = "4*mid_channels must divide 256 for the pooling kernel"; return false; }
     P.ctx_off = o;
     o = rup256(o + ((size_t)mid * 4 * mid + mid + (size_t)mid * mid * 9 + mid) * sizeof(float));
+    P.zero_off = o;
+    o += 256;
     P.total = o;
     return true;
 }
 
 int run_conv(const Plan &P, const Layer &L, const void *packed, const void *in, int in_ps, int Hin, int Win, void *out,
              int out_ps, int out_coff, int cstore, int epi, int B, hipStream_t s, const float *bias_table = nullptr,
-             float *planar = nullptr, int nplanes = 0)
+             float *planar = nullptr, int nplanes = 0, const void *zeros = nullptr)
 {
     ConvParams c{};
+    c.zeros = zeros ? zeros : (const char *)packed + P.zero_off;
     c.in = in; c.out = out; c.out_planar = planar;
     c.w = (const char *)packed + L.w_off;
     c.bias = bias_table ? bias_table : (const float *)((const char *)packed + L.b_off);
@@ -437,6 +440,7 @@ int emavfi_pack_weights(int in_channels, int mid_channels, int num_blocks, const
                                (const float *)params[P.m0.param], (const float *)params[P.m0.param + 1],
                                (float *)((char *)packed + P.ctx_off), P.mid, s),
                "pack context");
+    if (hipMemsetAsync((char *)packed + P.zero_off, 0, 256, s) != hipSuccess) return fail(EMAVFI_E_LAUNCH, "pack: zero page memset failed");
     return EMAVFI_OK;
 }
 
@@ -529,6 +533,7 @@ size_t emavfi_conv3x3_workspace_bytes(int B, int Cin, int Cout, int H, int W, in
     ws.take(L.w_bytes);
     ws.take((size_t)L.coutpad * sizeof(float));
     ws.take((size_t)B * Ho * Wo * rup(Cout, 16) * e);
+    ws.take(256);
     return ws.used;
 }
 
@@ -551,17 +556,19 @@ int emavfi_conv3x3(const float *x, const float *weight, const float *bias, float
     void *wp = ws.take(L.w_bytes);
     float *bp = (float *)ws.take((size_t)L.coutpad * sizeof(float));
     void *ycl = ws.take((size_t)B * Ho * Wo * ops * P.esize);
+    void *zpage = ws.take(256);
     if (ws.used > workspace_bytes) return fail(EMAVFI_E_WORKSPACE, "conv3x3: workspace needs %zu bytes, got %zu", ws.used, workspace_bytes);
     hipStream_t s = (hipStream_t)stream;
     L.w_off = (char *)wp - (char *)workspace;
     L.b_off = (char *)bp - (char *)workspace;
     PackDesc d{L.cout, L.cin_raw, 0, L.cin_take, L.ck, L.nchunk, L.nf, L.npass, 0};
+    if (hipMemsetAsync(zpage, 0, 256, s) != hipSuccess) return fail(EMAVFI_E_LAUNCH, "conv3x3: zero page memset failed");
     EMAVFI_TRY(launch_pack_conv(weight, bias, wp, bp, d, dtype, s), "conv3x3 pack");
     EMAVFI_TRY(launch_nchw_to_cl(x, xcl, B, Cin, H, W, L.cin_pad, dtype, s), "conv3x3 layout in");
     if (act == EMAVFI_ACT_TANH01) {
-        EMAVFI_TRY(run_conv(P, L, workspace, xcl, L.cin_pad, H, W, nullptr, 0, 0, 0, EPI_PLANAR_TANH01, B, s, nullptr, y, Cout), "conv3x3");
+        EMAVFI_TRY(run_conv(P, L, workspace, xcl, L.cin_pad, H, W, nullptr, 0, 0, 0, EPI_PLANAR_TANH01, B, s, nullptr, y, Cout, zpage), "conv3x3");
     } else {
-        EMAVFI_TRY(run_conv(P, L, workspace, xcl, L.cin_pad, H, W, ycl, ops, 0, ops, act == EMAVFI_ACT_RELU ? EPI_RELU : EPI_NONE, B, s), "conv3x3");
+        EMAVFI_TRY(run_conv(P, L, workspace, xcl, L.cin_pad, H, W, ycl, ops, 0, ops, act == EMAVFI_ACT_RELU ? EPI_RELU : EPI_NONE, B, s, nullptr, nullptr, 0, zpage), "conv3x3");
         EMAVFI_TRY(launch_cl_to_nchw(ycl, y, B, Cout, Ho, Wo, ops, 0, dtype, s), "conv3x3 layout out");
     }
     return EMAVFI_OK;
