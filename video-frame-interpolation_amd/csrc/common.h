@@ -103,10 +103,12 @@ struct DeformParams {
     void *out;         // channels-last T
     const void *w;     // packed [tap][kg][nf][lane][16 B]
     const float *bias; // [NF*32]
+    const void *zeros; // >= 16 bytes of zeros (DMA source for out-of-image window pixels)
     int x_ps, out_ps;
     int H, W, B;
     int cstore;
-    int ck, nf;  // host-side template selectors
+    int cin_real;  // real (unpadded) input channels
+    int ck, nf;    // host-side template selectors
 };
 
 int launch_conv3x3_f32(const ConvParams &p, hipStream_t s);

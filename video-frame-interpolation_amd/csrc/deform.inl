@@ -50,13 +50,12 @@ struct SampleTap {
 // Compare-free: positions are clamped to [-2, size+1] (NaN -> -2), so the int conversions cannot
 // overflow, and corner validity is an integer clamp to {0,1}.  A position <= -1 or >= size makes
 // both of its corners invalid or zero-weighted = the operator's "outside -> 0" rule.
-__device__ __forceinline__ SampleTap sample_tap(const float *__restrict__ om, int tap, int y, int x, int H, int W,
-                                                unsigned ps_bytes, bool in_image, int *yc0 = nullptr, int *yc1 = nullptr,
-                                                int *xc0 = nullptr, int *xc1 = nullptr)
+__device__ __forceinline__ SampleTap sample_tap_vals(float dy, float dx, float mk, int tap, int y, int x, int H, int W,
+                                                     unsigned ps_bytes, int *yc0 = nullptr, int *yc1 = nullptr,
+                                                     int *xc0 = nullptr, int *xc1 = nullptr)
 {
     SampleTap t;
     const int i = tap / 3, j = tap - 3 * i;
-    const float dy = om[2 * tap], dx = om[2 * tap + 1], mk = in_image ? om[18 + tap] : 0.0f;
     const float py = fminf(fmaxf((float)(y - 1 + i) + dy, -2.0f), (float)(H + 1));
     const float px = fminf(fmaxf((float)(x - 1 + j) + dx, -2.0f), (float)(W + 1));
     const float fy = floorf(py), fx = floorf(px);
@@ -78,6 +77,11 @@ __device__ __forceinline__ SampleTap sample_tap(const float *__restrict__ om, in
     t.w[2] = mk * (lh * uw) * (float)(vhh * vwl);
     t.w[3] = mk * (lh * lw) * (float)(vhh * vwh);
     return t;
+}
+__device__ __forceinline__ SampleTap sample_tap(const float *__restrict__ om, int tap, int y, int x, int H, int W,
+                                                unsigned ps_bytes, bool in_image)
+{
+    return sample_tap_vals(om[2 * tap], om[2 * tap + 1], in_image ? om[18 + tap] : 0.0f, tap, y, x, H, W, ps_bytes);
 }
 
 // fp32 blend of four 16-byte corner pieces -> one MFMA operand fragment

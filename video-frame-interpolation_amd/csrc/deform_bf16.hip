@@ -1,7 +1,7 @@
 #include "deform_lds.inl"
 int launch_deform_bf16(const DeformParams &p, hipStream_t s)
 {
-    // the reference width (mid_channels 64 -> 67 channels padded to 80): LDS-staged gather
-    if (p.ck == 80 && p.nf == 3) return launch_deform_lds<80, 3, 2>(p, s);
+    // the reference width (mid_channels 64 -> 67 channels, k-groups to 80): LDS-staged window of 72 channels
+    if (p.ck == 80 && p.nf == 3 && p.cin_real <= 72) return launch_deform_lds<80, 3, 72, 2>(p, s);
     return launch_deform_any<bf16_t>(p, s);
 }

@@ -1,39 +1,59 @@
-// bf16 modulated deformable conv with the input tile staged in LDS (the "tiled gather with LDS
+// bf16 modulated deformable conv with the input window staged in LDS (the "tiled gather with LDS
 // halo" of BASELINE.json).  Same operator and fragment scheme as deform.inl; what changes is
 // where the bilinear taps are fetched from:
 //
 //   * a 512-thread workgroup (8 waves = 2 per SIMD, so one wave's gather/blend VALU overlaps its
 //     partner's MFMAs) owns a 16x32 output tile; wave w owns rows 2w, 2w+1;
-//   * the input tile plus a halo of 1 (3x3 taps) + R (offset reach) + 1 (bilinear) pixels is
-//     loaded ONCE, coalesced, into LDS: (19+2R) x (35+2R) pixels x CK bf16 (R = 2: 23 x 39 x
-//     160 B = 140 KiB) - HBM/L2 sees each input pixel 1.75x instead of ~36 scattered corner
-//     fetches that thrash the 32 KiB L1 (deform.inl v1 measured 5.0 ms per B=8 720p launch);
+//   * the input window = tile + halo of 1 (3x3 taps) + R (offset reach) + 1 (bilinear) pixels
+//     is brought into LDS ONCE by global->LDS DMA (global_load_lds_dwordx4, every lane with its
+//     own source address, out-of-image pixels read a zero page): (19+2R) x (35+2R) pixels x CS
+//     staged channels.  Only the CS = 72 channels that can be non-zero are staged (67 real, the
+//     MFMA k-groups run to 80): 9 sixteen-byte slots per pixel - an ODD slot stride, so the
+//     ds_read_b128 gathers of neighbouring pixels are bank-conflict free - and lanes whose
+//     k-group piece would be channels 72..79 re-read slot 8: those channels only ever meet zero
+//     weights.  R = 2: 23 x 39 x 144 B = 126 KiB; HBM/L2 sees each input pixel 1.75x instead of
+//     ~36 scattered corner fetches thrashing the 32 KiB L1 (deform.inl measured 5.0 ms per
+//     B=8 720p launch with the global gather);
 //   * every lane gathers its own MFMA operand pieces with ds_read_b128; a tap whose four corners
-//     do not all lie inside the staged window (|offset| > R) falls back to the global gather of
+//     do not all lie inside the window (|offset| > R) falls back to the global gather of
 //     deform.inl for that lane - results are identical either way;
-//   * the tap's packed weights sit in one 15 KiB LDS buffer, prefetched through registers
-//     (two barriers per tap).
+//   * the tap's packed weights are double buffered in LDS and DMA'd one tap ahead (one barrier
+//     per tap); the next tap's (dy, dx, mask) are fetched one tap ahead as well.
 #include "deform.inl"
 
-template <int CK, int NF, int R> struct DeformLdsCfg {
+template <int CK, int NF, int CS, int R> struct DeformLdsCfg {
     static constexpr int TROWS = 16, TCOLS = 32;
     static constexpr int TR = TROWS + 3 + 2 * R, TC = TCOLS + 3 + 2 * R;
-    static constexpr int PSB = CK * 2;        // bytes per staged pixel
-    static constexpr int PIECES = PSB / 16;
+    static constexpr int SP = CS * 2 / 16;    // 16-byte slots per staged pixel
+    static constexpr int PSB = SP * 16;       // bytes per staged pixel
     static constexpr int KG = CK / 16;
     static constexpr int WTAP = KG * NF * 1024;
-    static constexpr int WVEC = KG * NF * 64;
-    static constexpr int WPT = (WVEC + 511) / 512;
-    static constexpr int LDS_TILE = TR * TC * PSB;
-    static constexpr int LDS_BYTES = LDS_TILE + WTAP;
+    static constexpr int WINST = KG * NF;
+    static constexpr int NSLOT = TR * TC * SP;
+    static constexpr int NINST = (NSLOT + 63) / 64;
+    static constexpr int LDS_TILE = NINST * 1024;
+    static constexpr int LDS_BYTES = LDS_TILE + 2 * WTAP;
     static constexpr int KB = (KG % 5 == 0) ? 5 : ((KG % 3 == 0) ? 3 : ((KG % 2 == 0) ? 2 : 1));
-    static_assert(LDS_BYTES <= 160 * 1024, "tile + weights do not fit the 160 KiB LDS");
+    static_assert(CS % 8 == 0 && CS <= CK, "staged channels: whole 16-byte slots, at most CK");
+    static_assert((SP & 1) == 1, "odd slot stride keeps neighbouring-pixel gathers conflict free");
+    static_assert(LDS_BYTES <= 160 * 1024, "window + weights do not fit the 160 KiB LDS");
 };
 
-template <int CK, int NF, int R>
+struct OmTap { float dy, dx, mk; };
+
+__device__ __forceinline__ OmTap load_om(const float *__restrict__ om, int tap, bool in_image)
+{
+    OmTap t;
+    t.dy = om[2 * tap]; t.dx = om[2 * tap + 1]; t.mk = in_image ? om[18 + tap] : 0.0f;
+    return t;
+}
+
+template <int CK, int NF, int CS, int R>
 __global__ __launch_bounds__(512) void deform_lds_kernel(const DeformParams p)
 {
-    using C = DeformLdsCfg<CK, NF, R>;
+    using C = DeformLdsCfg<CK, NF, CS, R>;
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *lds_x = smem;
     char *lds_w = smem + C::LDS_TILE;
@@ -45,19 +65,28 @@ __global__ __launch_bounds__(512) void deform_lds_kernel(const DeformParams p)
     const unsigned ps_bytes = (unsigned)p.x_ps * 2u;
     const int ty0 = blockIdx.y * C::TROWS - 1 - R, tx0 = blockIdx.x * C::TCOLS - 1 - R;
     const char *gplane = (const char *)p.x + (size_t)b * H * W * ps_bytes;
+    const char *zeros = (const char *)p.zeros;
 
-    // ---- stage the input window (zero outside the image) and tap 0's weights ----
-    for (int it = tid; it < C::TR * C::TC * C::PIECES; it += 512) {
-        const int pix = it / C::PIECES, pc = it - pix * C::PIECES;
-        const int ly = pix / C::TC, lx = pix - ly * C::TC;
-        const int gy = ty0 + ly, gxx = tx0 + lx;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (gy >= 0 && gy < H && gxx >= 0 && gxx < W)
-            v = *reinterpret_cast<const uint4 *>(gplane + (size_t)(gy * W + gxx) * ps_bytes + pc * 16);
-        *reinterpret_cast<uint4 *>(lds_x + pix * C::PSB + pc * 16) = v;
+    // ---- DMA the input window (zero outside the image) and tap 0's weights ----
+#pragma unroll
+    for (int i = 0; i < (C::NINST + 7) / 8; ++i) {
+        const int j = i * 8 + wave;
+        if (j < C::NINST) {
+            const int sl = j * 64 + lane;
+            const int pix = sl / C::SP, pc = sl - pix * C::SP;
+            const int ly = pix / C::TC, lx = pix - ly * C::TC;
+            const int gy = ty0 + ly, gxx = tx0 + lx;
+            const bool ok = sl < C::NSLOT && gy >= 0 && gy < H && gxx >= 0 && gxx < W;
+            const char *src = ok ? gplane + (size_t)(gy * W + gxx) * ps_bytes + pc * 16 : zeros;
+            __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)(lds_x + j * 1024), 16, 0, 0);
+        }
     }
-    for (int idx = tid; idx < C::WVEC; idx += 512)
-        *reinterpret_cast<uint4 *>(lds_w + idx * 16) = *reinterpret_cast<const uint4 *>((const char *)p.w + idx * 16);
+#pragma unroll
+    for (int i = 0; i < (C::WINST + 7) / 8; ++i) {
+        const int j = i * 8 + wave;
+        if (j < C::WINST)
+            __builtin_amdgcn_global_load_lds((gptr_t *)((const char *)p.w + j * 1024 + lane * 16), (lptr_t *)(lds_w + j * 1024), 16, 0, 0);
+    }
 
     f32x16 acc[2][NF];
 #pragma unroll
@@ -71,56 +100,66 @@ __global__ __launch_bounds__(512) void deform_lds_kernel(const DeformParams p)
     int py_y[2];
     bool in_img[2];
     const float *om[2];
+    OmTap nxt[2];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         py_y[m] = blockIdx.y * C::TROWS + wave * 2 + m;
         in_img[m] = py_y[m] < H && px_x < W;
         om[m] = p.om + (((size_t)b * H + (in_img[m] ? py_y[m] : 0)) * W + (in_img[m] ? px_x : 0)) * 32;
+        nxt[m] = load_om(om[m], 0, in_img[m]);
     }
     const char *gx = gplane + h * 16;
-    const char *lx0 = lds_x + h * 16;
+    __syncthreads();  // hipcc drains the DMA (vmcnt(0)) ahead of the barrier
 
+    int cur = 0;
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
-        uint4 wr[C::WPT];
         if (tap < 8) {
 #pragma unroll
-            for (int i = 0; i < C::WPT; ++i) {
-                const int idx = tid + i * 512;
-                if (idx < C::WVEC) wr[i] = *reinterpret_cast<const uint4 *>((const char *)p.w + (size_t)(tap + 1) * C::WTAP + idx * 16);
+            for (int i = 0; i < (C::WINST + 7) / 8; ++i) {
+                const int j = i * 8 + wave;
+                if (j < C::WINST)
+                    __builtin_amdgcn_global_load_lds((gptr_t *)((const char *)p.w + (size_t)(tap + 1) * C::WTAP + j * 1024 + lane * 16),
+                                                     (lptr_t *)(lds_w + (cur ^ 1) * C::WTAP + j * 1024), 16, 0, 0);
             }
         }
-        __syncthreads();  // this tap's weights (and, first time, the staged window) are visible
-        const char *wb = lds_w + lane * 16;
+        OmTap now[2] = {nxt[0], nxt[1]};
+        if (tap < 8) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) nxt[m] = load_om(om[m], tap + 1, in_img[m]);
+        }
+        const char *wb = lds_w + cur * C::WTAP + lane * 16;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             int yc0, yc1, xc0, xc1;
-            const SampleTap st = sample_tap(om[m], tap, py_y[m], px_x, H, W, ps_bytes, in_img[m], &yc0, &yc1, &xc0, &xc1);
-            // window-local byte offsets of the four corners; valid only when `inside`
+            const SampleTap st = sample_tap_vals(now[m].dy, now[m].dx, now[m].mk, tap, py_y[m], px_x, H, W, ps_bytes, &yc0, &yc1, &xc0, &xc1);
             const bool inside = yc0 >= ty0 && yc1 <= ty0 + C::TR - 1 && xc0 >= tx0 && xc1 <= tx0 + C::TC - 1;
-            const unsigned l00 = (unsigned)((yc0 - ty0) * C::TC + (xc0 - tx0)) * C::PSB;
-            const unsigned l01 = (unsigned)((yc0 - ty0) * C::TC + (xc1 - tx0)) * C::PSB;
-            const unsigned l10 = (unsigned)((yc1 - ty0) * C::TC + (xc0 - tx0)) * C::PSB;
-            const unsigned l11 = (unsigned)((yc1 - ty0) * C::TC + (xc1 - tx0)) * C::PSB;
-            const unsigned lo[4] = {l00, l01, l10, l11};
+            // window-local corner offsets, clamped into the window so every lane's LDS read is in
+            // bounds; lanes that are not `inside` overwrite what they read with the global gather
+            const int ly0 = min(max(yc0 - ty0, 0), C::TR - 1), ly1 = min(max(yc1 - ty0, 0), C::TR - 1);
+            const int lx0 = min(max(xc0 - tx0, 0), C::TC - 1), lx1 = min(max(xc1 - tx0, 0), C::TC - 1);
+            const unsigned lo[4] = {(unsigned)(ly0 * C::TC + lx0) * C::PSB, (unsigned)(ly0 * C::TC + lx1) * C::PSB,
+                                    (unsigned)(ly1 * C::TC + lx0) * C::PSB, (unsigned)(ly1 * C::TC + lx1) * C::PSB};
             const bool all_inside = __all(inside);
 #pragma unroll
             for (int k0 = 0; k0 < C::KG; k0 += C::KB) {
                 uint4 v[C::KB][4];
-                if (all_inside) {
 #pragma unroll
-                    for (int kk = 0; kk < C::KB; ++kk)
+                for (int kk = 0; kk < C::KB; ++kk) {
+                    // slot of this lane's piece in the staged pixel; pieces past the staged channels
+                    // (zero weights) re-read the last slot
+                    const int slot = (2 * (k0 + kk) + h < C::SP) ? 2 * (k0 + kk) + h : C::SP - 1;
 #pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            v[kk][c] = *reinterpret_cast<const uint4 *>(lx0 + lo[c] + (unsigned)((k0 + kk) * 32));
-                } else {
+                    for (int c = 0; c < 4; ++c) v[kk][c] = *reinterpret_cast<const uint4 *>(lds_x + lo[c] + (unsigned)(slot * 16));
+                }
+                if (!all_inside) {      // wave-uniform: some lane reaches past the window
+                    if (!inside) {      // ONE divergent region per batch
 #pragma unroll
-                    for (int kk = 0; kk < C::KB; ++kk)
+                        for (int kk = 0; kk < C::KB; ++kk)
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            if (inside) v[kk][c] = *reinterpret_cast<const uint4 *>(lx0 + lo[c] + (unsigned)((k0 + kk) * 32));
-                            else v[kk][c] = *reinterpret_cast<const uint4 *>(gx + st.o[c] + (unsigned)((k0 + kk) * 32));
-                        }
+                            for (int c = 0; c < 4; ++c)
+                                v[kk][c] = *reinterpret_cast<const uint4 *>(gx + st.o[c] + (unsigned)((k0 + kk) * 32));
+                    }
                 }
                 bf16x8 xf[C::KB];
 #pragma unroll
@@ -137,12 +176,8 @@ __global__ __launch_bounds__(512) void deform_lds_kernel(const DeformParams p)
             }
         }
         if (tap < 8) {
-            __syncthreads();  // every wave has finished reading this tap's weights
-#pragma unroll
-            for (int i = 0; i < C::WPT; ++i) {
-                const int idx = tid + i * 512;
-                if (idx < C::WVEC) *reinterpret_cast<uint4 *>(lds_w + idx * 16) = wr[i];
-            }
+            __syncthreads();  // drains the next tap's weight DMA; everyone is done with buffer `cur`
+            cur ^= 1;
         }
     }
 
@@ -161,17 +196,17 @@ __global__ __launch_bounds__(512) void deform_lds_kernel(const DeformParams p)
     }
 }
 
-template <int CK, int NF, int R> static int launch_deform_lds(const DeformParams &p, hipStream_t s)
+template <int CK, int NF, int CS, int R> static int launch_deform_lds(const DeformParams &p, hipStream_t s)
 {
-    using C = DeformLdsCfg<CK, NF, R>;
+    using C = DeformLdsCfg<CK, NF, CS, R>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&deform_lds_kernel<CK, NF, R>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&deform_lds_kernel<CK, NF, CS, R>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
     dim3 grid((p.W + C::TCOLS - 1) / C::TCOLS, (p.H + C::TROWS - 1) / C::TROWS, p.B);
-    deform_lds_kernel<CK, NF, R><<<grid, 512, C::LDS_BYTES, s>>>(p);
+    deform_lds_kernel<CK, NF, CS, R><<<grid, 512, C::LDS_BYTES, s>>>(p);
     return (int)hipGetLastError();
 }

@@ -177,13 +177,14 @@ int run_conv(const Plan &P, const Layer &L, const void *packed, const void *in, 
 }
 
 int run_deform(const Plan &P, const Layer &L, const void *packed, const void *x, int x_ps, const float *om, void *out,
-               int out_ps, int cstore, int B, int H, int W, hipStream_t s)
+               int out_ps, int cstore, int B, int H, int W, hipStream_t s, const void *zeros = nullptr)
 {
     DeformParams d{};
     d.x = x; d.om = om; d.out = out;
     d.w = (const char *)packed + L.w_off;
     d.bias = (const float *)((const char *)packed + L.b_off);
-    d.x_ps = x_ps; d.out_ps = out_ps; d.H = H; d.W = W; d.B = B; d.cstore = cstore; d.ck = L.ck; d.nf = L.nf;
+    d.zeros = zeros ? zeros : (const char *)packed + P.zero_off;
+    d.x_ps = x_ps; d.out_ps = out_ps; d.H = H; d.W = W; d.B = B; d.cstore = cstore; d.cin_real = L.cin_take; d.ck = L.ck; d.nf = L.nf;
     return P.dtype == EMAVFI_F32 ? launch_deform_f32(d, s) : launch_deform_bf16(d, s);
 }
 
@@ -585,7 +586,7 @@ size_t emavfi_deform_conv2d_workspace_bytes(int B, int C, int O, int H, int W, i
     Workspace ws{nullptr, 0, 0};
     const size_t px = (size_t)B * H * W;
     ws.take(px * L.ck * e); ws.take(px * 32 * sizeof(float)); ws.take(L.w_bytes);
-    ws.take((size_t)L.coutpad * sizeof(float)); ws.take(px * rup(O, 16) * e);
+    ws.take((size_t)L.coutpad * sizeof(float)); ws.take(px * rup(O, 16) * e); ws.take(256);
     return ws.used;
 }
 
@@ -608,15 +609,17 @@ int emavfi_deform_conv2d(const float *x, const float *offset, const float *mask,
     void *wp = ws.take(L.w_bytes);
     float *bp = (float *)ws.take((size_t)L.coutpad * sizeof(float));
     void *ycl = ws.take(px * ops * P.esize);
+    void *zpage = ws.take(256);
     if (ws.used > workspace_bytes) return fail(EMAVFI_E_WORKSPACE, "deform_conv2d: workspace needs %zu bytes, got %zu", ws.used, workspace_bytes);
     hipStream_t s = (hipStream_t)stream;
     L.w_off = (char *)wp - (char *)workspace;
     L.b_off = (char *)bp - (char *)workspace;
     PackDesc d{L.cout, L.cin_raw, 0, L.cin_take, L.ck, 1, L.nf, 1, 0};
+    if (hipMemsetAsync(zpage, 0, 256, s) != hipSuccess) return fail(EMAVFI_E_LAUNCH, "deform_conv2d: zero page memset failed");
     EMAVFI_TRY(launch_pack_conv(weight, bias, wp, bp, d, dtype, s), "deform pack");
     EMAVFI_TRY(launch_nchw_to_cl(x, xcl, B, C, H, W, L.ck, dtype, s), "deform layout in");
     EMAVFI_TRY(launch_om_from_nchw(offset, mask, om, B, H, W, s), "deform offsets");
-    EMAVFI_TRY(run_deform(P, L, workspace, xcl, L.ck, om, ycl, ops, ops, B, H, W, s), "deform_conv2d");
+    EMAVFI_TRY(run_deform(P, L, workspace, xcl, L.ck, om, ycl, ops, ops, B, H, W, s, zpage), "deform_conv2d");
     EMAVFI_TRY(launch_cl_to_nchw(ycl, y, B, O, H, W, ops, 0, dtype, s), "deform layout out");
     return EMAVFI_OK;
 }
