@@ -108,7 +108,7 @@ def warp_roofline(hip, B, H, W, steps=20):
     ms = sorted(hip.elapsed_ms(ev[2 * i], ev[2 * i + 1]) for i in range(steps))[steps // 2]
     hip.destroy(ev)
     gbs = 32.0 * B * H * W / (ms * 1e-3) / 1e9
-    return {"kernel": "warp_nchw_kernel (emavfi_warp)", "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
+    return {"kernel": "warp_tiled_kernel<3> (emavfi_warp, NCHW fp32)", "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
             "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "median_us": round(ms * 1e3, 2),
             "algorithmic_bytes_per_px": 32, "pixels": B * H * W}
 
@@ -135,26 +135,17 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+    from emavfi import EMA_VFI, lib, synth, dist as vdist
+    vdist.init("nccl", dev)
 
-    from emavfi import EMA_VFI, lib, synth
     B, H, W = args.batch, args.height, args.width
     dt = lib.dtype_code(args.dtype)
     model = EMA_VFI(compute_dtype=args.dtype).to(dev).eval()
     sd = synth.synthetic_state_dict(seed=0)
-    nbytes = lib.load().emavfi_packed_bytes(3, 64, 3, dt)
     if rank == 0:
         model.load_state_dict(sd, strict=True)
-        blob = model.packed_weights(dt, dev)
-    else:
-        blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    if world > 1:  # the path's one collective: RCCL broadcast of the packed weights over xGMI
-        dist.broadcast(blob, src=0)
-        model.load_packed_weights(dt, blob)
+    # the path's one collective: RCCL broadcast of the packed weights over xGMI (no-op at N=1)
+    vdist.share_model_weights(model, args.dtype, dev)
 
     f1, f2 = synth.fast_frames(100 + rank, B, H, W, device=dev)
     launches = lib.forward_launches(3, 64, 3, B, H, W, args.dtype)
@@ -171,8 +162,7 @@ def main():
             return model(f1, f2)
 
     def fence():
-        if world > 1:
-            dist.barrier()
+        vdist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -184,10 +174,7 @@ def main():
         out = step(i)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    elapsed = vdist.max_over_ranks(elapsed, dev)
     assert torch.isfinite(out).all()
 
     if rank == 0:
@@ -253,8 +240,8 @@ def main():
     if ev is not None:
         hip.destroy(ev)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        vdist.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

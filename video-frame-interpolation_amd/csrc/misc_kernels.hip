@@ -2,6 +2,7 @@
 // boundary, global-average-pool + context folding, and the backward bilinear warp.
 #include "common.h"
 #include "misc_kernels.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------
 // Weight packing: OIHW fp32 -> [pass][chunk][tap][kg][nf][lane][16 B] in MFMA operand order.
@@ -262,7 +263,7 @@ int launch_ctx_finish(const float *part, const float *ctxw, float *ctx_out, floa
 // order of the coordinate math is kept exactly, because sampling directly at x+flow differs from
 // the reference by up to 5e-4 at 720p.  Compiled without fast-math.
 // ------------------------------------------------------------------------------------------
-struct WarpTap { int o00, o01, o10, o11; float nw, ne, sw, se; };
+struct WarpTap { int o00, o01, o10, o11; float nw, ne, sw, se; int xa, xb, ya, yb; };
 
 __device__ __forceinline__ WarpTap warp_tap(int x, int y, float fx, float fy, int H, int W, float wden, float hden)
 {
@@ -280,6 +281,7 @@ __device__ __forceinline__ WarpTap warp_tap(int x, int y, float fx, float fy, in
     const int xa = max(xi, 0), xb = min(xi + 1, W - 1), ya = max(yi, 0), yb = min(yi + 1, H - 1);
     WarpTap t;
     t.o00 = ya * W + xa; t.o01 = ya * W + xb; t.o10 = yb * W + xa; t.o11 = yb * W + xb;
+    t.xa = xa; t.xb = xb; t.ya = ya; t.yb = yb;
     t.nw = (y0 && x0) ? s * e : 0.0f;
     t.ne = (y0 && x1) ? s * w : 0.0f;
     t.sw = (y1 && x0) ? n * e : 0.0f;
@@ -334,9 +336,118 @@ __global__ __launch_bounds__(256) void warp_nchw_kernel(const float *__restrict_
         }
     }
 }
+// Tiled variant (the one emavfi_warp launches when W % 4 == 0 and C == 3): a 256-thread block
+// owns a 32x64 pixel tile.  The frame2 window the tile can reach with |flow| <= R = 8 px
+// (tile + R each side + 1 for the bilinear neighbour: 49 rows x 84 columns x 3 planes = 48 KiB)
+// is brought into LDS by global->LDS DMA in 16-byte pieces (rows outside the image read a zero
+// page), so HBM/L2 traffic is coalesced full lines instead of 12 scattered 4-byte gathers per
+// pixel; the four taps are then read from LDS.  A pixel whose taps leave the window (|flow| > R)
+// gathers from global memory as the simple kernel does - same arithmetic, same result.
+__device__ const float g_zero_page[64] = {0};
+
+// T = void: NCHW fp32 planes (emavfi_warp).  T = float / bf16_t: the forward's fused variant, which
+// writes channels [coff, ps) of the channels-last fusion buffer (warped RGB, then zero padding).
+template <int C, typename T>
+__global__ __launch_bounds__(256) void warp_tiled_kernel(const float *__restrict__ frame2, const float *__restrict__ flow,
+                                                         float *__restrict__ out, int B, int H, int W, void *cl_dst, int ps,
+                                                         int coff)
+{
+    constexpr int TH = 32, TW = 64, R = 8, WR = TH + 2 * R + 1, WC = 84, PCS = WC / 4;
+    constexpr int NPIECE = C * WR * PCS, NINST = (NPIECE + 63) / 64;
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    __shared__ __attribute__((aligned(16))) float win[NINST * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (id % 8 labels the
+    // XCD group); give each group a contiguous run of tiles so x-neighbours, which share halo
+    // columns, hit the same XCD's L2.  Bijective for any grid size; placement only affects speed.
+    const int ntx = (W + TW - 1) / TW, nty = (H + TH - 1) / TH, nwg = gridDim.x;
+    const int grp = blockIdx.x & 7, kk = blockIdx.x >> 3, qq = nwg >> 3, rr = nwg & 7;
+    const int wg = (grp < rr ? grp * (qq + 1) : rr * (qq + 1) + (grp - rr) * qq) + kk;
+    const int b = wg / (ntx * nty), trem = wg - b * (ntx * nty);
+    const int ty = (trem / ntx) * TH, tx = (trem - (trem / ntx) * ntx) * TW;
+    const int wy0 = ty - R, wx0 = tx - R;  // tx is a multiple of 64, so wx0 is 16-byte aligned when W % 4 == 0
+    const size_t plane = (size_t)H * W;
+    const float *src_b = frame2 + (size_t)b * C * plane;
+#pragma unroll
+    for (int i = 0; i < (NINST + 3) / 4; ++i) {
+        const int j = i * 4 + wave;
+        if (j < NINST) {
+            const int idx = j * 64 + lane;
+            const int ch = idx / (WR * PCS), rem = idx - ch * (WR * PCS);
+            const int row = rem / PCS, pc = rem - row * PCS;
+            const int gy = wy0 + row, gx = wx0 + 4 * pc;
+            const bool ok = idx < NPIECE && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const float *src = ok ? src_b + (size_t)ch * plane + (size_t)gy * W + gx : g_zero_page;
+            __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)(win + j * 256), 16, 0, 0);
+        }
+    }
+    const float wden = (float)max(W - 1, 1), hden = (float)max(H - 1, 1);
+    // flow for this thread's two items (4 pixels each) while the DMA is in flight
+    f32x4 fx[2], fy[2];
+    int iy[2], ix[2];
+    bool live[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int item = tid + 256 * k;
+        iy[k] = ty + item / (TW / 4);
+        ix[k] = tx + 4 * (item % (TW / 4));
+        live[k] = iy[k] < H && ix[k] < W;
+        const size_t pix = (size_t)(live[k] ? iy[k] : 0) * W + (live[k] ? ix[k] : 0);
+        fx[k] = *reinterpret_cast<const f32x4 *>(flow + ((size_t)b * 2) * plane + pix);
+        fy[k] = *reinterpret_cast<const f32x4 *>(flow + ((size_t)b * 2 + 1) * plane + pix);
+    }
+    __syncthreads();  // hipcc drains the DMA (vmcnt(0)) ahead of the barrier
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (!live[k]) continue;
+        float v[C][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const WarpTap t = warp_tap(ix[k] + q, iy[k], fx[k][q], fy[k][q], H, W, wden, hden);
+            const bool inside = t.ya >= wy0 && t.yb <= wy0 + WR - 1 && t.xa >= wx0 && t.xb <= wx0 + WC - 1;
+            if (inside) {
+                const int l00 = (t.ya - wy0) * WC + (t.xa - wx0), l01 = (t.ya - wy0) * WC + (t.xb - wx0);
+                const int l10 = (t.yb - wy0) * WC + (t.xa - wx0), l11 = (t.yb - wy0) * WC + (t.xb - wx0);
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float *p = win + c * (WR * WC);
+                    float a = p[l00] * t.nw;
+                    a += p[l01] * t.ne;
+                    a += p[l10] * t.sw;
+                    a += p[l11] * t.se;
+                    v[c][q] = a;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < C; ++c) v[c][q] = warp_sample(src_b + (size_t)c * plane, t);
+            }
+        }
+        const size_t pix = (size_t)iy[k] * W + ix[k];
+        if constexpr (std::is_void<T>::value) {
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                *reinterpret_cast<f32x4 *>(out + ((size_t)b * C + c) * plane + pix) = f32x4{v[c][0], v[c][1], v[c][2], v[c][3]};
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                T *o = reinterpret_cast<T *>(cl_dst) + ((size_t)b * plane + pix + q) * ps + coff;
+#pragma unroll
+                for (int c = 0; c < C; ++c) o[c] = (T)v[c][q];
+                for (int c = C; c < ps - coff; ++c) o[c] = (T)0.0f;
+            }
+        }
+    }
+}
+
 int launch_warp_nchw(const float *frame2, const float *flow, float *out, int B, int C, int H, int W, hipStream_t s)
 {
     const size_t n = (size_t)B * H * W;
+    if ((W & 3) == 0 && C == 3) {
+        const int nwg = ((W + 63) / 64) * ((H + 31) / 32) * B;
+        warp_tiled_kernel<3, void><<<nwg, 256, 0, s>>>(frame2, flow, out, B, H, W, nullptr, 0, 0);
+        return (int)hipGetLastError();
+    }
     if ((W & 3) == 0) {
         const int grid = (int)std::min<size_t>((n / 4 + 255) / 256, 256 * 32);
         warp_nchw_kernel<true><<<grid, 256, 0, s>>>(frame2, flow, out, B, C, H, W);
@@ -367,6 +478,12 @@ __global__ __launch_bounds__(256) void warp_fused_kernel(const float *__restrict
 int launch_warp_fused(const float *frame2, const float *flow, void *dst, int B, int C, int H, int W, int ps, int coff, int dtype,
                       hipStream_t s)
 {
+    if ((W & 3) == 0 && C == 3) {
+        const int nwg = ((W + 63) / 64) * ((H + 31) / 32) * B;
+        if (dtype == 0) warp_tiled_kernel<3, float><<<nwg, 256, 0, s>>>(frame2, flow, nullptr, B, H, W, dst, ps, coff);
+        else warp_tiled_kernel<3, bf16_t><<<nwg, 256, 0, s>>>(frame2, flow, nullptr, B, H, W, dst, ps, coff);
+        return (int)hipGetLastError();
+    }
     const int grid = (int)std::min<size_t>(((size_t)B * H * W + 255) / 256, 256 * 64);
     if (dtype == 0) warp_fused_kernel<float><<<grid, 256, 0, s>>>(frame2, flow, (float *)dst, B, C, H, W, ps, coff);
     else warp_fused_kernel<bf16_t><<<grid, 256, 0, s>>>(frame2, flow, (bf16_t *)dst, B, C, H, W, ps, coff);

@@ -6,6 +6,6 @@
 (hand-written HIP for gfx950) reached through the C-ABI of ``include/emavfi.h``.
 """
 from .model import EMA_VFI, ModulatedDeformConvPack, DeformConv2d, conv, conv_block  # noqa: F401
-from . import lib, synth  # noqa: F401
+from . import lib, synth, dist  # noqa: F401
 
-__all__ = ["EMA_VFI", "ModulatedDeformConvPack", "DeformConv2d", "conv", "conv_block", "lib", "synth"]
+__all__ = ["EMA_VFI", "ModulatedDeformConvPack", "DeformConv2d", "conv", "conv_block", "lib", "synth", "dist"]
