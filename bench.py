@@ -69,8 +69,9 @@ class Hip:
             self.lib.hipEventDestroy(e)
 
 
-def cpu_baseline(sd, rows, width):
-    """The oracle (CPU restatement, kind "port") on a bounded strip of the 720p workload."""
+def cpu_baseline(sd, rows, width, dev=None):
+    """The oracle (CPU restatement, kind "port") on a bounded strip of the 720p workload; the same
+    strip then goes through the HIP path in both arithmetic modes for the accuracy fields."""
     from emavfi import synth
     from oracle import emavfi_oracle as oracle
     # the GPU box exposes every host core but this job's share is 16 (gpurun process guard)
@@ -79,9 +80,23 @@ def cpu_baseline(sd, rows, width):
     f1, f2 = synth.synthetic_frames(7, 1, rows, width, "natural")
     cpu_sd = {k: v.float().cpu() for k, v in sd.items()}
     t0 = time.perf_counter()
-    oracle.forward(cpu_sd, f1, f2)
+    ref = oracle.forward(cpu_sd, f1, f2)
     dt = time.perf_counter() - t0
     frac = rows / 720.0
+    accuracy = None
+    if dev is not None:
+        import math
+        from emavfi import EMA_VFI
+        accuracy = {"sample": f"the cpu_baseline strip (1 pair, {width}x{rows}), HIP path vs CPU oracle"}
+        for mode in ("fp32", "bf16"):
+            m = EMA_VFI(compute_dtype=mode).to(dev).eval()
+            m.load_state_dict(sd, strict=True)
+            with torch.no_grad():
+                got = m(f1.to(dev), f2.to(dev)).cpu()
+            mse = (got.double() - ref.double()).pow(2).mean().item()
+            accuracy[mode] = {"max_abs": float(f"{(got - ref).abs().max().item():.3e}"),
+                              "psnr_db": round(99.0 if mse == 0 else 10.0 * math.log10(1.0 / mse), 2)}
+    cpu_baseline.accuracy = accuracy
     return {"value": round(frac / dt, 5), "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": f"1 pair, {width}x{rows} strip ({frac:.3f} of a 1280x720 frame), fp32, oracle.forward once "
                       f"({dt:.1f} s); value = strip fraction / time; restated deform conv, not torchvision's C++ kernel",
@@ -235,7 +250,8 @@ def main():
         if world == 1:
             res["roofline_warp"] = warp_roofline(hip, B, H, W)
             if args.cpu_rows > 0:
-                res["cpu_baseline"] = cpu_baseline(sd, args.cpu_rows, W)
+                res["cpu_baseline"] = cpu_baseline(sd, args.cpu_rows, W, dev)
+                res["accuracy_vs_cpu_oracle"] = cpu_baseline.accuracy
         print(json.dumps(res), flush=True)
     if ev is not None:
         hip.destroy(ev)
