@@ -71,6 +71,43 @@ __device__ __forceinline__ void store4(bf16_t *p, float a, float b, float c, flo
     *reinterpret_cast<bf16x4 *>(p) = bf16x4{(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
 }
 
+// Channels-last epilogue store of one 32-channel accumulator fragment of pixel r.
+// Lane (r, h) holds channel groups {8g + 4h .. +3}, g = 0..3.  fp32: a group is already 16 bytes.
+// bf16: a group is 8 bytes, and 8-byte-per-lane stores are issue-bound (cdna_hip_programming.md T21),
+// so groups g and g+1 are exchanged between the h = 0 / h = 1 lanes of the pixel with
+// v_permlane32_swap: lane h=0 ends with channels 8g..8g+7, lane h=1 with 8(g+1)..8(g+1)+7 - one
+// 16-byte store each.  `limit` = channels of this fragment to store (multiple of 8).
+template <typename F>
+__device__ __forceinline__ void store_frag(float *base, const f32x16 &acc, int h, int limit, F act)
+{
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int c0 = 8 * g + 4 * h;
+        if (c0 < limit) store4(base + c0, act(acc[4 * g], c0), act(acc[4 * g + 1], c0 + 1), act(acc[4 * g + 2], c0 + 2), act(acc[4 * g + 3], c0 + 3));
+    }
+}
+template <typename F>
+__device__ __forceinline__ void store_frag(bf16_t *base, const f32x16 &acc, int h, int limit, F act)
+{
+#pragma unroll
+    for (int g = 0; g < 4; g += 2) {
+        unsigned a[2], b[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ca = 8 * g + 4 * h + 2 * j, cb = 8 * (g + 1) + 4 * h + 2 * j;
+            const __attribute__((ext_vector_type(2))) __bf16 pa = {(bf16_t)act(acc[4 * g + 2 * j], ca), (bf16_t)act(acc[4 * g + 2 * j + 1], ca + 1)};
+            const __attribute__((ext_vector_type(2))) __bf16 pb = {(bf16_t)act(acc[4 * (g + 1) + 2 * j], cb), (bf16_t)act(acc[4 * (g + 1) + 2 * j + 1], cb + 1)};
+            a[j] = __builtin_bit_cast(unsigned, pa);
+            b[j] = __builtin_bit_cast(unsigned, pb);
+            const auto sw = __builtin_amdgcn_permlane32_swap(a[j], b[j], false, false);
+            a[j] = sw[0];
+            b[j] = sw[1];
+        }
+        const int c0 = 8 * (g + h);  // h=0: channels 8g..8g+7, h=1: 8(g+1)..8(g+1)+7
+        if (c0 < limit) *reinterpret_cast<uint4 *>(base + c0) = make_uint4(a[0], a[1], b[0], b[1]);
+    }
+}
+
 // LDS pixel stride for CK channels of T: one 16-byte slot of padding makes the stride an odd
 // number of slots, so the 16 lanes of a ds_read_b128 group (consecutive pixels, same channel
 // offset) fall on 16 different slots of the 256-byte bank row: conflict-free.

@@ -14,8 +14,9 @@
 //     instructions are in flight together (the first version staged through registers with
 //     one load in flight per thread: 11 serialized L2/HBM round trips per tile);
 //   * the packed weights of one tap (KG*NF KiB, already in MFMA fragment order = lane-linear,
-//     exactly what the DMA writes) are double buffered in LDS: the next tap's weights are DMA'd
-//     while the current tap's MFMAs run (one barrier per tap);
+//     exactly what the DMA writes) sit in a 3-slot LDS ring filled by DMA two taps ahead; the
+//     per-tap barrier is a raw s_barrier behind a COUNTED s_waitcnt vmcnt(N) that leaves the newest
+//     tap's DMA in flight (2 slots / one tap ahead where a third slot would cost occupancy);
 //   * a wave owns MF rows of 32 pixels (MF pixel fragments) x NF channel fragments:
 //     D[cout][pixel] accumulates in MF*NF 32x32 fp32 tiles.
 // LDS pixel stride is an odd number of 16-byte slots (LdsPix), so the ds_read_b128 operand
@@ -36,7 +37,12 @@ template <typename T, int CK, int NF, int S> struct ConvCfg {
     static constexpr int NSLOT = IH * IW * SP;
     static constexpr int NINST = (NSLOT + 63) / 64;  // DMA wave-instructions per input tile
     static constexpr int LDS_IN = NINST * 1024;
-    static constexpr int LDS_BYTES = LDS_IN + 2 * WTAP;
+    // weight ring depth: 3 slots (DMA two taps ahead, counted vmcnt) when that neither overflows the
+    // 160 KiB LDS nor lowers the number of workgroups per CU; otherwise 2 slots (one tap ahead)
+    static constexpr int LDS2 = LDS_IN + 2 * WTAP, LDS3 = LDS_IN + 3 * WTAP;
+    static constexpr int WBUF = (LDS3 <= 160 * 1024 && (160 * 1024 / LDS3) == (160 * 1024 / LDS2)) ? 3 : 2;
+    static constexpr int AHEAD = WBUF - 1;
+    static constexpr int LDS_BYTES = LDS_IN + WBUF * WTAP;
     static_assert(CK % D::CHKG == 0, "CK must be a whole number of k-groups");
     static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the 160 KiB LDS");
 };
@@ -110,32 +116,32 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvParams p)
             }
         }
         const char *wc = wpass + (size_t)chunk * 9 * C::WTAP;
+        // weights: a 3-slot LDS ring filled by DMA two taps ahead.  `issue_w(t)` = this wave's share
+        // of tap t's 1-KiB blocks; every wave issues the same number NW or NW-1 of them, so a
+        // counted s_waitcnt leaves exactly the newest tap in flight across the barrier.
+        auto issue_w = [&](int t) {
 #pragma unroll
-        for (int i = 0; i < (C::WINST + 3) / 4; ++i) {
-            const int j = i * 4 + wave;
-            if (j < C::WINST)
-                __builtin_amdgcn_global_load_lds((gptr_t *)(wc + j * 1024 + lane * 16), (lptr_t *)(lds_w + j * 1024), 16, 0, 0);
-        }
-        __syncthreads();  // hipcc drains the DMA (vmcnt(0)) ahead of the barrier
+            for (int i = 0; i < (C::WINST + 3) / 4; ++i) {
+                const int j = i * 4 + wave;
+                if (j < C::WINST)
+                    __builtin_amdgcn_global_load_lds((gptr_t *)(wc + (size_t)t * C::WTAP + j * 1024 + lane * 16),
+                                                     (lptr_t *)(lds_w + (t % C::WBUF) * C::WTAP + j * 1024), 16, 0, 0);
+            }
+        };
+        issue_w(0);
+        if (C::AHEAD == 2) issue_w(1);
+        __syncthreads();  // hipcc drains the DMA (vmcnt(0)) ahead of the barrier: tile + first taps landed
 
-        int cur = 0;
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
-            if (tap < 8) {  // next tap's weights -> the other buffer, asynchronously
-#pragma unroll
-                for (int i = 0; i < (C::WINST + 3) / 4; ++i) {
-                    const int j = i * 4 + wave;
-                    if (j < C::WINST)
-                        __builtin_amdgcn_global_load_lds((gptr_t *)(wc + (size_t)(tap + 1) * C::WTAP + j * 1024 + lane * 16),
-                                                         (lptr_t *)(lds_w + (cur ^ 1) * C::WTAP + j * 1024), 16, 0, 0);
-                }
-            }
+            // the slot being refilled was last read one barrier ago (3-slot ring) / is the idle one (2-slot)
+            if (tap + C::AHEAD < 9) issue_w(tap + C::AHEAD);
             const int dy = tap / 3, dx = tap - 3 * dy;
             const char *xb[MF];
 #pragma unroll
             for (int m = 0; m < MF; ++m)
                 xb[m] = lds_in + (((wave * MF + m) * S + dy) * IW + r * S + dx) * PSTR + h * 16;
-            const char *wb = lds_w + cur * C::WTAP + lane * 16;
+            const char *wb = lds_w + (tap % C::WBUF) * C::WTAP + lane * 16;
 #pragma unroll
             for (int kg = 0; kg < C::KG; ++kg) {
                 vec xv[MF];
@@ -149,8 +155,15 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvParams p)
                 }
             }
             if (tap < 8) {
-                __syncthreads();  // drains this tap's weight DMA; everyone is done with buffer `cur`
-                cur ^= 1;
+                // tap+1's weights must have landed (issued a whole tap ago); tap+2's may stay in
+                // flight.  This wave issued nw2 DMA instructions for tap+2 (0 when tap+2 > 8).
+                const int nw2 = (C::AHEAD == 2 && tap + 2 < 9) ? (C::WINST - wave + 3) / 4 : 0;
+                if (nw2 >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else if (nw2 == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else if (nw2 == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
             }
         }
     }
@@ -175,25 +188,20 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvParams p)
             }
             continue;
         }
+        if (p.epi == EPI_OM) {
+            // mask = sigmoid(second chunk), ema_vfi.py:59; routed to channels 18..26 at pack time
+            const auto om_act = [](float v, int c) { return (c >= 18 && c < 27) ? 1.0f / (1.0f + expf(-v)) : v; };
+            store_frag(reinterpret_cast<float *>(p.out) + pix * p.out_ps, acc[m][0], h, p.cstore, om_act);
+            continue;
+        }
+        T *ob = reinterpret_cast<T *>(p.out) + pix * p.out_ps + p.out_coff + pass * NF * 32;
 #pragma unroll
-        for (int n = 0; n < NF; ++n)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c0 = pass * NF * 32 + n * 32 + 8 * g + 4 * h;
-                if (c0 >= p.cstore) continue;
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[j] = acc[m][n][4 * g + j];
-                    if (p.epi == EPI_RELU) v[j] = fmaxf(v[j], 0.0f);
-                    // mask = sigmoid(second chunk), ema_vfi.py:59; routed to channels 18..26 at pack time
-                    if (p.epi == EPI_OM && c0 + j >= 18 && c0 + j < 27) v[j] = 1.0f / (1.0f + expf(-v[j]));
-                }
-                if (p.epi == EPI_OM)
-                    store4(reinterpret_cast<float *>(p.out) + pix * p.out_ps + c0, v[0], v[1], v[2], v[3]);
-                else
-                    store4(reinterpret_cast<T *>(p.out) + pix * p.out_ps + p.out_coff + c0, v[0], v[1], v[2], v[3]);
-            }
+        for (int n = 0; n < NF; ++n) {
+            const int limit = p.cstore - (pass * NF + n) * 32;
+            if (limit <= 0) continue;
+            if (p.epi == EPI_RELU) store_frag(ob + n * 32, acc[m][n], h, limit, [](float v, int) { return fmaxf(v, 0.0f); });
+            else store_frag(ob + n * 32, acc[m][n], h, limit, [](float v, int) { return v; });
+        }
     }
 }
 

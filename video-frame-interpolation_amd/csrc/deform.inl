@@ -213,12 +213,7 @@ __global__ __launch_bounds__(256, 2) void deform_kernel(const DeformParams p)
         T *op = reinterpret_cast<T *>(p.out) + (((size_t)b * H + py_y[m]) * W + px_x) * p.out_ps;
 #pragma unroll
         for (int n = 0; n < NF; ++n)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c0 = n * 32 + 8 * g + 4 * h;
-                if (c0 >= p.cstore) continue;
-                store4(op + c0, acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]);
-            }
+            if (p.cstore - n * 32 > 0) store_frag(op + n * 32, acc[m][n], h, p.cstore - n * 32, [](float v, int) { return v; });
     }
 }
 

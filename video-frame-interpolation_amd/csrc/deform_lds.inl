@@ -129,52 +129,55 @@ __global__ __launch_bounds__(512) void deform_lds_kernel(const DeformParams p)
             for (int m = 0; m < 2; ++m) nxt[m] = load_om(om[m], tap + 1, in_img[m]);
         }
         const char *wb = lds_w + cur * C::WTAP + lane * 16;
+        // sampling geometry of this lane's two pixels for this tap
+        SampleTap st[2];
+        unsigned lo[2][4];
+        bool inside[2], all_inside[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             int yc0, yc1, xc0, xc1;
-            const SampleTap st = sample_tap_vals(now[m].dy, now[m].dx, now[m].mk, tap, py_y[m], px_x, H, W, ps_bytes, &yc0, &yc1, &xc0, &xc1);
-            const bool inside = yc0 >= ty0 && yc1 <= ty0 + C::TR - 1 && xc0 >= tx0 && xc1 <= tx0 + C::TC - 1;
+            st[m] = sample_tap_vals(now[m].dy, now[m].dx, now[m].mk, tap, py_y[m], px_x, H, W, ps_bytes, &yc0, &yc1, &xc0, &xc1);
+            inside[m] = yc0 >= ty0 && yc1 <= ty0 + C::TR - 1 && xc0 >= tx0 && xc1 <= tx0 + C::TC - 1;
             // window-local corner offsets, clamped into the window so every lane's LDS read is in
             // bounds; lanes that are not `inside` overwrite what they read with the global gather
             const int ly0 = min(max(yc0 - ty0, 0), C::TR - 1), ly1 = min(max(yc1 - ty0, 0), C::TR - 1);
             const int lx0 = min(max(xc0 - tx0, 0), C::TC - 1), lx1 = min(max(xc1 - tx0, 0), C::TC - 1);
-            const unsigned lo[4] = {(unsigned)(ly0 * C::TC + lx0) * C::PSB, (unsigned)(ly0 * C::TC + lx1) * C::PSB,
-                                    (unsigned)(ly1 * C::TC + lx0) * C::PSB, (unsigned)(ly1 * C::TC + lx1) * C::PSB};
-            const bool all_inside = __all(inside);
+            lo[m][0] = (unsigned)(ly0 * C::TC + lx0) * C::PSB; lo[m][1] = (unsigned)(ly0 * C::TC + lx1) * C::PSB;
+            lo[m][2] = (unsigned)(ly1 * C::TC + lx0) * C::PSB; lo[m][3] = (unsigned)(ly1 * C::TC + lx1) * C::PSB;
+            all_inside[m] = __all(inside[m]);
+        }
+        // software pipeline over the 2*KG (row, k-group) steps: the four corner pieces of step s+1
+        // are in flight while step s is blended and contracted
+        auto gather = [&](int sidx, uint4 (&v)[4]) {
+            const int m = sidx / C::KG, kg = sidx - m * C::KG;
+            // slot of this lane's piece in the staged pixel; pieces past the staged channels
+            // (zero weights) re-read the last slot
+            const int slot = (2 * kg + h < C::SP) ? 2 * kg + h : C::SP - 1;
 #pragma unroll
-            for (int k0 = 0; k0 < C::KG; k0 += C::KB) {
-                uint4 v[C::KB][4];
+            for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const uint4 *>(lds_x + lo[m][c] + (unsigned)(slot * 16));
+            if (!all_inside[m]) {   // wave-uniform: some lane reaches past the window
+                if (!inside[m]) {   // one divergent region per step
 #pragma unroll
-                for (int kk = 0; kk < C::KB; ++kk) {
-                    // slot of this lane's piece in the staged pixel; pieces past the staged channels
-                    // (zero weights) re-read the last slot
-                    const int slot = (2 * (k0 + kk) + h < C::SP) ? 2 * (k0 + kk) + h : C::SP - 1;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[kk][c] = *reinterpret_cast<const uint4 *>(lds_x + lo[c] + (unsigned)(slot * 16));
+                    for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const uint4 *>(gx + st[m].o[c] + (unsigned)(kg * 32));
                 }
-                if (!all_inside) {      // wave-uniform: some lane reaches past the window
-                    if (!inside) {      // ONE divergent region per batch
+            }
+        };
+        uint4 vb[2][4];
+        gather(0, vb[0]);
 #pragma unroll
-                        for (int kk = 0; kk < C::KB; ++kk)
+        for (int sidx = 0; sidx < 2 * C::KG; ++sidx) {
+            if (sidx + 1 < 2 * C::KG) gather(sidx + 1, vb[(sidx + 1) & 1]);
+            const int m = sidx / C::KG, kg = sidx - m * C::KG;
+            const bf16x8 xf = blend4(vb[sidx & 1], st[m].w, bf16_t{});
 #pragma unroll
-                            for (int c = 0; c < 4; ++c)
-                                v[kk][c] = *reinterpret_cast<const uint4 *>(gx + st.o[c] + (unsigned)((k0 + kk) * 32));
-                    }
-                }
-                bf16x8 xf[C::KB];
-#pragma unroll
-                for (int kk = 0; kk < C::KB; ++kk) xf[kk] = blend4(v[kk], st.w, bf16_t{});
-#pragma unroll
-                for (int kk = 0; kk < C::KB; ++kk)
-#pragma unroll
-                    for (int n = 0; n < NF; ++n) {
-                        const bf16x8 wv = *reinterpret_cast<const bf16x8 *>(wb + ((k0 + kk) * NF + n) * 1024);
-                        mma_kg(acc[m][n], wv, xf[kk]);
-                    }
-#pragma unroll
-                for (int n = 0; n < NF; ++n) mfma_retire(acc[m][n]);
+            for (int n = 0; n < NF; ++n) {
+                const bf16x8 wv = *reinterpret_cast<const bf16x8 *>(wb + (kg * NF + n) * 1024);
+                mma_kg(acc[m][n], wv, xf);
             }
         }
+        // retire the tap's accumulator chains before the next tap's geometry code (common.h)
+#pragma unroll
+        for (int n = 0; n < NF; ++n) { mfma_retire(acc[0][n]); mfma_retire(acc[1][n]); }
         if (tap < 8) {
             __syncthreads();  // drains the next tap's weight DMA; everyone is done with buffer `cur`
             cur ^= 1;
@@ -187,12 +190,7 @@ __global__ __launch_bounds__(512) void deform_lds_kernel(const DeformParams p)
         bf16_t *op = reinterpret_cast<bf16_t *>(p.out) + (((size_t)b * H + py_y[m]) * W + px_x) * p.out_ps;
 #pragma unroll
         for (int n = 0; n < NF; ++n)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c0 = n * 32 + 8 * g + 4 * h;
-                if (c0 >= p.cstore) continue;
-                store4(op + c0, acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]);
-            }
+            if (p.cstore - n * 32 > 0) store_frag(op + n * 32, acc[m][n], h, p.cstore - n * 32, [](float v, int) { return v; });
     }
 }
 
