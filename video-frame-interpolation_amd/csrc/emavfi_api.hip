@@ -212,7 +212,7 @@ void carve_forward(const Plan &P, Workspace &ws, FwdBuffers &f, int B, int H, in
     f.H2 = (H + 1) / 2; f.W2 = (W + 1) / 2; f.H4 = (f.H2 + 1) / 2; f.W4 = (f.W2 + 1) / 2;
     f.p2 = rup(2 * P.mid, 16); f.p4 = rup(4 * P.mid, 16); f.p_half = rup(P.mid / 2, 16);
     const int npix4 = f.H4 * f.W4;
-    f.nparts = npix4 >= 64 * 64 ? 64 : (npix4 >= 64 ? npix4 / 64 : 1);
+    f.nparts = npix4 >= 256 * 64 ? 256 : (npix4 >= 64 ? npix4 / 64 : 1);  // >= 64 pixels per partial sum
     f.in16 = ws.take(px * 16 * e);
     f.fA = ws.take(px * P.p_mid * e);
     f.fB = ws.take(px * P.p_mid * e);

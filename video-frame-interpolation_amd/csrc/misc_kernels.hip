@@ -94,6 +94,18 @@ __global__ void pack_input_kernel(const float *__restrict__ f1, const float *__r
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t b = i / plane, pix = i - b * plane;
         T *o = dst + i * cpad;
+        if (cpad == 16) {  // the model's case (2*in_channels <= 16): one pixel = 16 channels, 16-byte stores
+            float v[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                v[c] = 0.0f;
+                if (c < C) v[c] = f1[(b * C + c) * plane + pix];
+                else if (c < 2 * C) v[c] = f2[(b * C + (c - C)) * plane + pix];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) store4(o + 4 * q, v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+            continue;
+        }
         for (int c = 0; c < cpad; ++c) {
             float v = 0.0f;
             if (c < C) v = f1[(b * C + c) * plane + pix];
@@ -432,6 +444,13 @@ __global__ __launch_bounds__(256) void warp_tiled_kernel(const float *__restrict
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 T *o = reinterpret_cast<T *>(cl_dst) + ((size_t)b * plane + pix + q) * ps + coff;
+                if (ps - coff == 16 && (coff & 7) == 0) {  // mid_channels 64: channels 64..79, aligned
+                    store4(o, v[0][q], C > 1 ? v[C > 1 ? 1 : 0][q] : 0.0f, C > 2 ? v[C > 2 ? 2 : 0][q] : 0.0f, 0.0f);
+                    store4(o + 4, 0.0f, 0.0f, 0.0f, 0.0f);
+                    store4(o + 8, 0.0f, 0.0f, 0.0f, 0.0f);
+                    store4(o + 12, 0.0f, 0.0f, 0.0f, 0.0f);
+                    continue;
+                }
 #pragma unroll
                 for (int c = 0; c < C; ++c) o[c] = (T)v[c][q];
                 for (int c = C; c < ps - coff; ++c) o[c] = (T)0.0f;
