@@ -64,10 +64,12 @@ __device__ __forceinline__ SampleTap sample_tap_vals(float dy, float dx, float m
     const int hlc = min(max(hl, 0), H - 1), wlc = min(max(wl, 0), W - 1);
     const int hhc = min(max(hh, 0), H - 1), whc = min(max(wh, 0), W - 1);
     if (yc0) { *yc0 = hlc; *yc1 = hhc; *xc0 = wlc; *xc1 = whc; }  // clamped corner coordinates
-    t.o[0] = (unsigned)(hlc * W + wlc) * ps_bytes;
-    t.o[1] = (unsigned)(hlc * W + whc) * ps_bytes;
-    t.o[2] = (unsigned)(hhc * W + wlc) * ps_bytes;
-    t.o[3] = (unsigned)(hhc * W + whc) * ps_bytes;
+    // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): rows, W and pixel indices are < 2^24
+    const unsigned r0 = __umul24((unsigned)hlc, (unsigned)W), r1 = __umul24((unsigned)hhc, (unsigned)W);
+    t.o[0] = __umul24(r0 + wlc, ps_bytes);
+    t.o[1] = __umul24(r0 + whc, ps_bytes);
+    t.o[2] = __umul24(r1 + wlc, ps_bytes);
+    t.o[3] = __umul24(r1 + whc, ps_bytes);
     const int vhl = min(max(hl + 1, 0), 1) * min(max(H - hl, 0), 1);  // 0 <= hl <= H-1
     const int vhh = min(max(hh + 1, 0), 1) * min(max(H - hh, 0), 1);
     const int vwl = min(max(wl + 1, 0), 1) * min(max(W - wl, 0), 1);

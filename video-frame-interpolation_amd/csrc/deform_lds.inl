@@ -2,8 +2,9 @@
 // halo" of BASELINE.json).  Same operator and fragment scheme as deform.inl; what changes is
 // where the bilinear taps are fetched from:
 //
-//   * a 512-thread workgroup (8 waves = 2 per SIMD, so one wave's gather/blend VALU overlaps its
-//     partner's MFMAs) owns a 16x32 output tile; wave w owns rows 2w, 2w+1;
+//   * one workgroup owns a 16x32 output tile; a wave owns RPW rows (RPW = 1: 1024 threads, 16 waves =
+//     4 per SIMD, <= 128 VGPRs; RPW = 2: 512 threads, 8 waves) - the waves sharing a SIMD overlap one
+//     wave's gather/blend VALU and LDS latency with another's MFMAs;
 //   * the input window = tile + halo of 1 (3x3 taps) + R (offset reach) + 1 (bilinear) pixels
 //     is brought into LDS ONCE by global->LDS DMA (global_load_lds_dwordx4, every lane with its
 //     own source address, out-of-image pixels read a zero page): (19+2R) x (35+2R) pixels x CS
@@ -21,7 +22,8 @@
 //     per tap); the next tap's (dy, dx, mask) are fetched one tap ahead as well.
 #include "deform.inl"
 
-template <int CK, int NF, int CS, int R> struct DeformLdsCfg {
+template <int CK, int NF, int CS, int R, int RPW> struct DeformLdsCfg {
+    static constexpr int WAVES = 16 / RPW, THREADS = 64 * WAVES;
     static constexpr int TROWS = 16, TCOLS = 32;
     static constexpr int TR = TROWS + 3 + 2 * R, TC = TCOLS + 3 + 2 * R;
     static constexpr int SP = CS * 2 / 16;    // 16-byte slots per staged pixel
@@ -48,10 +50,10 @@ __device__ __forceinline__ OmTap load_om(const float *__restrict__ om, int tap, 
     return t;
 }
 
-template <int CK, int NF, int CS, int R>
-__global__ __launch_bounds__(512) void deform_lds_kernel(const DeformParams p)
+template <int CK, int NF, int CS, int R, int RPW>
+__global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const DeformParams p)
 {
-    using C = DeformLdsCfg<CK, NF, CS, R>;
+    using C = DeformLdsCfg<CK, NF, CS, R, RPW>;
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -69,8 +71,8 @@ __global__ __launch_bounds__(512) void deform_lds_kernel(const DeformParams p)
 
     // ---- DMA the input window (zero outside the image) and tap 0's weights ----
 #pragma unroll
-    for (int i = 0; i < (C::NINST + 7) / 8; ++i) {
-        const int j = i * 8 + wave;
+    for (int i = 0; i < (C::NINST + C::WAVES - 1) / C::WAVES; ++i) {
+        const int j = i * C::WAVES + wave;
         if (j < C::NINST) {
             const int sl = j * 64 + lane;
             const int pix = sl / C::SP, pc = sl - pix * C::SP;
@@ -82,28 +84,28 @@ __global__ __launch_bounds__(512) void deform_lds_kernel(const DeformParams p)
         }
     }
 #pragma unroll
-    for (int i = 0; i < (C::WINST + 7) / 8; ++i) {
-        const int j = i * 8 + wave;
+    for (int i = 0; i < (C::WINST + C::WAVES - 1) / C::WAVES; ++i) {
+        const int j = i * C::WAVES + wave;
         if (j < C::WINST)
             __builtin_amdgcn_global_load_lds((gptr_t *)((const char *)p.w + j * 1024 + lane * 16), (lptr_t *)(lds_w + j * 1024), 16, 0, 0);
     }
 
-    f32x16 acc[2][NF];
+    f32x16 acc[RPW][NF];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < RPW; ++m)
 #pragma unroll
         for (int n = 0; n < NF; ++n)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[m][n][i] = p.bias[n * 32 + acc_channel(i, h)];
 
     const int px_x = blockIdx.x * C::TCOLS + r;
-    int py_y[2];
-    bool in_img[2];
-    const float *om[2];
-    OmTap nxt[2];
+    int py_y[RPW];
+    bool in_img[RPW];
+    const float *om[RPW];
+    OmTap nxt[RPW];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        py_y[m] = blockIdx.y * C::TROWS + wave * 2 + m;
+    for (int m = 0; m < RPW; ++m) {
+        py_y[m] = blockIdx.y * C::TROWS + wave * RPW + m;
         in_img[m] = py_y[m] < H && px_x < W;
         om[m] = p.om + (((size_t)b * H + (in_img[m] ? py_y[m] : 0)) * W + (in_img[m] ? px_x : 0)) * 32;
         nxt[m] = load_om(om[m], 0, in_img[m]);
@@ -116,25 +118,27 @@ __global__ __launch_bounds__(512) void deform_lds_kernel(const DeformParams p)
     for (int tap = 0; tap < 9; ++tap) {
         if (tap < 8) {
 #pragma unroll
-            for (int i = 0; i < (C::WINST + 7) / 8; ++i) {
-                const int j = i * 8 + wave;
+            for (int i = 0; i < (C::WINST + C::WAVES - 1) / C::WAVES; ++i) {
+                const int j = i * C::WAVES + wave;
                 if (j < C::WINST)
                     __builtin_amdgcn_global_load_lds((gptr_t *)((const char *)p.w + (size_t)(tap + 1) * C::WTAP + j * 1024 + lane * 16),
                                                      (lptr_t *)(lds_w + (cur ^ 1) * C::WTAP + j * 1024), 16, 0, 0);
             }
         }
-        OmTap now[2] = {nxt[0], nxt[1]};
+        OmTap now[RPW];
+#pragma unroll
+        for (int m = 0; m < RPW; ++m) now[m] = nxt[m];
         if (tap < 8) {
 #pragma unroll
-            for (int m = 0; m < 2; ++m) nxt[m] = load_om(om[m], tap + 1, in_img[m]);
+            for (int m = 0; m < RPW; ++m) nxt[m] = load_om(om[m], tap + 1, in_img[m]);
         }
         const char *wb = lds_w + cur * C::WTAP + lane * 16;
         // sampling geometry of this lane's two pixels for this tap
-        SampleTap st[2];
-        unsigned lo[2][4];
-        bool inside[2], all_inside[2];
+        SampleTap st[RPW];
+        unsigned lo[RPW][4];
+        bool inside[RPW], all_inside[RPW];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+        for (int m = 0; m < RPW; ++m) {
             int yc0, yc1, xc0, xc1;
             st[m] = sample_tap_vals(now[m].dy, now[m].dx, now[m].mk, tap, py_y[m], px_x, H, W, ps_bytes, &yc0, &yc1, &xc0, &xc1);
             inside[m] = yc0 >= ty0 && yc1 <= ty0 + C::TR - 1 && xc0 >= tx0 && xc1 <= tx0 + C::TC - 1;
@@ -142,11 +146,12 @@ __global__ __launch_bounds__(512) void deform_lds_kernel(const DeformParams p)
             // bounds; lanes that are not `inside` overwrite what they read with the global gather
             const int ly0 = min(max(yc0 - ty0, 0), C::TR - 1), ly1 = min(max(yc1 - ty0, 0), C::TR - 1);
             const int lx0 = min(max(xc0 - tx0, 0), C::TC - 1), lx1 = min(max(xc1 - tx0, 0), C::TC - 1);
-            lo[m][0] = (unsigned)(ly0 * C::TC + lx0) * C::PSB; lo[m][1] = (unsigned)(ly0 * C::TC + lx1) * C::PSB;
-            lo[m][2] = (unsigned)(ly1 * C::TC + lx0) * C::PSB; lo[m][3] = (unsigned)(ly1 * C::TC + lx1) * C::PSB;
+            const unsigned q0 = __umul24((unsigned)ly0, (unsigned)C::TC), q1 = __umul24((unsigned)ly1, (unsigned)C::TC);
+            lo[m][0] = __umul24(q0 + lx0, (unsigned)C::PSB); lo[m][1] = __umul24(q0 + lx1, (unsigned)C::PSB);
+            lo[m][2] = __umul24(q1 + lx0, (unsigned)C::PSB); lo[m][3] = __umul24(q1 + lx1, (unsigned)C::PSB);
             all_inside[m] = __all(inside[m]);
         }
-        // software pipeline over the 2*KG (row, k-group) steps: the four corner pieces of step s+1
+        // software pipeline over the RPW*KG (row, k-group) steps: the four corner pieces of step s+1
         // are in flight while step s is blended and contracted
         auto gather = [&](int sidx, uint4 (&v)[4]) {
             const int m = sidx / C::KG, kg = sidx - m * C::KG;
@@ -165,8 +170,8 @@ __global__ __launch_bounds__(512) void deform_lds_kernel(const DeformParams p)
         uint4 vb[2][4];
         gather(0, vb[0]);
 #pragma unroll
-        for (int sidx = 0; sidx < 2 * C::KG; ++sidx) {
-            if (sidx + 1 < 2 * C::KG) gather(sidx + 1, vb[(sidx + 1) & 1]);
+        for (int sidx = 0; sidx < RPW * C::KG; ++sidx) {
+            if (sidx + 1 < RPW * C::KG) gather(sidx + 1, vb[(sidx + 1) & 1]);
             const int m = sidx / C::KG, kg = sidx - m * C::KG;
             const bf16x8 xf = blend4(vb[sidx & 1], st[m].w, bf16_t{});
 #pragma unroll
@@ -177,7 +182,9 @@ __global__ __launch_bounds__(512) void deform_lds_kernel(const DeformParams p)
         }
         // retire the tap's accumulator chains before the next tap's geometry code (common.h)
 #pragma unroll
-        for (int n = 0; n < NF; ++n) { mfma_retire(acc[0][n]); mfma_retire(acc[1][n]); }
+        for (int m = 0; m < RPW; ++m)
+#pragma unroll
+            for (int n = 0; n < NF; ++n) mfma_retire(acc[m][n]);
         if (tap < 8) {
             __syncthreads();  // drains the next tap's weight DMA; everyone is done with buffer `cur`
             cur ^= 1;
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(512) void deform_lds_kernel(const DeformParams p)
     }
 
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < RPW; ++m) {
         if (!in_img[m]) continue;
         bf16_t *op = reinterpret_cast<bf16_t *>(p.out) + (((size_t)b * H + py_y[m]) * W + px_x) * p.out_ps;
 #pragma unroll
@@ -194,17 +201,17 @@ __global__ __launch_bounds__(512) void deform_lds_kernel(const DeformParams p)
     }
 }
 
-template <int CK, int NF, int CS, int R> static int launch_deform_lds(const DeformParams &p, hipStream_t s)
+template <int CK, int NF, int CS, int R, int RPW> static int launch_deform_lds(const DeformParams &p, hipStream_t s)
 {
-    using C = DeformLdsCfg<CK, NF, CS, R>;
+    using C = DeformLdsCfg<CK, NF, CS, R, RPW>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&deform_lds_kernel<CK, NF, CS, R>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&deform_lds_kernel<CK, NF, CS, R, RPW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
     dim3 grid((p.W + C::TCOLS - 1) / C::TCOLS, (p.H + C::TROWS - 1) / C::TROWS, p.B);
-    deform_lds_kernel<CK, NF, CS, R><<<grid, 512, C::LDS_BYTES, s>>>(p);
+    deform_lds_kernel<CK, NF, CS, R, RPW><<<grid, C::THREADS, C::LDS_BYTES, s>>>(p);
     return (int)hipGetLastError();
 }

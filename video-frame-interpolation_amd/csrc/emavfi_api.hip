@@ -290,6 +290,7 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
     if (B < 1 || H < 1 || W < 1) return fail(EMAVFI_E_ARG, "forward: B, H, W must be >= 1 (got %d, %d, %d)", B, H, W);
     if ((size_t)B * H * W >= ((size_t)1 << 31)) return fail(EMAVFI_E_ARG, "forward: B*H*W must be < 2^31");
     if ((size_t)H * W * P.fpad * P.esize >= ((size_t)1 << 32)) return fail(EMAVFI_E_ARG, "forward: one sample's activation plane must be < 4 GiB");
+    if ((size_t)H * W >= ((size_t)1 << 24)) return fail(EMAVFI_E_ARG, "forward: H*W must be < 2^24 (24-bit pixel index arithmetic in the gather kernels)");
     Workspace ws{(char *)workspace, workspace_bytes, 0};
     FwdBuffers f;
     carve_forward(P, ws, f, B, H, W);
@@ -597,6 +598,7 @@ int emavfi_deform_conv2d(const float *x, const float *offset, const float *mask,
     if (dtype != EMAVFI_F32 && dtype != EMAVFI_BF16) return fail(EMAVFI_E_ARG, "deform_conv2d: bad dtype %d", dtype);
     if (!x || !offset || !mask || !weight || !y || !workspace) return fail(EMAVFI_E_ARG, "deform_conv2d: null pointer");
     if (B < 1 || C < 1 || O < 1 || H < 1 || W < 1) return fail(EMAVFI_E_ARG, "deform_conv2d: bad shape");
+    if ((size_t)H * W >= ((size_t)1 << 24)) return fail(EMAVFI_E_ARG, "deform_conv2d: H*W must be < 2^24");
     Plan P{};
     P.dtype = dtype; P.esize = dtype == EMAVFI_F32 ? 4 : 2;
     Layer L = mk(0, O, C);
