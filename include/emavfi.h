@@ -113,6 +113,20 @@ int emavfi_forward_profiled(int in_channels, int mid_channels, int num_blocks, c
 int emavfi_warp(const float *frame2, const float *flow, float *out,
                 int B, int C, int H, int W, void *stream);
 
+/* Frame pre/post-processing around the forward (the reference does both on the host, per frame).
+ * emavfi_preprocess_u8: transforms.ToTensor() + Normalize(mean, std), inference.py:38-41 / :44-48
+ *   (cv2.resize excluded): frames_hwc uint8 [B,H,W,C] -> out_nchw fp32 [B,C,H,W] = ((u8/255) - mean[c]) / std[c].
+ * emavfi_postprocess_u8: denormalize_frame, inference.py:51-58: frames_nchw fp32 [B,C,H,W] -> out_hwc uint8
+ *   [B,H,W,C] = uint8(clip(x * std[c] + mean[c], 0, 1) * 255) (truncation; float64 arithmetic as numpy's
+ *   promotion makes it there).  denormalize = 0 skips the x*std+mean step, which the reference applies to an
+ *   output that is already in [0,1].
+ * `mean` and `std` are HOST pointers to C values (C <= 4): fp32 for preprocess (torchvision builds fp32
+ * tensors), float64 for postprocess (numpy's np.array([...]) constants); the frame pointers are device pointers. */
+int emavfi_preprocess_u8(const unsigned char *frames_hwc, float *out_nchw, int B, int H, int W, int C,
+                         const float *mean, const float *std, void *stream);
+int emavfi_postprocess_u8(const float *frames_nchw, unsigned char *out_hwc, int B, int H, int W, int C,
+                          const double *mean, const double *std, int denormalize, void *stream);
+
 /* One conv / conv_block (ema_vfi.py:7-14): Conv2d(k=3, p=1, stride 1 or 2) + activation.
  * x [B,Cin,H,W], weight [Cout,Cin,3,3], bias [Cout], y [B,Cout,ceil(H/stride),ceil(W/stride)]. */
 size_t emavfi_conv3x3_workspace_bytes(int B, int Cin, int Cout, int H, int W, int stride, int dtype);

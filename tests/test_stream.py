@@ -1,0 +1,116 @@
+"""GPU pre/post-processing and the streaming harness, against a plain
+restatement of the reference's host loop (inference.py:38-58, 146-205)."""
+import numpy as np
+import pytest
+import torch
+
+from emavfi import EMA_VFI, FrameInterpolator, lib, synth
+from oracle import emavfi_oracle as oracle
+
+MEAN = np.array([0.485, 0.456, 0.406])   # inference.py:40 (float64 in numpy, as there)
+STD = np.array([0.229, 0.224, 0.225])
+
+
+def ref_preprocess(u8_hwc):
+    """transforms.ToTensor() + Normalize (inference.py:38-41): /255 then (x - mean) / std, fp32."""
+    t = torch.from_numpy(u8_hwc).permute(2, 0, 1).float().div(255)
+    mean = torch.tensor(MEAN, dtype=torch.float32).view(3, 1, 1)
+    std = torch.tensor(STD, dtype=torch.float32).view(3, 1, 1)
+    return t.sub(mean).div(std)
+
+
+def ref_denormalize(t_chw):
+    """denormalize_frame (inference.py:51-58) verbatim in numpy."""
+    frame = t_chw.float().numpy()
+    frame = np.transpose(frame, (1, 2, 0))
+    frame = (frame * STD) + MEAN
+    frame = np.clip(frame, 0, 1)
+    return (frame * 255).astype(np.uint8)
+
+
+def ref_loop(frames, forward, factor, interval):
+    """The reference's while-loop (inference.py:158-201) on in-memory frames."""
+    out, it = [], iter(frames)
+    frame1 = next(it, None)
+    if frame1 is None:
+        return out
+    t1, frame_num = ref_preprocess(frame1), 0
+    while True:
+        frame_num += 1
+        frame2 = next(it, None)
+        if frame_num % interval == 0:
+            if frame2 is None:
+                out.append(frame1)
+                break
+            t2 = ref_preprocess(frame2)
+            for _ in range(factor):
+                out.append(ref_denormalize(forward(t1[None], t2[None])[0]))
+            out.append(ref_denormalize(t1))
+            frame1, t1 = frame2, t2
+        else:
+            if frame2 is None:
+                out.append(ref_denormalize(t1))
+                break
+            frame1, t1 = frame2, ref_preprocess(frame2)
+    return out
+
+
+def test_schedule_matches_reference_loop_counts():
+    for n in range(0, 9):
+        for interval in (1, 2, 3):
+            frames = [np.full((2, 2, 3), i, np.uint8) for i in range(n)]
+            ref = ref_loop(frames, lambda a, b: torch.zeros(1, 3, 2, 2), 2, interval)
+            pairs, last = FrameInterpolator.schedule(n, interval)
+            assert (0 if last is None else len(pairs) * 3 + 1) == len(ref), (n, interval)
+
+
+@pytest.mark.gpu
+def test_preprocess_and_postprocess_bit_exact():
+    g = np.random.default_rng(0)
+    u8 = g.integers(0, 256, (3, 37, 53, 3), dtype=np.uint8)
+    got = lib.preprocess_u8(torch.from_numpy(u8).cuda()).cpu()
+    ref = torch.stack([ref_preprocess(f) for f in u8])
+    assert torch.equal(got, ref)
+    x = torch.from_numpy(g.normal(0.4, 0.6, (2, 3, 19, 31)).astype(np.float32))
+    x[0, 0, 0, 0], x[0, 1, 0, 0] = 5.0, -5.0
+    for denorm in (True, False):
+        got = lib.postprocess_u8(x.cuda(), denormalize=denorm).cpu().numpy()
+        if denorm:
+            ref = np.stack([ref_denormalize(t) for t in x])
+        else:
+            ref = (np.clip(np.transpose(x.numpy(), (0, 2, 3, 1)).astype(np.float64), 0, 1) * 255).astype(np.uint8)
+        assert np.array_equal(got, ref)
+    # round trip of a source frame: what the reference writes for frame1 (inference.py:187-188)
+    rt = lib.postprocess_u8(lib.preprocess_u8(torch.from_numpy(u8).cuda())).cpu().numpy()
+    assert np.array_equal(rt, np.stack([ref_denormalize(ref_preprocess(f)) for f in u8]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("factor,interval,batch", [(1, 1, 8), (3, 1, 2), (2, 2, 3)])
+def test_stream_matches_reference_loop(factor, interval, batch):
+    sd = synth.synthetic_state_dict(seed=21, mid_channels=8)
+    f1, _ = synth.synthetic_frames_u8(5, 7, 24, 32, "natural")
+    frames = [f for f in f1]
+    model = EMA_VFI(mid_channels=8, compute_dtype="fp32").cuda().eval()
+    model.load_state_dict(sd)
+    got = list(FrameInterpolator(model, factor, interval, batch_pairs=batch).run(frames))
+    ref = ref_loop(frames, lambda a, b: oracle.forward(sd, a, b), factor, interval)
+    assert len(got) == len(ref)
+    assert len(got) == FrameInterpolator(model, factor, interval).count_outputs(len(frames))
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape and a.dtype == np.uint8
+        # predictions may differ by one count where a ~1e-6 difference crosses a truncation boundary
+        assert np.abs(a.astype(np.int16) - b.astype(np.int16)).max() <= 1
+    assert np.array_equal(got[-1], frames[-1])  # last frame is written raw
+
+
+@pytest.mark.gpu
+def test_stream_without_quirks_passes_sources_through():
+    sd = synth.synthetic_state_dict(seed=22, mid_channels=8)
+    frames = [f for f in synth.synthetic_frames_u8(6, 4, 16, 32, "stress")[0]]
+    model = EMA_VFI(mid_channels=8, compute_dtype="fp32").cuda().eval()
+    model.load_state_dict(sd)
+    got = list(FrameInterpolator(model, 1, 1, reference_quirks=False).run(frames))
+    assert len(got) == 2 * 3 + 1
+    for k in range(3):
+        assert np.array_equal(got[2 * k + 1], frames[k])

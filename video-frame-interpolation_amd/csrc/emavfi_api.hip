@@ -514,6 +514,27 @@ int emavfi_warp(const float *frame2, const float *flow, float *out, int B, int C
     return EMAVFI_OK;
 }
 
+int emavfi_preprocess_u8(const unsigned char *frames_hwc, float *out_nchw, int B, int H, int W, int C, const float *mean,
+                         const float *std, void *stream)
+{
+    if (!frames_hwc || !out_nchw || !mean || !std) return fail(EMAVFI_E_ARG, "preprocess_u8: null pointer");
+    if (B < 1 || H < 1 || W < 1 || C < 1 || C > 4) return fail(EMAVFI_E_ARG, "preprocess_u8: bad shape (C must be 1..4)");
+    for (int c = 0; c < C; ++c)
+        if (!(std[c] != 0.0f)) return fail(EMAVFI_E_ARG, "preprocess_u8: std[%d] must be non-zero", c);
+    EMAVFI_TRY(launch_preprocess_u8(frames_hwc, out_nchw, B, H, W, C, mean, std, (hipStream_t)stream), "preprocess_u8");
+    return EMAVFI_OK;
+}
+
+int emavfi_postprocess_u8(const float *frames_nchw, unsigned char *out_hwc, int B, int H, int W, int C, const double *mean,
+                          const double *std, int denormalize, void *stream)
+{
+    if (!frames_nchw || !out_hwc || !mean || !std) return fail(EMAVFI_E_ARG, "postprocess_u8: null pointer");
+    if (B < 1 || H < 1 || W < 1 || C < 1 || C > 4) return fail(EMAVFI_E_ARG, "postprocess_u8: bad shape (C must be 1..4)");
+    EMAVFI_TRY(launch_postprocess_u8(frames_nchw, out_hwc, B, H, W, C, mean, std, denormalize ? 1 : 0, (hipStream_t)stream),
+               "postprocess_u8");
+    return EMAVFI_OK;
+}
+
 // ---- stage-level entries (diagnostics / parity tests of single operators) ----
 static bool single_conv_layer(Layer &L, int Cin, int Cout, int stride, int esize)
 {

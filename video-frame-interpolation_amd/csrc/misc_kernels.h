@@ -22,3 +22,7 @@ int launch_ctx_finish(const float *part, const float *ctxw, float *ctx_out, floa
 int launch_warp_nchw(const float *frame2, const float *flow, float *out, int B, int C, int H, int W, hipStream_t s);
 int launch_warp_fused(const float *frame2, const float *flow, void *dst, int B, int C, int H, int W, int ps, int coff, int dtype,
                       hipStream_t s);
+int launch_preprocess_u8(const unsigned char *src, float *dst, int B, int H, int W, int C, const float *mean, const float *stdv,
+                         hipStream_t s);
+int launch_postprocess_u8(const float *src, unsigned char *dst, int B, int H, int W, int C, const double *mean, const double *stdv,
+                          int denorm, hipStream_t s);

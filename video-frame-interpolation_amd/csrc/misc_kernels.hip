@@ -508,3 +508,63 @@ int launch_warp_fused(const float *frame2, const float *flow, void *dst, int B, 
     else warp_fused_kernel<bf16_t><<<grid, 256, 0, s>>>(frame2, flow, (bf16_t *)dst, B, C, H, W, ps, coff);
     return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------
+// Frame pre/post-processing on the GPU: what the reference does on the
+// host around every forward.
+//   preprocess:  transforms.ToTensor() + Normalize(mean, std)  (inference.py:38-41, 44-48):
+//                uint8 HWC -> float32 /255 -> (x - mean) / std, NCHW.  True fp32 divisions, same order.
+//   postprocess: denormalize_frame (inference.py:51-58): NCHW fp32 -> HWC, x * std + mean (the
+//                reference applies this to an output that is already in [0,1] - kept behind `denorm`),
+//                clip to [0,1], * 255, astype(uint8) (truncation).  numpy promotes to float64 there
+//                (np.array([...]) is float64), so the arithmetic here is double: bit-exact bytes.
+// ------------------------------------------------------------------------------------------
+struct Stats4 { float mean[4], stdv[4]; };
+struct Stats4d { double mean[4], stdv[4]; };  // numpy's float64 constants in denormalize_frame
+
+__global__ void preprocess_u8_kernel(const unsigned char *__restrict__ src, float *__restrict__ dst, int B, int H, int W, int C,
+                                     Stats4 st)
+{
+    const size_t plane = (size_t)H * W, total = (size_t)B * plane;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / plane, pix = i - b * plane;
+        const unsigned char *p = src + i * C;
+        for (int c = 0; c < C; ++c) {
+            const float v = (float)p[c] / 255.0f;
+            dst[(b * C + c) * plane + pix] = (v - st.mean[c]) / st.stdv[c];
+        }
+    }
+}
+__global__ void postprocess_u8_kernel(const float *__restrict__ src, unsigned char *__restrict__ dst, int B, int H, int W, int C,
+                                      Stats4d st, int denorm)
+{
+    const size_t plane = (size_t)H * W, total = (size_t)B * plane;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / plane, pix = i - b * plane;
+        unsigned char *p = dst + i * C;
+        for (int c = 0; c < C; ++c) {
+            double v = (double)src[(b * C + c) * plane + pix];
+            if (denorm) v = v * st.stdv[c] + st.mean[c];
+            v = fmin(fmax(v, 0.0), 1.0) * 255.0;   // NaN -> 0 (fmax), as np.clip then astype would not define
+            p[c] = (unsigned char)v;
+        }
+    }
+}
+int launch_preprocess_u8(const unsigned char *src, float *dst, int B, int H, int W, int C, const float *mean, const float *stdv,
+                         hipStream_t s)
+{
+    Stats4 st{};
+    for (int c = 0; c < C && c < 4; ++c) { st.mean[c] = mean[c]; st.stdv[c] = stdv[c]; }
+    const int grid = (int)std::min<size_t>(((size_t)B * H * W + 255) / 256, 65535 * 4);
+    preprocess_u8_kernel<<<grid, 256, 0, s>>>(src, dst, B, H, W, C, st);
+    return (int)hipGetLastError();
+}
+int launch_postprocess_u8(const float *src, unsigned char *dst, int B, int H, int W, int C, const double *mean, const double *stdv,
+                          int denorm, hipStream_t s)
+{
+    Stats4d st{};
+    for (int c = 0; c < C && c < 4; ++c) { st.mean[c] = mean[c]; st.stdv[c] = stdv[c]; }
+    const int grid = (int)std::min<size_t>(((size_t)B * H * W + 255) / 256, 65535 * 4);
+    postprocess_u8_kernel<<<grid, 256, 0, s>>>(src, dst, B, H, W, C, st, denorm);
+    return (int)hipGetLastError();
+}

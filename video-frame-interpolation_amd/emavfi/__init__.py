@@ -7,5 +7,6 @@
 """
 from .model import EMA_VFI, ModulatedDeformConvPack, DeformConv2d, conv, conv_block  # noqa: F401
 from . import lib, synth, dist  # noqa: F401
+from .stream import FrameInterpolator  # noqa: F401
 
-__all__ = ["EMA_VFI", "ModulatedDeformConvPack", "DeformConv2d", "conv", "conv_block", "lib", "synth", "dist"]
+__all__ = ["EMA_VFI", "ModulatedDeformConvPack", "DeformConv2d", "conv", "conv_block", "lib", "synth", "dist", "FrameInterpolator"]

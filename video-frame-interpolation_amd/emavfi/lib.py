@@ -30,6 +30,8 @@ _PROTOTYPES = {
     "emavfi_forward_launches": (c_int, [c_int] * 7 + [c_char_p, c_size_t, POINTER(ctypes.c_double), POINTER(ctypes.c_double), c_int]),
     "emavfi_forward_profiled": (c_int, [c_int] * 3 + [c_void_p] * 5 + [c_size_t] + [c_int] * 4 + [POINTER(c_void_p), c_int, c_void_p]),
     "emavfi_warp": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
+    "emavfi_preprocess_u8": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [POINTER(ctypes.c_float), POINTER(ctypes.c_float), c_void_p]),
+    "emavfi_postprocess_u8": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [POINTER(ctypes.c_double), POINTER(ctypes.c_double), c_int, c_void_p]),
     "emavfi_conv3x3_workspace_bytes": (c_size_t, [c_int] * 7),
     "emavfi_conv3x3": (c_int, [c_void_p] * 4 + [c_int] * 8 + [c_void_p, c_size_t, c_void_p]),
     "emavfi_deform_conv2d_workspace_bytes": (c_size_t, [c_int] * 6),
@@ -188,3 +190,44 @@ def forward_launches(in_channels, mid_channels, num_blocks, B, H, W, dtype):
           "emavfi_forward_launches")
     labels = names.value.decode().strip().split("\n")
     return [(labels[i], fl[i], by[i]) for i in range(n)]
+
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)  # reference inference.py:40
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def _stats(mean, std, C, ctype=ctypes.c_float):
+    if len(mean) != C or len(std) != C:
+        raise ValueError(f"mean/std must have {C} entries")
+    return (ctype * C)(*mean), (ctype * C)(*std)
+
+
+def preprocess_u8(frames_hwc, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+    """ToTensor + Normalize of reference inference.py:38-41 on the GPU: uint8 [B,H,W,C] -> fp32 [B,C,H,W]."""
+    import torch
+    _require_cuda(frames_hwc)
+    if frames_hwc.dtype != torch.uint8 or frames_hwc.dim() != 4:
+        raise ValueError("preprocess_u8: uint8 [B,H,W,C] tensor expected")
+    x = frames_hwc.contiguous()
+    B, H, W, C = x.shape
+    m, s = _stats(mean, std, C)
+    out = torch.empty(B, C, H, W, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(load().emavfi_preprocess_u8(x.data_ptr(), out.data_ptr(), B, H, W, C, m, s, _stream()), "emavfi_preprocess_u8")
+    return out
+
+
+def postprocess_u8(frames_nchw, denormalize=True, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+    """denormalize_frame of reference inference.py:51-58 on the GPU: fp32 [B,C,H,W] -> uint8 [B,H,W,C]."""
+    import torch
+    _require_cuda(frames_nchw)
+    x = _f32c(frames_nchw)
+    if x.dim() != 4:
+        raise ValueError("postprocess_u8: [B,C,H,W] tensor expected")
+    B, C, H, W = x.shape
+    m, s = _stats(mean, std, C, ctypes.c_double)  # numpy's float64 constants (inference.py:55)
+    out = torch.empty(B, H, W, C, dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        check(load().emavfi_postprocess_u8(x.data_ptr(), out.data_ptr(), B, H, W, C, m, s, 1 if denormalize else 0, _stream()),
+              "emavfi_postprocess_u8")
+    return out
