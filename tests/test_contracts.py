@@ -1,0 +1,86 @@
+"""Driver-facing contracts: bench.py's JSON line, __graft_entry__.smoke(), launch enumeration, size limits."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT
+from emavfi import EMA_VFI, lib, synth
+
+
+def test_forward_launch_enumeration_matches_survey_flops():
+    """1 054 908 FLOP/px in the reference's formulation; this build folds the
+    broadcast-context half of motion_estimation.0 (2*36 864 FLOP/px) into a bias and adds ~24 FLOP/px of warp."""
+    B, H, W = 2, 64, 96
+    launches = lib.forward_launches(3, 64, 3, B, H, W, "bf16")
+    names = [n for n, _, _ in launches]
+    assert len(launches) == 23 and names[0] == "pack_input" and names[-1].startswith("conv3x3<bf16,ck=32,nf=1,s=1>")
+    assert sum(n.startswith("deform<") for n in names) == 3
+    per_px = sum(f for _, f, _ in launches) / (B * H * W)
+    assert abs(per_px - (1054908 - 2 * 36864 + 24)) < 1.0
+    assert all(b > 0 for _, _, b in launches)
+    # fp32 labels and byte counts differ, flops do not
+    l32 = lib.forward_launches(3, 64, 3, B, H, W, "fp32")
+    assert [f for _, f, _ in l32] == [f for _, f, _ in launches]
+    assert all("f32" in n for n, _, _ in l32 if "<" in n)
+
+
+def test_size_limits_are_argument_errors_not_crashes():
+    L = lib.load()
+    rc = L.emavfi_forward(3, 64, 3, None, None, None, None, None, 0, 1, 4096, 4096, lib.BF16, None, None)
+    assert rc == -1 and "2^24" in lib.last_error()
+    rc = L.emavfi_forward(3, 64, 3, None, None, None, None, None, 0, 1, 8192, 4096, lib.F32, None, None)
+    assert rc == -1 and "4 GiB" in lib.last_error()
+    assert L.emavfi_forward_launches(3, 64, 3, 1, 64, 64, lib.BF16, None, 0, None, None, 0) == 23
+    assert L.emavfi_forward_launches(3, 7, 3, 1, 64, 64, lib.BF16, None, 0, None, None, 0) == -2
+
+
+@pytest.mark.gpu
+def test_bench_json_contract():
+    """`python bench.py` prints ONE JSON line with the fields the driver and the judge read."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "2",
+                          "--height", "96", "--width", "128", "--cpu-rows", "24"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["steps"] == 2 and r["warmup"] == 1 and r["higher_is_better"] is True
+    assert r["scaling"] == "weak" and r["vs_baseline"] is None and r["dtype"] == "bf16" and r["data"] == "synthetic"
+    assert "workload" in r["config"] and "model" not in r["config"]
+    assert r["value"] > 0 and abs(r["value"] - 2 * 2 / (r["ms_per_step"] * 2e-3)) / r["value"] < 0.02
+    rf = r["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and "traffic" in rf
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = r["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb and cb["unit"] == "frames/s"
+    assert r["accuracy_vs_cpu_oracle"]["fp32"]["max_abs"] <= 1e-3
+
+
+@pytest.mark.gpu
+def test_smoke_entry_point():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.smoke()
+
+
+@pytest.mark.gpu
+def test_config5_1080p_runs_deterministically():
+    """BASELINE.json configs[4] size (1920x1080): ragged 16-row deform tiles (1080 = 67.5 x 16), bf16 vs fp32."""
+    sd = synth.synthetic_state_dict(seed=0)
+    f1, f2 = synth.fast_frames(9, 1, 1080, 1920, device="cuda:0")
+    outs = {}
+    for mode in ("fp32", "bf16"):
+        m = EMA_VFI(compute_dtype=mode).cuda().eval()
+        m.load_state_dict(sd)
+        with torch.no_grad():
+            a, b = m(f1, f2), m(f1, f2)
+        assert torch.equal(a, b) and torch.isfinite(a).all() and a.min() >= 0 and a.max() <= 1
+        outs[mode] = a
+    mse = (outs["fp32"].double() - outs["bf16"].double()).pow(2).mean().item()
+    assert mse < 10 ** (-3.5)  # PSNR of bf16 against fp32 > 35 dB
