@@ -47,6 +47,71 @@ template <typename T, int CK, int NF, int S> struct ConvCfg {
     static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the 160 KiB LDS");
 };
 
+// ---- shared by both kernels: accumulator initialisation and epilogue for MF pixel rows ----
+// `y0` = first output row of this wave, x = output column of this lane.
+template <int MF, int NF>
+__device__ __forceinline__ void conv_init_acc(f32x16 (&acc)[MF][NF], const ConvParams &p, int b, int pass, int y0, int x, int h)
+{
+    const int coutpad = p.npass * NF * 32;
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+        const float *bp = p.bias + pass * NF * 32;
+        if (p.bias_mode == 1) {
+            // motion_estimation.0: the spatially constant context half of the concatenated input
+            // (ema_vfi.py:124) is folded into a bias that depends only on which taps fall inside
+            // the image; the table is indexed by that border class (see ctx_finish_kernel).
+            const int y = y0 + m;
+            const int ym = (y >= 1 ? 1 : 0) | (y <= p.Hout - 2 ? 2 : 0);
+            const int xm = (x >= 1 ? 1 : 0) | (x <= p.Wout - 2 ? 2 : 0);
+            bp += ((size_t)b * 16 + ym * 4 + xm) * coutpad;
+        }
+#pragma unroll
+        for (int n = 0; n < NF; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][n][i] = bp[n * 32 + acc_channel(i, h)];
+    }
+}
+
+// lane (r, h) holds pixel r = column x, 4 consecutive channels per register quad
+template <typename T, int MF, int NF>
+__device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[MF][NF], const ConvParams &p, int b, int pass, int y0, int x, int h)
+{
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+        const int y = y0 + m;
+        if (y >= p.Hout || x >= p.Wout) continue;
+        const size_t pix = ((size_t)b * p.Hout + y) * p.Wout + x;
+        if (p.epi == EPI_PLANAR || p.epi == EPI_PLANAR_TANH01) {
+            // flow head / reconstruction tail: <= 4 real channels, written as NCHW fp32 planes
+            if (h == 0 && pass == 0) {
+                const size_t plane = (size_t)p.Hout * p.Wout;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < p.nplanes) {
+                        float v = acc[m][0][c];
+                        if (p.epi == EPI_PLANAR_TANH01) v = (tanhf(v) + 1.0f) / 2.0f;  // ema_vfi.py:106,146
+                        p.out_planar[((size_t)b * p.nplanes + c) * plane + (size_t)y * p.Wout + x] = v;
+                    }
+            }
+            continue;
+        }
+        if (p.epi == EPI_OM) {
+            // mask = sigmoid(second chunk), ema_vfi.py:59; routed to channels 18..26 at pack time
+            const auto om_act = [](float v, int c) { return (c >= 18 && c < 27) ? 1.0f / (1.0f + expf(-v)) : v; };
+            store_frag(reinterpret_cast<float *>(p.out) + pix * p.out_ps, acc[m][0], h, p.cstore, om_act);
+            continue;
+        }
+        T *ob = reinterpret_cast<T *>(p.out) + pix * p.out_ps + p.out_coff + pass * NF * 32;
+#pragma unroll
+        for (int n = 0; n < NF; ++n) {
+            const int limit = p.cstore - (pass * NF + n) * 32;
+            if (limit <= 0) continue;
+            if (p.epi == EPI_RELU) store_frag(ob + n * 32, acc[m][n], h, limit, [](float v, int) { return fmaxf(v, 0.0f); });
+            else store_frag(ob + n * 32, acc[m][n], h, limit, [](float v, int) { return v; });
+        }
+    }
+}
+
 template <typename T, int CK, int NF, int S>
 __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvParams p)
 {
@@ -61,27 +126,10 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvParams p)
     const int r = lane & 31, h = lane >> 5;
     const int tx = blockIdx.x, ty = blockIdx.y;
     const int b = blockIdx.z / p.npass, pass = blockIdx.z - b * p.npass;
-    const int coutpad = p.npass * NF * 32;
 
     // ---- accumulators start at the bias ----
     f32x16 acc[MF][NF];
-#pragma unroll
-    for (int m = 0; m < MF; ++m) {
-        const float *bp = p.bias + pass * NF * 32;
-        if (p.bias_mode == 1) {
-            // motion_estimation.0: the spatially constant context half of the concatenated input
-            // (ema_vfi.py:124) is folded into a bias that depends only on which taps fall inside
-            // the image; the table is indexed by that border class (see ctx_finish_kernel).
-            const int y = ty * C::TH + wave * MF + m, x = tx * 32 + r;
-            const int ym = (y >= 1 ? 1 : 0) | (y <= p.Hout - 2 ? 2 : 0);
-            const int xm = (x >= 1 ? 1 : 0) | (x <= p.Wout - 2 ? 2 : 0);
-            bp += ((size_t)b * 16 + ym * 4 + xm) * coutpad;
-        }
-#pragma unroll
-        for (int n = 0; n < NF; ++n)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[m][n][i] = bp[n * 32 + acc_channel(i, h)];
-    }
+    conv_init_acc<MF, NF>(acc, p, b, pass, ty * C::TH + wave * MF, tx * 32 + r, h);
 
     const int iy0 = ty * C::TH * S - 1, ix0 = tx * 32 * S - 1;
     const char *gin = (const char *)p.in + (size_t)b * p.Hin * p.Win * p.in_ps * sizeof(T);
@@ -168,41 +216,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvParams p)
         }
     }
 
-    // ---- epilogue: lane (r, h) holds pixel r, 4 consecutive channels per register quad ----
-#pragma unroll
-    for (int m = 0; m < MF; ++m) {
-        const int y = ty * C::TH + wave * MF + m, x = tx * 32 + r;
-        if (y >= p.Hout || x >= p.Wout) continue;
-        const size_t pix = ((size_t)b * p.Hout + y) * p.Wout + x;
-        if (p.epi == EPI_PLANAR || p.epi == EPI_PLANAR_TANH01) {
-            // flow head / reconstruction tail: <= 4 real channels, written as NCHW fp32 planes
-            if (h == 0 && pass == 0) {
-                const size_t plane = (size_t)p.Hout * p.Wout;
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (c < p.nplanes) {
-                        float v = acc[m][0][c];
-                        if (p.epi == EPI_PLANAR_TANH01) v = (tanhf(v) + 1.0f) / 2.0f;  // ema_vfi.py:106,146
-                        p.out_planar[((size_t)b * p.nplanes + c) * plane + (size_t)y * p.Wout + x] = v;
-                    }
-            }
-            continue;
-        }
-        if (p.epi == EPI_OM) {
-            // mask = sigmoid(second chunk), ema_vfi.py:59; routed to channels 18..26 at pack time
-            const auto om_act = [](float v, int c) { return (c >= 18 && c < 27) ? 1.0f / (1.0f + expf(-v)) : v; };
-            store_frag(reinterpret_cast<float *>(p.out) + pix * p.out_ps, acc[m][0], h, p.cstore, om_act);
-            continue;
-        }
-        T *ob = reinterpret_cast<T *>(p.out) + pix * p.out_ps + p.out_coff + pass * NF * 32;
-#pragma unroll
-        for (int n = 0; n < NF; ++n) {
-            const int limit = p.cstore - (pass * NF + n) * 32;
-            if (limit <= 0) continue;
-            if (p.epi == EPI_RELU) store_frag(ob + n * 32, acc[m][n], h, limit, [](float v, int) { return fmaxf(v, 0.0f); });
-            else store_frag(ob + n * 32, acc[m][n], h, limit, [](float v, int) { return v; });
-        }
-    }
+    conv_epilogue<T, MF, NF>(acc, p, b, pass, ty * C::TH + wave * MF, tx * 32 + r, h);
 }
 
 template <typename T, int CK, int NF, int S> static int launch_conv_inst(const ConvParams &p, hipStream_t s)
@@ -217,6 +231,121 @@ template <typename T, int CK, int NF, int S> static int launch_conv_inst(const C
     }
     dim3 grid((p.Wout + 31) / 32, (p.Hout + C::TH - 1) / C::TH, p.B * p.npass);
     conv3x3_kernel<T, CK, NF, S><<<grid, 256, C::LDS_BYTES, s>>>(p);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Persistent, weights-resident variant (bf16, stride 1, all input channels in one chunk, one pass):
+// the tile-per-workgroup kernel above DMA-ingests the input tile AND all nine taps' weights for every
+// 256-pixel tile (64->64: 49 + 72 KiB); at B=8 x 720p that is 3.5 GB per launch = 5.3 TB/s of
+// LDS-DMA fill, ~83 % of the chip-wide LDS-DMA ceiling (MI355X_MICROARCH.md: 6.4 TB/s) - the kernel
+// was ingest-bound, not MFMA-bound.  Here a workgroup stays resident (grid = CUs x workgroups per CU),
+// DMAs the nine taps' weights ONCE, and walks tiles of WAVES*2 rows x 32 columns: per tile only the
+// input tile is ingested, there is no per-tap weight DMA and no per-tap barrier (one barrier after the
+// tile's DMA, one before the next tile overwrites it), so a wave issues its 9*KG*2*NF MFMAs back to back.
+// ------------------------------------------------------------------------------------------
+template <typename T, int CK, int NF, int WAVES> struct ConvPersistCfg {
+    using D = DT<T>;
+    static constexpr int MF = 2, TH = WAVES * MF, TW = 32, IH = TH + 2, IW = TW + 2;
+    static constexpr int PSTR = LdsPix<T, CK>::BYTES;
+    static constexpr int PIECES = CK * (int)sizeof(T) / 16;
+    static constexpr int KG = CK / D::CHKG;
+    static constexpr int WTAP = KG * NF * 1024, WINST = 9 * KG * NF;
+    static constexpr int SP = PSTR / 16, NSLOT = IH * IW * SP, NINST = (NSLOT + 63) / 64;
+    static constexpr int LDS_W = 9 * WTAP, LDS_IN = NINST * 1024, LDS_BYTES = LDS_W + LDS_IN;
+    static constexpr int WG_PER_CU = (160 * 1024 / LDS_BYTES) > 4 ? 4 : (160 * 1024 / LDS_BYTES);
+    static_assert(LDS_BYTES <= 160 * 1024, "resident weights + tile do not fit the 160 KiB LDS");
+};
+
+template <typename T, int CK, int NF, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void conv3x3_persist_kernel(const ConvParams p)
+{
+    using C = ConvPersistCfg<T, CK, NF, WAVES>;
+    using vec = typename DT<T>::vec;
+    constexpr int MF = C::MF, IW = C::IW, PSTR = C::PSTR;
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *lds_w = smem;
+    char *lds_in = smem + C::LDS_W;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const char *zeros = (const char *)p.zeros;
+
+    // all nine taps' packed weights, once per workgroup
+#pragma unroll 1
+    for (int j = wave; j < C::WINST; j += WAVES)
+        __builtin_amdgcn_global_load_lds((gptr_t *)((const char *)p.w + j * 1024 + lane * 16), (lptr_t *)(lds_w + j * 1024), 16, 0, 0);
+
+    const int ntx = (p.Wout + 31) / 32, nty = (p.Hout + C::TH - 1) / C::TH;
+    const int ntiles = ntx * nty * p.B;
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / (ntx * nty), trem = tile - b * (ntx * nty);
+        const int ty = trem / ntx, tx = trem - ty * ntx;
+        const int iy0 = ty * C::TH - 1, ix0 = tx * 32 - 1;
+        const char *gin = (const char *)p.in + (size_t)b * p.Hin * p.Win * p.in_ps * sizeof(T);
+        if (tile != (int)blockIdx.x) __syncthreads();  // every wave has finished reading the previous tile
+#pragma unroll
+        for (int i = 0; i < (C::NINST + WAVES - 1) / WAVES; ++i) {
+            const int j = i * WAVES + wave;
+            if (j < C::NINST) {
+                const int sl = j * 64 + lane;
+                const int pix = sl / C::SP, pc = sl - pix * C::SP;
+                const int ly = pix / IW, lx = pix - ly * IW;
+                const int gy = iy0 + ly, gx = ix0 + lx;
+                const bool ok = sl < C::NSLOT && pc < C::PIECES && gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
+                const char *src = ok ? gin + ((size_t)gy * p.Win + gx) * p.in_ps * sizeof(T) + pc * 16 : zeros;
+                __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)(lds_in + j * 1024), 16, 0, 0);
+            }
+        }
+        f32x16 acc[MF][NF];
+        conv_init_acc<MF, NF>(acc, p, b, 0, ty * C::TH + wave * MF, tx * 32 + r, h);
+        __syncthreads();  // hipcc drains the DMA (vmcnt(0)) ahead of the barrier: tile (and, first time, weights) landed
+
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap - 3 * dy;
+            const char *xb[MF];
+#pragma unroll
+            for (int m = 0; m < MF; ++m) xb[m] = lds_in + (((wave * MF + m) + dy) * IW + r + dx) * PSTR + h * 16;
+            const char *wb = lds_w + tap * C::WTAP + lane * 16;
+#pragma unroll
+            for (int kg = 0; kg < C::KG; ++kg) {
+                vec xv[MF];
+#pragma unroll
+                for (int m = 0; m < MF; ++m) xv[m] = *reinterpret_cast<const vec *>(xb[m] + kg * 32);
+#pragma unroll
+                for (int n = 0; n < NF; ++n) {
+                    const vec wv = *reinterpret_cast<const vec *>(wb + (kg * NF + n) * 1024);
+#pragma unroll
+                    for (int m = 0; m < MF; ++m) mma_kg(acc[m][n], wv, xv[m]);
+                }
+            }
+        }
+        conv_epilogue<T, MF, NF>(acc, p, b, 0, ty * C::TH + wave * MF, tx * 32 + r, h);
+    }
+}
+
+template <typename T, int CK, int NF, int WAVES> static int launch_conv_persist(const ConvParams &p, hipStream_t s)
+{
+    using C = ConvPersistCfg<T, CK, NF, WAVES>;
+    static int wg_per_cu = 0;  // resident workgroups per CU: registers and LDS both limit it
+    if (!wg_per_cu) {
+        const void *fn = reinterpret_cast<const void *>(&conv3x3_persist_kernel<T, CK, NF, WAVES>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        int n = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3x3_persist_kernel<T, CK, NF, WAVES>, 64 * WAVES, C::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        // a persistent grid must not exceed what is resident: queued workgroups would only start
+        // when others have finished their whole tile list
+        wg_per_cu = n < 1 ? 1 : (n > C::WG_PER_CU ? C::WG_PER_CU : n);
+    }
+    const int ntiles = ((p.Wout + 31) / 32) * ((p.Hout + C::TH - 1) / C::TH) * p.B;
+    const int resident = 256 * wg_per_cu;  // MI355X: 256 CUs
+    conv3x3_persist_kernel<T, CK, NF, WAVES><<<ntiles < resident ? ntiles : resident, 64 * WAVES, C::LDS_BYTES, s>>>(p);
     return (int)hipGetLastError();
 }
 
