@@ -95,3 +95,28 @@ def test_product_path_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), f
                 assert "liboracle" not in text, f
+
+
+def test_checkpoint_variants_load():
+    """DataParallel prefix, fp16 tensors, wrapper dict, shape errors."""
+    sd = synth.synthetic_state_dict(seed=5, mid_channels=8)
+    ref = EMA_VFI(mid_channels=8)
+    ref.load_state_dict(sd, strict=True)
+    variants = {
+        "module-prefix": {"module." + k: v for k, v in sd.items()},
+        "wrapped": {"state_dict": dict(sd), "epoch": 3},
+        "half": {k: v.half() for k, v in sd.items()},
+    }
+    for name, v in variants.items():
+        m = EMA_VFI(mid_channels=8)
+        m.load_state_dict(v, strict=True)
+        for (k, a), (_, b) in zip(m.named_parameters(), ref.named_parameters()):
+            assert a.dtype == torch.float32
+            tol = 2e-3 if name == "half" else 0.0
+            assert (a - b).abs().max().item() <= tol * max(1.0, b.abs().max().item()), (name, k)
+    bad = dict(sd)
+    bad["feat_ext_conv1.0.weight"] = torch.zeros(8, 5, 3, 3)
+    with pytest.raises(RuntimeError, match="feat_ext_conv1.0.weight has shape"):
+        EMA_VFI(mid_channels=8).load_state_dict(bad)
+    with pytest.raises(RuntimeError):  # strict: a reference checkpoint of another width does not load
+        EMA_VFI(mid_channels=8).load_state_dict(synth.synthetic_state_dict(seed=5, mid_channels=16))

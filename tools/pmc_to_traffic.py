@@ -23,6 +23,9 @@ def label(k):
     m = re.match(r"_Z14conv3x3_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)EEv", k)
     if m:
         return f"conv3x3<{'bf16' if m.group(1) == 'DF16b' else 'f32'},ck={m.group(2)},nf={m.group(3)},s={m.group(4)}>"
+    m = re.match(r"_Z22conv3x3_persist_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi\d+EEv", k)
+    if m:  # persistent variant serves the same layers (stride 1) as the tile-per-workgroup kernel
+        return f"conv3x3<{'bf16' if m.group(1) == 'DF16b' else 'f32'},ck={m.group(2)},nf={m.group(3)},s=1>"
     if "warp_tiled_kernel" in k:
         return "warp_tiled<3,nchw fp32> (emavfi_warp)" if "void>" in k else "warp_fused<bf16>"
     if "pack_input_kernel" in k:

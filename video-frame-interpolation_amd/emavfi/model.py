@@ -116,6 +116,30 @@ class EMA_VFI(nn.Module):
         self.last_taps = None
 
     # ------------------------------------------------------------------ weights
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        """``nn.Module.load_state_dict`` plus the checkpoint shapes met in practice for this model
+        (SURVEY.md section 8f row 4): a ``{"state_dict": ...}`` / ``{"model": ...}`` wrapper, keys saved
+        from ``nn.DataParallel`` (``module.`` prefix), half-precision tensors (cast to fp32, the dtype
+        ``train.py:182,190`` saves).  Shapes are verified against the reference's parameter table and a
+        mismatch raises with the offending key."""
+        sd = state_dict
+        for wrapper in ("state_dict", "model", "model_state_dict"):
+            if isinstance(sd, dict) and wrapper in sd and isinstance(sd[wrapper], dict) and \
+                    all(isinstance(k, str) for k in sd[wrapper]):
+                sd = sd[wrapper]
+                break
+        clean = OrderedDict()
+        for k, v in sd.items():
+            k2 = k[len("module."):] if k.startswith("module.") else k
+            clean[k2] = v.float() if torch.is_tensor(v) and v.is_floating_point() and v.dtype != torch.float32 else v
+        own = dict(self.named_parameters())
+        for k, v in clean.items():
+            if k in own and torch.is_tensor(v) and tuple(v.shape) != tuple(own[k].shape):
+                raise RuntimeError(f"EMA_VFI.load_state_dict: {k} has shape {tuple(v.shape)}, "
+                                   f"expected {tuple(own[k].shape)} for EMA_VFI({self.in_channels}, "
+                                   f"{self.mid_channels}, {self.num_blocks})")
+        return super().load_state_dict(clean, strict=strict, assign=assign)
+
     def _ordered_params(self):
         """Tensors in the order emavfi_pack_weights expects = the reference's registration order."""
         return [p for _, p in self.named_parameters()]
