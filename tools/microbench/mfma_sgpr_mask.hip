@@ -1,0 +1,79 @@
+// Micro-benchmark: a VALU-produced lane mask (v_cmp_*_e64 -> SGPR pair) created directly behind a
+// burst of MFMAs, combined by SALU (s_and_b64), held across a global-load wait and then consumed by
+// v_cndmask - the instruction pattern of the first deformable-conv kernel, where bits 48-63 of such a
+// mask were intermittently zero when two workgroups shared a CU.
+// Every lane's predicate is true by construction, so any 0 selected by v_cndmask is a fault.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int NOPS>
+__global__ void k(const float *src, unsigned long long *bad_masks, float *sink, int iters)
+{
+    f32x16 acc = {0};
+    const int lane = threadIdx.x & 63;
+    const int pos = lane & 31;                    // > -1 and < 48 for every lane
+    const float *p = src + (blockIdx.x * blockDim.x + threadIdx.x) % 4096;
+    unsigned long long bad = 0;
+    const unsigned a0 = 0x3f803f80u;
+    float one = 1.0f, tmp;
+    for (int it = 0; it < iters; ++it) {
+        float res;
+        asm volatile(
+            "v_mov_b32 v16, %4\n\t v_mov_b32 v17, %4\n\t v_mov_b32 v18, %4\n\t v_mov_b32 v19, %4\n\t"
+            "v_mov_b32 v20, %4\n\t v_mov_b32 v21, %4\n\t v_mov_b32 v22, %4\n\t v_mov_b32 v23, %4\n\t"
+            "s_nop 4\n\t"
+            "v_mfma_f32_32x32x16_bf16 %0, v[16:19], v[20:23], %0\n\t"
+            "v_mfma_f32_32x32x16_bf16 %0, v[16:19], v[20:23], %0\n\t"
+            "v_mfma_f32_32x32x16_bf16 %0, v[16:19], v[20:23], %0\n\t"
+            "v_mfma_f32_32x32x16_bf16 %0, v[16:19], v[20:23], %0\n\t"
+            "v_mfma_f32_32x32x16_bf16 %0, v[16:19], v[20:23], %0\n\t"
+            "v_mfma_f32_32x32x16_bf16 %0, v[16:19], v[20:23], %0\n\t"
+            // predicate-heavy code in the MFMA shadow, as hipcc emitted it (no wait states between
+            // the VALU compares that write SGPR pairs and the SALU ops that combine them)
+            "v_cmp_gt_i32_e64 s[40:41], 64, %3\n\t"
+            "v_cmp_lt_i32_e64 s[42:43], -1, %3\n\t"
+            "v_cmp_lt_i32_e64 s[44:45], -2, %3\n\t"
+            "v_cmp_gt_i32_e64 s[46:47], 48, %3\n\t"
+            "v_mul_lo_u32 v24, %3, %3\n\t"
+            "v_mul_lo_u32 v25, %3, v24\n\t"
+            "s_and_b64 s[44:45], s[44:45], s[40:41]\n\t"
+            "s_and_b64 s[42:43], s[46:47], s[42:43]\n\t"
+            "s_and_b64 s[40:41], s[46:47], s[40:41]\n\t"
+            "global_load_dword %2, %5, off\n\t"
+            "s_waitcnt vmcnt(0)\n\t"
+            "v_cndmask_b32_e64 %1, 0, %6, s[42:43]\n\t"
+            "s_nop 7\n\t s_nop 7\n\t"
+            : "+v"(acc), "=v"(res), "=v"(tmp)
+            : "v"(pos), "v"(a0), "v"(p), "v"(one)
+            : "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "s40", "s41", "s42", "s43", "s44",
+              "s45", "s46", "s47", "memory");
+        bad |= __ballot(res != 1.0f);
+        acc[0] += tmp * 0.0f;
+    }
+    if (lane == 0) bad_masks[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = bad;
+    sink[blockIdx.x * blockDim.x + threadIdx.x] = acc[0] + acc[7];
+}
+
+int main()
+{
+    const int iters = 4000;
+    float *src, *sink; unsigned long long *bm;
+    hipMalloc(&src, 4096 * 4 + 64); hipMemset(src, 0, 4096 * 4 + 64);
+    for (int threads : {256, 512, 1024}) {
+        const int blocks = 256 * 4, waves = blocks * threads / 64;
+        hipMalloc(&sink, (size_t)blocks * threads * 4); hipMalloc(&bm, (size_t)waves * 8);
+        for (int rep = 0; rep < 3; ++rep) {
+            hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(threads), 0, 0, src, bm, sink, iters);
+            hipDeviceSynchronize();
+            std::vector<unsigned long long> h(waves);
+            hipMemcpy(h.data(), bm, waves * 8, hipMemcpyDeviceToHost);
+            int badw = 0; unsigned long long any = 0;
+            for (auto m : h) { badw += m != 0; any |= m; }
+            printf("threads/WG %4d: %d of %d waves saw a wrong v_cndmask result; union of faulty lanes = 0x%016llx\n", threads, badw, waves, any);
+        }
+        hipFree(sink); hipFree(bm);
+    }
+    return 0;
+}

@@ -17,10 +17,8 @@
 // barrier per tap).  Sampling positions, floor and corner weights are fp32 in both dtypes and
 // are computed without comparisons (clamps), so no lane masks are held across memory waits.
 //
-// Scheduling rule (common.h, mfma_retire): a wave never runs its VALU-heavy gather in the shadow
-// of its own queued MFMAs - each batch's accumulator chains are retired before the next gather
-// starts.  The overlap of VALU (gather/blend) with the matrix pipe comes from the partner wave
-// on the SIMD (two workgroups per CU).  Regression test for the failure this prevents:
+// Empirical guard (common.h, mfma_retire): each batch's accumulator chains are
+// retired before the next gather's predicate-heavy code; it costs nothing measurable.  Regression test:
 // tests/test_gpu_parity.py::test_deform_bf16_is_deterministic_at_two_workgroups_per_cu.
 //
 // The gather reads global memory through L1/L2 (each input pixel is re-read by ~36 corner
