@@ -148,10 +148,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    # one process per GPU; the modulo only matters for rehearsals with more ranks than GPUs
+    # (EMAVFI_DIST_BACKEND=gloo, e.g. 2 ranks sharing the single GPU of a test box - RCCL itself
+    # refuses two ranks on one device)
+    local_dev = local % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     from emavfi import EMA_VFI, lib, synth, dist as vdist
-    vdist.init("nccl", dev)
+    backend = os.environ.get("EMAVFI_DIST_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm
+    vdist.init(backend, dev)
 
     B, H, W = args.batch, args.height, args.width
     dt = lib.dtype_code(args.dtype)
@@ -204,7 +209,7 @@ def main():
                                       f"{'bf16 convs + fp32 warp' if args.dtype == 'bf16' else 'fp32 MFMA convs + fp32 warp'}, "
                                       "EMA_VFI(3,64,3), synthetic non-degenerate weights",
                           "pairs_per_gpu": B, "height": H, "width": W, "parallelism": f"replica-dp{world}",
-                          "collectives": "one RCCL broadcast of packed weights before timing" if world > 1 else "none"},
+                          "collectives": f"one {backend} broadcast of packed weights before timing" if world > 1 else "none"},
                "frames_per_sec_per_gpu": round(value / world, 2),
                "forward_passes_per_sec": round(value, 2),
                "whole_forward": {"tflops_algorithmic": round(FLOP_PER_PX * B * H * W / (ms_step * 1e-3) / 1e12, 2),

@@ -71,7 +71,8 @@ def max_over_ranks(value: float, device=None) -> float:
     """MAX-reduce a host scalar (the benchmark's elapsed time) over all ranks."""
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return float(value)
-    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    on_cpu = device is None or dist.get_backend() == "gloo"
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if on_cpu else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
