@@ -226,6 +226,20 @@ def test_forward_ragged_sizes(H, W):
     assert (out - oracle.forward(sd, f1, f2)).abs().max().item() <= 1e-3
 
 
+@pytest.mark.parametrize("H,W", [(5, 7), (1, 36), (40, 1), (17, 33), (31, 100)])
+def test_forward_ragged_sizes_mid64_both_dtypes(H, W):
+    """The mid_channels = 64 kernels (persistent conv, LDS-window deform, tiled warp when W % 4 == 0)
+    on sizes that are not multiples of any tile: fp32 <= 1e-3 vs the oracle, bf16 close to it."""
+    sd = synth.synthetic_state_dict(seed=0)
+    f1, f2 = synth.synthetic_frames(13, 2, H, W, "natural")
+    ref = oracle.forward(sd, f1, f2)
+    with torch.no_grad():
+        a = make_model(sd, dtype="fp32")(f1.to(DEV), f2.to(DEV)).cpu()
+        b = make_model(sd, dtype="bf16")(f1.to(DEV), f2.to(DEV)).cpu()
+    assert (a - ref).abs().max().item() <= 1e-3
+    assert torch.isfinite(b).all() and (b - ref).abs().max().item() <= 0.15
+
+
 def test_forward_bf16_psnr():
     """BASELINE configs[2] arithmetic (bf16 convs, fp32 warp) on a natural pair: PSNR vs the fp32 oracle."""
     sd = synth.synthetic_state_dict(seed=0)
