@@ -113,7 +113,6 @@ class EMA_VFI(nn.Module):
             [ModulatedDeformConvPack(m + 3, m + 3, kernel_size=3, padding=1, groups=1) for _ in range(num_blocks)])
         self.reconstruction = nn.Sequential(conv_block(m + 3, m), conv_block(m, m // 2), conv(m // 2, in_channels), nn.Tanh())
         self._packed = {}      # dtype code -> (key, packed uint8 tensor)
-        self.last_taps = None
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
