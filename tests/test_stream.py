@@ -114,3 +114,28 @@ def test_stream_without_quirks_passes_sources_through():
     assert len(got) == 2 * 3 + 1
     for k in range(3):
         assert np.array_equal(got[2 * k + 1], frames[k])
+
+
+@pytest.mark.gpu
+def test_recursive_mode_emits_distinct_midpoints():
+    """Opt-in mode that the reference lacks (it has no timestep input): factor 3 -> quarter points."""
+    sd = synth.synthetic_state_dict(seed=23, mid_channels=8)
+    frames = [f for f in synth.synthetic_frames_u8(7, 5, 24, 32, "natural")[0]]
+    model = EMA_VFI(mid_channels=8, compute_dtype="fp32").cuda().eval()
+    model.load_state_dict(sd)
+    fi = FrameInterpolator(model, 3, 1, batch_pairs=2, reference_quirks=False, mode="recursive")
+    got = list(fi.run(frames))
+    assert len(got) == fi.count_outputs(len(frames)) == 4 * 4 + 1
+    # oracle replay of the recursion for the first pair
+    mean = torch.tensor(MEAN, dtype=torch.float32).view(1, 3, 1, 1)
+    std = torch.tensor(STD, dtype=torch.float32).view(1, 3, 1, 1)
+    a, b = ref_preprocess(frames[0])[None], ref_preprocess(frames[1])[None]
+    mid = oracle.forward(sd, a, b)
+    q1 = oracle.forward(sd, a, (mid - mean) / std)
+    q3 = oracle.forward(sd, (mid - mean) / std, b)
+    for g, r in zip(got[:3], (q1, mid, q3)):
+        want = (np.clip(np.transpose(r[0].numpy(), (1, 2, 0)).astype(np.float64), 0, 1) * 255).astype(np.uint8)
+        assert np.abs(g.astype(np.int16) - want.astype(np.int16)).max() <= 1
+    assert np.array_equal(got[3], frames[0])
+    with pytest.raises(ValueError):
+        FrameInterpolator(model, 2, mode="recursive")

@@ -17,13 +17,17 @@ What changes is how the work is scheduled, not what is computed:
   * ToTensor/Normalize and denormalize/clip/uint8 run on the GPU (emavfi_preprocess_u8 / _postprocess_u8);
   * the ``interpolation_factor`` identical forwards of a pair are computed once and emitted that many
     times (bit-identical to recomputing them);
-  * host<->device copies use pinned buffers on a side stream so batch k+1 uploads while batch k computes.
+  * a three-stage pipeline on three streams - upload of batch k+1, compute of batch k, download of batch
+    k-1 - through preallocated pinned host buffers; consecutive pairs share a frame, so a batch of n
+    pairs uploads n+1 frames (frame_interval 1), not 2n.
+``mode="recursive"`` (opt-in, not in the reference, which has no timestep input) replaces the repeated
+identical prediction by recursive midpoints: factor 1 -> [1/2]; factor 3 -> [1/4, 1/2, 3/4]; factor 7 -> eighths.
 ``reference_quirks=False`` drops the de-normalisation of the already-[0,1] model output (appendix A of
 SURVEY.md) and passes source frames through untouched; order and counts stay the same.
 """
 from __future__ import annotations
 
-from typing import Iterable, Iterator, List
+from typing import Iterable, Iterator, List, Optional
 
 import numpy as np
 import torch
@@ -33,18 +37,25 @@ from . import lib as _lib
 
 class FrameInterpolator:
     def __init__(self, model, interpolation_factor: int = 1, frame_interval: int = 1, batch_pairs: int = 8,
-                 reference_quirks: bool = True, device=None):
+                 reference_quirks: bool = True, mode: str = "reference", device=None):
         if interpolation_factor < 0 or frame_interval < 1 or batch_pairs < 1:
             raise ValueError("interpolation_factor >= 0, frame_interval >= 1, batch_pairs >= 1 required")
+        if mode not in ("reference", "recursive"):
+            raise ValueError("mode must be 'reference' (the reference's repeated identical prediction) or 'recursive'")
+        if mode == "recursive" and (interpolation_factor + 1) & interpolation_factor:
+            raise ValueError("recursive midpoints need interpolation_factor = 2^k - 1 (1, 3, 7, ...)")
         self.model = model
         self.factor = int(interpolation_factor)
         self.interval = int(frame_interval)
         self.batch_pairs = int(batch_pairs)
         self.quirks = bool(reference_quirks)
+        self.mode = mode
         self.device = torch.device(device) if device is not None else next(model.parameters()).device
         if self.device.type != "cuda":
             raise RuntimeError("FrameInterpolator needs the model on a ROCm device (no CPU path)")
-        self._copy_stream = torch.cuda.Stream(device=self.device)
+        self._up = torch.cuda.Stream(device=self.device)
+        self._down = torch.cuda.Stream(device=self.device)
+        self._shape = None
 
     # ---- the reference's frame selection (inference.py:158-201), as (pairs, tail) over frame indices
     @staticmethod
@@ -62,49 +73,131 @@ class FrameInterpolator:
                 pairs.append((cur, nxt))
             cur, nxt = nxt, nxt + 1      # in the skip branch the reference also advances frame1
 
-    def _upload(self, frames: List[np.ndarray]) -> torch.Tensor:
-        host = torch.from_numpy(np.ascontiguousarray(np.stack(frames))).pin_memory()
-        with torch.cuda.stream(self._copy_stream):
-            dev = host.to(self.device, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(self._copy_stream)
-        return dev, ev, host
+    def count_outputs(self, n_frames: int) -> int:
+        pairs, last = self.schedule(n_frames, self.interval)
+        return 0 if last is None else len(pairs) * (self.factor + 1) + 1
+
+    # ---- buffers: two slots, each (pinned uint8 in, device uint8 in, pinned uint8 out)
+    def _alloc(self, shape):
+        if self._shape == shape:
+            return
+        H, W, C = shape
+        nb, nout = self.batch_pairs, max(self.factor if self.mode == "recursive" else 1, 1)
+        self._shape = shape
+        self._slots = []
+        for _ in range(2):
+            self._slots.append({
+                "h_in": torch.empty(2 * nb, H, W, C, dtype=torch.uint8).pin_memory(),
+                "d_in": torch.empty(2 * nb, H, W, C, dtype=torch.uint8, device=self.device),
+                "h_pred": torch.empty(nb * nout, H, W, C, dtype=torch.uint8).pin_memory(),
+                "h_src": torch.empty(nb, H, W, C, dtype=torch.uint8).pin_memory(),
+                "up": torch.cuda.Event(), "consumed": torch.cuda.Event(), "done": torch.cuda.Event(),
+                "down": torch.cuda.Event(),
+            })
+
+    def _stage_upload(self, slot, frames, chunk):
+        """Copy the distinct frames of `chunk` into the slot's pinned buffer and start the H2D copy.
+        Returns (number of uploaded frames, index tensors of each pair's first / second frame)."""
+        order, pos = [], {}
+        for a, b in chunk:
+            for f in (a, b):
+                if f not in pos:
+                    pos[f] = len(order)
+                    order.append(f)
+        slot["up"].synchronize()          # the previous H2D out of this pinned buffer has finished
+        for i, f in enumerate(order):
+            slot["h_in"][i].copy_(torch.from_numpy(frames[f]))
+        n = len(order)
+        with torch.cuda.stream(self._up):
+            self._up.wait_event(slot["consumed"])   # the main stream is done with this slot's device buffer
+            slot["d_in"][:n].copy_(slot["h_in"][:n], non_blocking=True)
+            slot["up"].record(self._up)
+        # positions stay on the host: a device index tensor would be a synchronous pageable copy on the
+        # main stream, i.e. the host would block behind the compute it has just enqueued
+        return n, [pos[a] for a, _ in chunk], [pos[b] for _, b in chunk]
+
+    @staticmethod
+    def _rows(x, idx):
+        """x[idx] without a device index tensor: a view when idx is a run of consecutive rows (the usual case:
+        consecutive pairs share frames), otherwise a stack of row views."""
+        if all(idx[k + 1] == idx[k] + 1 for k in range(len(idx) - 1)):
+            return x[idx[0]:idx[0] + len(idx)]
+        return torch.stack([x[i] for i in idx])
+
+    def _predict(self, x1, x2):
+        """[n, k, 3, H, W] predictions per pair: k = 1 (reference mode) or `factor` recursive midpoints."""
+        with torch.no_grad():
+            mid = self.model(x1, x2)
+            if self.mode == "reference" or self.factor <= 1:
+                return mid.unsqueeze(1)
+            # the model consumes normalised frames and returns [0,1] images: re-normalise midpoints to recurse
+            mean = torch.tensor(_lib.IMAGENET_MEAN, device=mid.device).view(1, 3, 1, 1)
+            std = torch.tensor(_lib.IMAGENET_STD, device=mid.device).view(1, 3, 1, 1)
+
+            def rec(a, b, depth):
+                m = self.model(a, b)
+                if depth == 1:
+                    return [m]
+                mn = (m - mean) / std
+                return rec(a, mn, depth - 1) + [m] + rec(mn, b, depth - 1)
+
+            levels = (self.factor + 1).bit_length() - 1
+            return torch.stack(rec(x1, x2, levels), dim=1)
 
     def run(self, frames: Iterable[np.ndarray]) -> Iterator[np.ndarray]:
         """Yields uint8 HWC frames in the order the reference's writer receives them."""
-        frames = [np.asarray(f) for f in frames]
+        frames = [np.ascontiguousarray(f) for f in frames]
         for f in frames:
             if f.dtype != np.uint8 or f.ndim != 3 or f.shape != frames[0].shape:
                 raise ValueError("FrameInterpolator.run: same-shape uint8 HWC frames expected")
         pairs, last = self.schedule(len(frames), self.interval)
         if last is None:
             return
+        self._alloc(frames[0].shape)
         main = torch.cuda.current_stream(self.device)
-        # upload batch 0, then pipeline: upload k+1 while k computes
         chunks = [pairs[i:i + self.batch_pairs] for i in range(0, len(pairs), self.batch_pairs)]
-        pending = None
-        if chunks:
-            pending = self._upload([frames[a] for a, _ in chunks[0]] + [frames[b] for _, b in chunks[0]])
-        for ci, chunk in enumerate(chunks):
-            dev_u8, ev, _keep = pending
-            pending = None
-            if ci + 1 < len(chunks):
-                nxt = chunks[ci + 1]
-                pending = self._upload([frames[a] for a, _ in nxt] + [frames[b] for _, b in nxt])
-            main.wait_event(ev)
-            n = len(chunk)
-            x = _lib.preprocess_u8(dev_u8)                       # [2n,3,H,W]
-            with torch.no_grad():
-                pred = self.model(x[:n], x[n:])
-            pred_u8 = _lib.postprocess_u8(pred, denormalize=self.quirks)
-            src_u8 = _lib.postprocess_u8(x[:n], denormalize=True) if self.quirks else dev_u8[:n]
-            pred_h, src_h = pred_u8.cpu().numpy(), src_u8.cpu().numpy()   # one D2H per batch, not per frame
-            for k in range(n):
-                for _ in range(self.factor):
-                    yield pred_h[k]
-                yield src_h[k]
-        yield frames[last]
+        npred = self.factor if self.mode == "recursive" else 1
 
-    def count_outputs(self, n_frames: int) -> int:
-        pairs, last = self.schedule(n_frames, self.interval)
-        return 0 if last is None else len(pairs) * (self.factor + 1) + 1
+        def drain(slot, chunk):
+            slot["down"].synchronize()            # this batch's download has landed in the pinned buffers
+            pred_h, src_h = slot["h_pred"].numpy(), slot["h_src"].numpy()
+            for k, (a, _) in enumerate(chunk):
+                if self.mode == "recursive":
+                    for j in range(npred):
+                        yield pred_h[k * npred + j].copy()
+                else:
+                    for _ in range(self.factor):
+                        yield pred_h[k].copy()
+                yield src_h[k].copy() if self.quirks else frames[a]
+
+        staged = self._stage_upload(self._slots[0], frames, chunks[0]) if chunks else None
+        prev = None
+        for ci, chunk in enumerate(chunks):
+            slot = self._slots[ci & 1]
+            nup, ia, ib = staged
+            n = len(chunk)
+            main.wait_event(slot["up"])
+            x = _lib.preprocess_u8(slot["d_in"][:nup])                  # distinct frames, normalised once
+            slot["consumed"].record(main)
+            x1, x2 = self._rows(x, ia), self._rows(x, ib)
+            pred = self._predict(x1, x2)                                 # [n, k, 3, H, W]
+            pred_u8 = _lib.postprocess_u8(pred.reshape(-1, *pred.shape[2:]), denormalize=self.quirks)
+            src_u8 = _lib.postprocess_u8(x1, denormalize=True) if self.quirks else None
+            slot["done"].record(main)
+            with torch.cuda.stream(self._down):       # download behind the compute, on its own stream
+                self._down.wait_event(slot["done"])
+                slot["h_pred"][:n * npred].copy_(pred_u8, non_blocking=True)
+                if src_u8 is not None:
+                    slot["h_src"][:n].copy_(src_u8, non_blocking=True)
+                slot["down"].record(self._down)
+            pred_u8.record_stream(self._down)         # keep the device tensors alive for the copy stream
+            if src_u8 is not None:
+                src_u8.record_stream(self._down)
+            if ci + 1 < len(chunks):                  # host-side staging of the next batch overlaps this batch's compute
+                staged = self._stage_upload(self._slots[(ci + 1) & 1], frames, chunks[ci + 1])
+            if prev is not None:                      # emit the previous batch (its slot is reused only after this)
+                yield from drain(*prev)
+            prev = (slot, chunk)
+        if prev is not None:
+            yield from drain(*prev)
+        yield frames[last]
