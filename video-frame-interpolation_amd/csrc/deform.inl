@@ -101,6 +101,38 @@ __device__ __forceinline__ bf16x8 blend4(const uint4 (&v)[4], const float (&w)[4
     }
     return bf16x8{(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)a[4], (bf16_t)a[5], (bf16_t)a[6], (bf16_t)a[7]};
 }
+// Same blend on the dot-product unit: v_dot2c_f32_bf16 takes the packed pair as it sits in the register
+// (no unpack) - weights (w, 0) pick the low channel of a dword, (0, w) the high one.  fp32 accumulation,
+// but the four corner weights are rounded to bf16 (8 significant bits, like the blended value itself).
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+struct BlendW { unsigned lo[4], hi[4]; };  // bf16(w) in the low / high half, other half zero
+__device__ __forceinline__ BlendW blend_weights_bf16(const float (&w)[4])
+{
+    BlendW r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const unsigned short b = __builtin_bit_cast(unsigned short, (bf16_t)w[c]);
+        r.lo[c] = b;
+        r.hi[c] = (unsigned)b << 16;
+    }
+    return r;
+}
+__device__ __forceinline__ bf16x8 blend4_dot2(const uint4 (&v)[4], const BlendW &w)
+{
+    float a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const unsigned d[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            a[2 * q] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, d[q]), __builtin_bit_cast(bf16x2_t, w.lo[c]), a[2 * q], false);
+            a[2 * q + 1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, d[q]), __builtin_bit_cast(bf16x2_t, w.hi[c]), a[2 * q + 1], false);
+        }
+    }
+    return bf16x8{(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)a[4], (bf16_t)a[5], (bf16_t)a[6], (bf16_t)a[7]};
+}
 __device__ __forceinline__ f32x4 blend4(const uint4 (&v)[4], const float (&w)[4], float)
 {
     f32x4 a = {0.f, 0.f, 0.f, 0.f};

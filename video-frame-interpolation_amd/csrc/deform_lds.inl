@@ -22,6 +22,13 @@
 //     per tap); the next tap's (dy, dx, mask) are fetched one tap ahead as well.
 #include "deform.inl"
 
+#ifndef EMAVFI_DEFORM_DOT2
+#define EMAVFI_DEFORM_DOT2 1
+#endif
+#ifndef EMAVFI_DEFORM_WREG
+#define EMAVFI_DEFORM_WREG 1
+#endif
+
 template <int CK, int NF, int CS, int R, int RPW> struct DeformLdsCfg {
     static constexpr int WAVES = 16 / RPW, THREADS = 64 * WAVES;
     static constexpr int TROWS = 16, TCOLS = 32;
@@ -34,7 +41,7 @@ template <int CK, int NF, int CS, int R, int RPW> struct DeformLdsCfg {
     static constexpr int NSLOT = TR * TC * SP;
     static constexpr int NINST = (NSLOT + 63) / 64;
     static constexpr int LDS_TILE = NINST * 1024;
-    static constexpr int LDS_BYTES = LDS_TILE + 2 * WTAP;
+    static constexpr int LDS_BYTES = LDS_TILE + (EMAVFI_DEFORM_WREG ? 0 : 2 * WTAP);
     static constexpr int KB = (KG % 5 == 0) ? 5 : ((KG % 3 == 0) ? 3 : ((KG % 2 == 0) ? 2 : 1));
     static_assert(CS % 8 == 0 && CS <= CK, "staged channels: whole 16-byte slots, at most CK");
     static_assert((SP & 1) == 1, "odd slot stride keeps neighbouring-pixel gathers conflict free");
@@ -58,7 +65,9 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
     typedef __attribute__((address_space(3))) void lptr_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *lds_x = smem;
+#if !EMAVFI_DEFORM_WREG
     char *lds_w = smem + C::LDS_TILE;
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -83,12 +92,21 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
             __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)(lds_x + j * 1024), 16, 0, 0);
         }
     }
+#if !EMAVFI_DEFORM_WREG
 #pragma unroll
     for (int i = 0; i < (C::WINST + C::WAVES - 1) / C::WAVES; ++i) {
         const int j = i * C::WAVES + wave;
         if (j < C::WINST)
             __builtin_amdgcn_global_load_lds((gptr_t *)((const char *)p.w + j * 1024 + lane * 16), (lptr_t *)(lds_w + j * 1024), 16, 0, 0);
     }
+#else
+    // weights never touch LDS: every wave loads its MFMA A fragments straight from the packed blob (135 KiB,
+    // L2/L1 resident, one k-group ahead) - no weight ring, no per-tap barrier, the waves run decoupled
+    const char *wlane = (const char *)p.w + lane * 16;
+    bf16x8 wq[2][NF], w0next[NF];
+#pragma unroll
+    for (int n = 0; n < NF; ++n) w0next[n] = *reinterpret_cast<const bf16x8 *>(wlane + n * 1024);
+#endif
 
     f32x16 acc[RPW][NF];
 #pragma unroll
@@ -113,9 +131,12 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
     const char *gx = gplane + h * 16;
     __syncthreads();  // hipcc drains the DMA (vmcnt(0)) ahead of the barrier
 
+#if !EMAVFI_DEFORM_WREG
     int cur = 0;
+#endif
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
+#if !EMAVFI_DEFORM_WREG
         if (tap < 8) {
 #pragma unroll
             for (int i = 0; i < (C::WINST + C::WAVES - 1) / C::WAVES; ++i) {
@@ -125,6 +146,11 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
                                                      (lptr_t *)(lds_w + (cur ^ 1) * C::WTAP + j * 1024), 16, 0, 0);
             }
         }
+#else
+#pragma unroll
+        for (int n = 0; n < NF; ++n) wq[0][n] = w0next[n];
+        const char *wtap = wlane + (size_t)tap * C::WTAP;
+#endif
         OmTap now[RPW];
 #pragma unroll
         for (int m = 0; m < RPW; ++m) now[m] = nxt[m];
@@ -132,11 +158,16 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
 #pragma unroll
             for (int m = 0; m < RPW; ++m) nxt[m] = load_om(om[m], tap + 1, in_img[m]);
         }
+#if !EMAVFI_DEFORM_WREG
         const char *wb = lds_w + cur * C::WTAP + lane * 16;
+#endif
         // sampling geometry of this lane's two pixels for this tap
         SampleTap st[RPW];
         unsigned lo[RPW][4];
         bool inside[RPW], all_inside[RPW];
+#if EMAVFI_DEFORM_DOT2
+        BlendW bw[RPW];
+#endif
 #pragma unroll
         for (int m = 0; m < RPW; ++m) {
             int yc0, yc1, xc0, xc1;
@@ -150,11 +181,18 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
             lo[m][0] = __umul24(q0 + lx0, (unsigned)C::PSB); lo[m][1] = __umul24(q0 + lx1, (unsigned)C::PSB);
             lo[m][2] = __umul24(q1 + lx0, (unsigned)C::PSB); lo[m][3] = __umul24(q1 + lx1, (unsigned)C::PSB);
             all_inside[m] = __all(inside[m]);
+#if EMAVFI_DEFORM_DOT2
+            bw[m] = blend_weights_bf16(st[m].w);
+#endif
         }
         // software pipeline over the RPW*KG (row, k-group) steps: the four corner pieces of step s+1
         // are in flight while step s is blended and contracted
         auto gather = [&](int sidx, uint4 (&v)[4]) {
+#if EMAVFI_DEFORM_WREG
+            const int kg = sidx / RPW, m = sidx - kg * RPW;   // k-group outer: one weight fragment set serves RPW rows
+#else
             const int m = sidx / C::KG, kg = sidx - m * C::KG;
+#endif
             // slot of this lane's piece in the staged pixel; pieces past the staged channels
             // (zero weights) re-read the last slot
             const int slot = (2 * kg + h < C::SP) ? 2 * kg + h : C::SP - 1;
@@ -172,12 +210,33 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
 #pragma unroll
         for (int sidx = 0; sidx < RPW * C::KG; ++sidx) {
             if (sidx + 1 < RPW * C::KG) gather(sidx + 1, vb[(sidx + 1) & 1]);
+#if EMAVFI_DEFORM_WREG
+            const int kg = sidx / RPW, m = sidx - kg * RPW;
+            if (m == 0) {  // fetch the next k-group's fragments (or the next tap's first) while this one is used
+                if (kg + 1 < C::KG) {
+#pragma unroll
+                    for (int n = 0; n < NF; ++n) wq[(kg + 1) & 1][n] = *reinterpret_cast<const bf16x8 *>(wtap + ((kg + 1) * NF + n) * 1024);
+                } else if (tap < 8) {
+#pragma unroll
+                    for (int n = 0; n < NF; ++n) w0next[n] = *reinterpret_cast<const bf16x8 *>(wtap + C::WTAP + n * 1024);
+                }
+            }
+#else
             const int m = sidx / C::KG, kg = sidx - m * C::KG;
+#endif
+#if EMAVFI_DEFORM_DOT2
+            const bf16x8 xf = blend4_dot2(vb[sidx & 1], bw[m]);
+#else
             const bf16x8 xf = blend4(vb[sidx & 1], st[m].w, bf16_t{});
+#endif
 #pragma unroll
             for (int n = 0; n < NF; ++n) {
+#if EMAVFI_DEFORM_WREG
+                mma_kg(acc[m][n], wq[kg & 1][n], xf);
+#else
                 const bf16x8 wv = *reinterpret_cast<const bf16x8 *>(wb + (kg * NF + n) * 1024);
                 mma_kg(acc[m][n], wv, xf);
+#endif
             }
         }
         // retire the tap's accumulator chains before the next tap's geometry code (common.h)
@@ -185,10 +244,12 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
         for (int m = 0; m < RPW; ++m)
 #pragma unroll
             for (int n = 0; n < NF; ++n) mfma_retire(acc[m][n]);
+#if !EMAVFI_DEFORM_WREG
         if (tap < 8) {
             __syncthreads();  // drains the next tap's weight DMA; everyone is done with buffer `cur`
             cur ^= 1;
         }
+#endif
     }
 
 #pragma unroll
