@@ -300,3 +300,35 @@ def test_reload_state_dict_repacks():
         b = m(f1.to(DEV), f2.to(DEV)).cpu()
     assert (a - oracle.forward(sd_a, f1, f2)).abs().max().item() <= 1e-3
     assert (b - oracle.forward(sd_b, f1, f2)).abs().max().item() <= 1e-3
+
+
+_FUSION_AB = r"""
+import hashlib, sys, torch
+sys.path[:0] = [r"%(pkg)s"]
+from emavfi import EMA_VFI, synth
+m = EMA_VFI(compute_dtype="bf16").to("cuda:0").eval()
+m.load_state_dict(synth.synthetic_state_dict(seed=21, mid_channels=64))
+f1, f2 = synth.synthetic_frames(22, 2, 75, 131, "natural")
+with torch.no_grad():
+    out = m(f1.cuda(), f2.cuda()).cpu()
+print("SHA", hashlib.sha256(out.numpy().tobytes()).hexdigest())
+"""
+
+
+def test_fused_pack_is_bit_identical_to_two_launches():
+    """bf16 at the reference width runs offset_conv inside the deform kernel (one launch per
+    ModulatedDeformConvPack).  Same arithmetic in the same order as conv3x3(EPI_OM) + deform: the frames must be
+    bit-identical to the two-launch path (EMAVFI_NO_FUSED_OFFSET=1), ragged size included."""
+    import os
+    import subprocess
+    import sys
+    from conftest import PKG
+    code = _FUSION_AB % {"pkg": PKG}
+    shas = []
+    for extra in ({}, {"EMAVFI_NO_FUSED_OFFSET": "1"}):
+        env = dict(os.environ, **extra)
+        env.pop("EMAVFI_NO_FUSED_OFFSET", None) if not extra else None
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        shas.append([l for l in r.stdout.splitlines() if l.startswith("SHA")][-1])
+    assert shas[0] == shas[1]

@@ -137,11 +137,15 @@ struct ConvParams {
 
 struct DeformParams {
     const void *x;     // channels-last T, CK channels used
-    const float *om;   // [px][32] fp32: 18 offsets (dy,dx per tap), 9 masks, 5 pad
+    float *om;         // [px][32] fp32: 18 offsets (dy,dx per tap), 9 masks, 5 pad (read; written first when fused)
     void *out;         // channels-last T
     const void *w;     // packed [tap][kg][nf][lane][16 B]
     const float *bias; // [NF*32]
     const void *zeros; // >= 16 bytes of zeros (DMA source for out-of-image window pixels)
+    // fused ModulatedDeformConvPack (bf16 LDS kernel only): when off_w is set the kernel first runs the pack's
+    // offset_conv (3x3, cin -> 27, packed like a (CK, nf=1) conv layer) on the staged window and WRITES om
+    const void *off_w;
+    const float *off_bias;
     int x_ps, out_ps;
     int H, W, B;
     int cstore;
@@ -153,3 +157,4 @@ int launch_conv3x3_f32(const ConvParams &p, hipStream_t s);
 int launch_conv3x3_bf16(const ConvParams &p, hipStream_t s);
 int launch_deform_f32(const DeformParams &p, hipStream_t s);
 int launch_deform_bf16(const DeformParams &p, hipStream_t s);
+bool deform_bf16_can_fuse_offset_conv(int ck, int nf, int cin_real, int off_ck, int off_nf);

@@ -21,6 +21,7 @@
 //   * the tap's packed weights are double buffered in LDS and DMA'd one tap ahead (one barrier
 //     per tap); the next tap's (dy, dx, mask) are fetched one tap ahead as well.
 #include "deform.inl"
+#include <type_traits>
 
 #ifndef EMAVFI_DEFORM_DOT2
 #define EMAVFI_DEFORM_DOT2 1
@@ -57,7 +58,7 @@ __device__ __forceinline__ OmTap load_om(const float *__restrict__ om, int tap, 
     return t;
 }
 
-template <int CK, int NF, int CS, int R, int RPW>
+template <int CK, int NF, int CS, int R, int RPW, bool FUSE_OFF>
 __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const DeformParams p)
 {
     using C = DeformLdsCfg<CK, NF, CS, R, RPW>;
@@ -103,9 +104,10 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
     // weights never touch LDS: every wave loads its MFMA A fragments straight from the packed blob (135 KiB,
     // L2/L1 resident, one k-group ahead) - no weight ring, no per-tap barrier, the waves run decoupled
     const char *wlane = (const char *)p.w + lane * 16;
-    bf16x8 wq[2][NF], w0next[NF];
+    bf16x8 wq[2][NF];  // [kg & 1]; the next tap's first k-group arrives in wq[1] (KG is odd) and moves to wq[0]
+    static_assert((C::KG & 1) == 1, "cross-tap prefetch slot assumes an odd k-group count");
 #pragma unroll
-    for (int n = 0; n < NF; ++n) w0next[n] = *reinterpret_cast<const bf16x8 *>(wlane + n * 1024);
+    for (int n = 0; n < NF; ++n) wq[1][n] = *reinterpret_cast<const bf16x8 *>(wlane + n * 1024);
 #endif
 
     f32x16 acc[RPW][NF];
@@ -126,10 +128,64 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
         py_y[m] = blockIdx.y * C::TROWS + wave * RPW + m;
         in_img[m] = py_y[m] < H && px_x < W;
         om[m] = p.om + (((size_t)b * H + (in_img[m] ? py_y[m] : 0)) * W + (in_img[m] ? px_x : 0)) * 32;
-        nxt[m] = load_om(om[m], 0, in_img[m]);
+        if (!FUSE_OFF) nxt[m] = load_om(om[m], 0, in_img[m]);
     }
     const char *gx = gplane + h * 16;
+    // offset_conv weight fragments of the first two taps ride along with the window DMA
+    const char *owl = (const char *)p.off_w + lane * 16;
+    bf16x8 ow[FUSE_OFF ? 3 : 1][C::KG];
+    if constexpr (FUSE_OFF) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int kg = 0; kg < C::KG; ++kg) ow[t][kg] = *reinterpret_cast<const bf16x8 *>(owl + (t * C::KG + kg) * 1024);
+    }
     __syncthreads();  // hipcc drains the DMA (vmcnt(0)) ahead of the barrier
+
+    // fused: this lane's half of its pixels' (dy, dx, mask) values stays in registers in accumulator layout:
+    // channel c sits in half-lane (c >> 2) & 1, register (c & 3) + 4 * (c >> 3)
+    f32x16 omr[FUSE_OFF ? RPW : 1];
+    if constexpr (FUSE_OFF) {
+        // ---- the pack's offset_conv (ema_vfi.py:41,56: 3x3, pad 1, cin -> 27) on the staged window ----
+        // Plain (undeformed) taps: the B operand of lane (r, h) is a 16-byte piece of window pixel
+        // (row + i + R, r + j + R), read as it lies; out-of-image pixels were zero-filled by the DMA = the
+        // conv's zero padding.  Weight fragments come from L2 two taps ahead.  Same tap/k-group order and the
+        // same epilogue as the stand-alone conv3x3 EPI_OM layer -> bit-identical om.
+        f32x16 (&oacc)[RPW] = omr;
+#pragma unroll
+        for (int m = 0; m < RPW; ++m)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[m][i] = p.off_bias[acc_channel(i, h)];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap < 7) {  // two taps ahead (L2 latency is ~3 taps of MFMA time for one wave)
+#pragma unroll
+                for (int kg = 0; kg < C::KG; ++kg) ow[(tap + 2) % 3][kg] = *reinterpret_cast<const bf16x8 *>(owl + ((tap + 2) * C::KG + kg) * 1024);
+            }
+            const int i = tap / 3, j = tap - 3 * i;
+#pragma unroll
+            for (int m = 0; m < RPW; ++m) {
+                const char *xp = lds_x + (((wave * RPW + m) + i + R) * C::TC + (r + j + R)) * C::PSB;
+#pragma unroll
+                for (int kg = 0; kg < C::KG; ++kg) {
+                    const int slot = (2 * kg + h < C::SP) ? 2 * kg + h : C::SP - 1;
+                    const bf16x8 xv = *reinterpret_cast<const bf16x8 *>(xp + slot * 16);
+                    mma_kg(oacc[m], ow[tap % 3][kg], xv);
+                }
+            }
+        }
+        // mask = sigmoid(third chunk), ema_vfi.py:59 (channels 18..26 after the pack-time routing); pixels outside
+        // the image get mask 0.  Nothing goes through memory: the main loop picks (dy, dx, mask) of a tap out of
+        // these registers with one v_permlane32_swap per value.
+#pragma unroll
+        for (int m = 0; m < RPW; ++m)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int c = acc_channel(i, h);
+                const float v = oacc[m][i];
+                oacc[m][i] = (c >= 18 && c < 27) ? (in_img[m] ? 1.0f / (1.0f + expf(-v)) : 0.0f) : v;
+            }
+    }
 
 #if !EMAVFI_DEFORM_WREG
     int cur = 0;
@@ -148,15 +204,45 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
         }
 #else
 #pragma unroll
-        for (int n = 0; n < NF; ++n) wq[0][n] = w0next[n];
+        for (int n = 0; n < NF; ++n) wq[0][n] = wq[1][n];
         const char *wtap = wlane + (size_t)tap * C::WTAP;
 #endif
         OmTap now[RPW];
+        if constexpr (FUSE_OFF) {
+            // value of channel c of this lane's pixel, wherever its half-lane keeps it: a = b = reg, swap a.hi <-> b.lo
+            auto pick = [&](const f32x16 &v, auto cc) {
+                constexpr int c = decltype(cc)::value;
+                const unsigned u = __float_as_uint(v[(c & 3) + 4 * (c >> 3)]);
+                const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                return __uint_as_float(((c >> 2) & 1) ? sw[1] : sw[0]);
+            };
+            auto take = [&](auto kc) {
+                constexpr int k = decltype(kc)::value;
 #pragma unroll
-        for (int m = 0; m < RPW; ++m) now[m] = nxt[m];
-        if (tap < 8) {
+                for (int m = 0; m < RPW; ++m) {
+                    now[m].dy = pick(omr[m], std::integral_constant<int, 2 * k>{});
+                    now[m].dx = pick(omr[m], std::integral_constant<int, 2 * k + 1>{});
+                    now[m].mk = pick(omr[m], std::integral_constant<int, 18 + k>{});
+                }
+            };
+            switch (tap) {  // wave-uniform; registers cannot be indexed by a loop variable
+            case 0: take(std::integral_constant<int, 0>{}); break;
+            case 1: take(std::integral_constant<int, 1>{}); break;
+            case 2: take(std::integral_constant<int, 2>{}); break;
+            case 3: take(std::integral_constant<int, 3>{}); break;
+            case 4: take(std::integral_constant<int, 4>{}); break;
+            case 5: take(std::integral_constant<int, 5>{}); break;
+            case 6: take(std::integral_constant<int, 6>{}); break;
+            case 7: take(std::integral_constant<int, 7>{}); break;
+            default: take(std::integral_constant<int, 8>{}); break;
+            }
+        } else {
 #pragma unroll
-            for (int m = 0; m < RPW; ++m) nxt[m] = load_om(om[m], tap + 1, in_img[m]);
+            for (int m = 0; m < RPW; ++m) now[m] = nxt[m];
+            if (tap < 8) {
+#pragma unroll
+                for (int m = 0; m < RPW; ++m) nxt[m] = load_om(om[m], tap + 1, in_img[m]);
+            }
         }
 #if !EMAVFI_DEFORM_WREG
         const char *wb = lds_w + cur * C::WTAP + lane * 16;
@@ -218,7 +304,7 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
                     for (int n = 0; n < NF; ++n) wq[(kg + 1) & 1][n] = *reinterpret_cast<const bf16x8 *>(wtap + ((kg + 1) * NF + n) * 1024);
                 } else if (tap < 8) {
 #pragma unroll
-                    for (int n = 0; n < NF; ++n) w0next[n] = *reinterpret_cast<const bf16x8 *>(wtap + C::WTAP + n * 1024);
+                    for (int n = 0; n < NF; ++n) wq[1][n] = *reinterpret_cast<const bf16x8 *>(wtap + C::WTAP + n * 1024);
                 }
             }
 #else
@@ -262,17 +348,17 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
     }
 }
 
-template <int CK, int NF, int CS, int R, int RPW> static int launch_deform_lds(const DeformParams &p, hipStream_t s)
+template <int CK, int NF, int CS, int R, int RPW, bool FUSE_OFF> static int launch_deform_lds(const DeformParams &p, hipStream_t s)
 {
     using C = DeformLdsCfg<CK, NF, CS, R, RPW>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&deform_lds_kernel<CK, NF, CS, R, RPW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&deform_lds_kernel<CK, NF, CS, R, RPW, FUSE_OFF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
     dim3 grid((p.W + C::TCOLS - 1) / C::TCOLS, (p.H + C::TROWS - 1) / C::TROWS, p.B);
-    deform_lds_kernel<CK, NF, CS, R, RPW><<<grid, C::THREADS, C::LDS_BYTES, s>>>(p);
+    deform_lds_kernel<CK, NF, CS, R, RPW, FUSE_OFF><<<grid, C::THREADS, C::LDS_BYTES, s>>>(p);
     return (int)hipGetLastError();
 }

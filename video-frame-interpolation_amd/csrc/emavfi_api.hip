@@ -176,11 +176,15 @@ int run_conv(const Plan &P, const Layer &L, const void *packed, const void *in, 
     return P.dtype == EMAVFI_F32 ? launch_conv3x3_f32(c, s) : launch_conv3x3_bf16(c, s);
 }
 
-int run_deform(const Plan &P, const Layer &L, const void *packed, const void *x, int x_ps, const float *om, void *out,
-               int out_ps, int cstore, int B, int H, int W, hipStream_t s, const void *zeros = nullptr)
+int run_deform(const Plan &P, const Layer &L, const void *packed, const void *x, int x_ps, float *om, void *out,
+               int out_ps, int cstore, int B, int H, int W, hipStream_t s, const void *zeros = nullptr, const Layer *off = nullptr)
 {
     DeformParams d{};
     d.x = x; d.om = om; d.out = out;
+    if (off) {  // fused ModulatedDeformConvPack: the kernel computes om itself
+        d.off_w = (const char *)packed + off->w_off;
+        d.off_bias = (const float *)((const char *)packed + off->b_off);
+    }
     d.w = (const char *)packed + L.w_off;
     d.bias = (const float *)((const char *)packed + L.b_off);
     d.zeros = zeros ? zeros : (const char *)packed + P.zero_off;
@@ -364,12 +368,22 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
     void *x = f.fu0, *y = f.fu1;
     for (int i = 0; i < P.nb; ++i) {
         conv_work(P, P.off[i], B, H, W, 4.0, fl, by);
-        EMAVFI_STEP(rec, conv_name(P, P.off[i]) + " offset_conv", fl, by,
-                    run_conv(P, P.off[i], packed, x, P.fpad, H, W, f.om, 32, 0, 32, EPI_OM, B, s));
         const double cf = mid + 3;
-        EMAVFI_STEP(rec, deform_name(P, P.dcn[i]) + " dcn_v2", 2.0 * 9.0 * cf * cf * px,
-                    px * (2.0 * cf * e + 27.0 * 4.0) + 9.0 * cf * cf * e,
-                    run_deform(P, P.dcn[i], packed, x, P.fpad, f.om, y, P.fpad, P.fpad, B, H, W, s));
+        const bool fused = dtype == EMAVFI_BF16 && P.off[i].nchunk == 1 && P.off[i].npass == 1 && P.off[i].stride == 1 &&
+                           deform_bf16_can_fuse_offset_conv(P.dcn[i].ck, P.dcn[i].nf, P.dcn[i].cin_take, P.off[i].ck, P.off[i].nf);
+        if (fused) {
+            // one launch for the whole pack (ema_vfi.py:54-60): offset_conv on the staged window, then the DCN;
+            // the input is read once and the offsets / masks never leave the registers
+            EMAVFI_STEP(rec, deform_name(P, P.dcn[i]) + " offset_conv+dcn_v2", fl + 2.0 * 9.0 * cf * cf * px,
+                        px * (2.0 * cf * e) + 9.0 * cf * (cf + 27.0) * e,
+                        run_deform(P, P.dcn[i], packed, x, P.fpad, f.om, y, P.fpad, P.fpad, B, H, W, s, nullptr, &P.off[i]));
+        } else {
+            EMAVFI_STEP(rec, conv_name(P, P.off[i]) + " offset_conv", fl, by,
+                        run_conv(P, P.off[i], packed, x, P.fpad, H, W, f.om, 32, 0, 32, EPI_OM, B, s));
+            EMAVFI_STEP(rec, deform_name(P, P.dcn[i]) + " dcn_v2", 2.0 * 9.0 * cf * cf * px,
+                        px * (2.0 * cf * e + 27.0 * 4.0) + 9.0 * cf * cf * e,
+                        run_deform(P, P.dcn[i], packed, x, P.fpad, f.om, y, P.fpad, P.fpad, B, H, W, s));
+        }
         if (!rec.dry && taps && taps[5 + i])
             EMAVFI_TRY(launch_cl_to_nchw(y, taps[5 + i], B, mid + 3, H, W, P.fpad, 0, dtype, s), "tap fused");
         void *t = x; x = y; y = t;
