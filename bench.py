@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-PEAK = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA TFLOP/s (MI355X_MICROARCH.md, chip-level table)
+PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}   # dense MFMA TFLOP/s (MI355X_MICROARCH.md, chip-level table)
 PEAK_HBM_GBS = 8000.0                     # HBM3E spec peak (same table)
 FLOP_PER_PX = 1054908.0                   # whole forward, unfolded
 
@@ -88,7 +88,7 @@ def cpu_baseline(sd, rows, width, dev=None):
         import math
         from emavfi import EMA_VFI
         accuracy = {"sample": f"the cpu_baseline strip (1 pair, {width}x{rows}), HIP path vs CPU oracle"}
-        for mode in ("fp32", "bf16"):
+        for mode in ("fp32", "bf16", "fp16"):
             m = EMA_VFI(compute_dtype=mode).to(dev).eval()
             m.load_state_dict(sd, strict=True)
             with torch.no_grad():
@@ -136,7 +136,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="frame pairs per GPU (configs[2]: 8)")
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--width", type=int, default=1280)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"],
+                    help="bf16 = BASELINE configs[2]; fp16 = the autocast arithmetic of the reference; fp32 = parity mode")
     ap.add_argument("--cpu-rows", type=int, default=360, help="rows of the 720p strip the CPU baseline runs (0 = skip)")
     ap.add_argument("--no-events", action="store_true", help="time the plain entry point (no per-launch events)")
     args = ap.parse_args()
@@ -203,10 +204,10 @@ def main():
         value = frames / elapsed
         res = {"metric": "interpolated_frames_per_sec_720p_2x", "value": round(value, 2), "unit": "frames/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype if args.dtype != "fp32" else "f32",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "fp16": "f16"}.get(args.dtype, args.dtype),
                "data": "synthetic",
                "config": {"workload": f"BASELINE configs[2]: batch {B} x {W}x{H} frame pairs per GPU, "
-                                      f"{'bf16 convs + fp32 warp' if args.dtype == 'bf16' else 'fp32 MFMA convs + fp32 warp'}, "
+                                      f"{args.dtype + ' convs + fp32 warp' if args.dtype != 'fp32' else 'fp32 MFMA convs + fp32 warp'}, "
                                       "EMA_VFI(3,64,3), synthetic non-degenerate weights",
                           "pairs_per_gpu": B, "height": H, "width": W, "parallelism": f"replica-dp{world}",
                           "collectives": f"one {backend} broadcast of packed weights before timing" if world > 1 else "none"},

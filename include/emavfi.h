@@ -26,9 +26,14 @@
  *    every convolution with fp32-input MFMA (exact fp32 FMA chains; this is the
  *    parity mode, <= 1e-3 max-abs vs the reference's CPU forward);
  *    EMAVFI_BF16 stores activations and weights in bf16 and accumulates in
- *    fp32 (BASELINE.json configs[2]: "bf16 convs + fp32 warp").  Flow, warp
- *    coordinates, deformable offsets / masks / bilinear weights, the pooled
- *    context vector and the output are fp32 in both modes.
+ *    fp32 (BASELINE.json configs[2]: "bf16 convs + fp32 warp"); its fused
+ *    deformable kernel rounds the four bilinear corner weights to bf16 too.
+ *    EMAVFI_F16 is the same data flow in IEEE half precision - the arithmetic
+ *    torch.cuda.amp.autocast() gives the reference's convolutions on a GPU
+ *    (inference.py:159) - with fp32 corner weights; values beyond +-65504
+ *    overflow to inf exactly as they would there.  Flow, warp coordinates,
+ *    deformable offsets / masks / sampling positions, the pooled context
+ *    vector and the output are fp32 in every mode.
  *  - The model is identified by the reference constructor's three integers
  *    (ema_vfi.py:64): in_channels, mid_channels, num_blocks.
  */
@@ -45,6 +50,7 @@ extern "C" {
 
 #define EMAVFI_F32 0
 #define EMAVFI_BF16 1
+#define EMAVFI_F16 2
 
 #define EMAVFI_OK 0
 #define EMAVFI_E_ARG (-1)         /* bad shape / dtype / null pointer / misaligned pointer */

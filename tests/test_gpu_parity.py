@@ -76,7 +76,7 @@ CONV_CASES = [  # (Cin, Cout, H, W, stride, act): one per reference layer shape 
 ]
 
 
-@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-5), ("bf16", 2e-2), ("fp16", 3e-3)])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv3x3_matches_aten(case, dtype, tol):
     Cin, Cout, H, W, stride, act = case
@@ -92,7 +92,7 @@ def test_conv3x3_matches_aten(case, dtype, tol):
 
 
 # ------------------------------------------------------------------ deformable conv (rows O, D)
-@pytest.mark.parametrize("dtype,tol", [("fp32", 3e-5), ("bf16", 3e-2)])
+@pytest.mark.parametrize("dtype,tol", [("fp32", 3e-5), ("bf16", 3e-2), ("fp16", 4e-3)])
 @pytest.mark.parametrize("C,O,H,W,spread", [(67, 67, 19, 41, 2.0), (67, 67, 8, 32, 12.0), (11, 11, 23, 37, 1.5),
                                             (5, 7, 1, 1, 1.0), (19, 19, 9, 33, 3.0), (35, 35, 16, 16, 2.0)])
 def test_deform_conv2d_matches_oracle(C, O, H, W, spread, dtype, tol):
@@ -236,8 +236,10 @@ def test_forward_ragged_sizes_mid64_both_dtypes(H, W):
     with torch.no_grad():
         a = make_model(sd, dtype="fp32")(f1.to(DEV), f2.to(DEV)).cpu()
         b = make_model(sd, dtype="bf16")(f1.to(DEV), f2.to(DEV)).cpu()
+        c = make_model(sd, dtype="fp16")(f1.to(DEV), f2.to(DEV)).cpu()
     assert (a - ref).abs().max().item() <= 1e-3
     assert torch.isfinite(b).all() and (b - ref).abs().max().item() <= 0.15
+    assert torch.isfinite(c).all() and (c - ref).abs().max().item() <= 0.03
 
 
 def test_forward_bf16_psnr():
@@ -253,12 +255,35 @@ def test_forward_bf16_psnr():
     assert p >= 30.0
 
 
+def test_forward_fp16_autocast_parity_mode():
+    """the arithmetic torch.cuda.amp.autocast() gives the reference on a GPU (fp16 convolutions, fp32
+    warp / offsets / accumulation).  Parity is UNPINNED (no GPU run of the reference exists): the check is the fp32
+    oracle at a tolerance that 10 mantissa bits must meet and bf16 does not, plus the dtype resolution rules."""
+    sd = synth.synthetic_state_dict(seed=0)
+    f1, f2 = synth.synthetic_frames(1, 2, 256, 256, "natural")
+    ref = oracle.forward(sd, f1, f2)
+    with torch.no_grad():
+        h = make_model(sd, dtype="fp16")(f1.to(DEV), f2.to(DEV)).cpu()
+        b = make_model(sd, dtype="bf16")(f1.to(DEV), f2.to(DEV)).cpu()
+        m = make_model(sd, dtype=None)
+        with torch.autocast("cuda", dtype=torch.float16):
+            auto_h = m(f1.to(DEV), f2.to(DEV)).float().cpu()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            auto_b = m(f1.to(DEV), f2.to(DEV)).float().cpu()
+        plain = m(f1.to(DEV), f2.to(DEV)).cpu()
+    ph, pb = psnr(h, ref), psnr(b, ref)
+    print(f"fp16 vs fp32 oracle: PSNR {ph:.1f} dB, max-abs {(h - ref).abs().max().item():.3e} (bf16: {pb:.1f} dB)")
+    assert ph >= 60.0 and ph >= pb + 10.0
+    assert torch.equal(auto_h, h) and torch.equal(auto_b, b)      # autocast dtype selects the arithmetic
+    assert (plain - ref).abs().max().item() <= 1e-3               # no autocast: exact-fp32 parity mode
+
+
 def test_full_size_properties_config3():
     """BASELINE configs[2] size (B=8, 1280x720): size-independent properties instead of a CPU replay -
     determinism, batch-permutation equivariance (bit exact), output range."""
     sd = synth.synthetic_state_dict(seed=0)
     f1, f2 = synth.fast_frames(3, 8, 720, 1280, device=DEV)
-    for dtype in ("fp32", "bf16"):
+    for dtype in ("fp32", "bf16", "fp16"):
         m = make_model(sd, dtype=dtype)
         with torch.no_grad():
             a = m(f1, f2)
@@ -306,17 +331,18 @@ _FUSION_AB = r"""
 import hashlib, sys, torch
 sys.path[:0] = [r"%(pkg)s"]
 from emavfi import EMA_VFI, synth
-m = EMA_VFI(compute_dtype="bf16").to("cuda:0").eval()
-m.load_state_dict(synth.synthetic_state_dict(seed=21, mid_channels=64))
-f1, f2 = synth.synthetic_frames(22, 2, 75, 131, "natural")
-with torch.no_grad():
-    out = m(f1.cuda(), f2.cuda()).cpu()
-print("SHA", hashlib.sha256(out.numpy().tobytes()).hexdigest())
+for dt in ("bf16", "fp16"):
+    m = EMA_VFI(compute_dtype=dt).to("cuda:0").eval()
+    m.load_state_dict(synth.synthetic_state_dict(seed=21, mid_channels=64))
+    f1, f2 = synth.synthetic_frames(22, 2, 75, 131, "natural")
+    with torch.no_grad():
+        out = m(f1.cuda(), f2.cuda()).cpu()
+    print("SHA", dt, hashlib.sha256(out.numpy().tobytes()).hexdigest())
 """
 
 
 def test_fused_pack_is_bit_identical_to_two_launches():
-    """bf16 at the reference width runs offset_conv inside the deform kernel (one launch per
+    """bf16 / fp16 at the reference width run offset_conv inside the deform kernel (one launch per
     ModulatedDeformConvPack).  Same arithmetic in the same order as conv3x3(EPI_OM) + deform: the frames must be
     bit-identical to the two-launch path (EMAVFI_NO_FUSED_OFFSET=1), ragged size included."""
     import os
@@ -330,5 +356,5 @@ def test_fused_pack_is_bit_identical_to_two_launches():
         env.pop("EMAVFI_NO_FUSED_OFFSET", None) if not extra else None
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stderr[-2000:]
-        shas.append([l for l in r.stdout.splitlines() if l.startswith("SHA")][-1])
-    assert shas[0] == shas[1]
+        shas.append([l for l in r.stdout.splitlines() if l.startswith("SHA")])
+    assert len(shas[0]) == 2 and shas[0] == shas[1]

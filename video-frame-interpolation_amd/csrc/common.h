@@ -6,6 +6,9 @@
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef _Float16 half_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
@@ -19,6 +22,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 // One "k-group" = what one 16-byte operand load per lane feeds to the matrix core:
 //   bf16: 16 input channels -> one v_mfma_f32_32x32x16_bf16
 //         (lane (r, h) holds channels 8h..8h+7 of row/col r)
+//   f16:  the same shape on v_mfma_f32_32x32x16_f16 (EMAVFI_F16: what torch.cuda.amp.autocast() computes convs in)
 //   fp32:  8 input channels -> four v_mfma_f32_32x32x2_f32
 //         (lane (r, h) holds channels 4h..4h+3; MFMA j contracts channels {j, 4+j})
 template <typename T> struct DT;
@@ -32,6 +36,11 @@ template <> struct DT<bf16_t> {
     static constexpr int EPV = 8;
     using vec = bf16x8;
 };
+template <> struct DT<half_t> {
+    static constexpr int CHKG = 16;
+    static constexpr int EPV = 8;
+    using vec = f16x8;
+};
 
 // D[cout][pixel] += W[cout][k] * X[k][pixel] for one k-group.  Orientation: weights are the
 // A operand (rows = output channels), pixels are the B operand (cols), so each lane ends up
@@ -40,6 +49,10 @@ template <> struct DT<bf16_t> {
 __device__ __forceinline__ void mma_kg(f32x16 &acc, const bf16x8 &w, const bf16x8 &x)
 {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma_kg(f32x16 &acc, const f16x8 &w, const f16x8 &x)
+{
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, acc, 0, 0, 0);
 }
 __device__ __forceinline__ void mma_kg(f32x16 &acc, const f32x4 &w, const f32x4 &x)
 {
@@ -71,6 +84,10 @@ __device__ __forceinline__ void store4(bf16_t *p, float a, float b, float c, flo
 {
     *reinterpret_cast<bf16x4 *>(p) = bf16x4{(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
 }
+__device__ __forceinline__ void store4(half_t *p, float a, float b, float c, float d)
+{
+    *reinterpret_cast<f16x4 *>(p) = f16x4{(half_t)a, (half_t)b, (half_t)c, (half_t)d};
+}
 
 // Channels-last epilogue store of one 32-channel accumulator fragment of pixel r.
 // Lane (r, h) holds channel groups {8g + 4h .. +3}, g = 0..3.  fp32: a group is already 16 bytes.
@@ -87,17 +104,18 @@ __device__ __forceinline__ void store_frag(float *base, const f32x16 &acc, int h
         if (c0 < limit) store4(base + c0, act(acc[4 * g], c0), act(acc[4 * g + 1], c0 + 1), act(acc[4 * g + 2], c0 + 2), act(acc[4 * g + 3], c0 + 3));
     }
 }
-template <typename F>
-__device__ __forceinline__ void store_frag(bf16_t *base, const f32x16 &acc, int h, int limit, F act)
+template <typename T16, typename F>
+__device__ __forceinline__ void store_frag16(T16 *base, const f32x16 &acc, int h, int limit, F act)
 {
+    typedef __attribute__((ext_vector_type(2))) T16 pair_t;
 #pragma unroll
     for (int g = 0; g < 4; g += 2) {
         unsigned a[2], b[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int ca = 8 * g + 4 * h + 2 * j, cb = 8 * (g + 1) + 4 * h + 2 * j;
-            const __attribute__((ext_vector_type(2))) __bf16 pa = {(bf16_t)act(acc[4 * g + 2 * j], ca), (bf16_t)act(acc[4 * g + 2 * j + 1], ca + 1)};
-            const __attribute__((ext_vector_type(2))) __bf16 pb = {(bf16_t)act(acc[4 * (g + 1) + 2 * j], cb), (bf16_t)act(acc[4 * (g + 1) + 2 * j + 1], cb + 1)};
+            const pair_t pa = {(T16)act(acc[4 * g + 2 * j], ca), (T16)act(acc[4 * g + 2 * j + 1], ca + 1)};
+            const pair_t pb = {(T16)act(acc[4 * (g + 1) + 2 * j], cb), (T16)act(acc[4 * (g + 1) + 2 * j + 1], cb + 1)};
             a[j] = __builtin_bit_cast(unsigned, pa);
             b[j] = __builtin_bit_cast(unsigned, pb);
             const auto sw = __builtin_amdgcn_permlane32_swap(a[j], b[j], false, false);
@@ -108,6 +126,10 @@ __device__ __forceinline__ void store_frag(bf16_t *base, const f32x16 &acc, int 
         if (c0 < limit) *reinterpret_cast<uint4 *>(base + c0) = make_uint4(a[0], a[1], b[0], b[1]);
     }
 }
+template <typename F>
+__device__ __forceinline__ void store_frag(bf16_t *base, const f32x16 &acc, int h, int limit, F act) { store_frag16(base, acc, h, limit, act); }
+template <typename F>
+__device__ __forceinline__ void store_frag(half_t *base, const f32x16 &acc, int h, int limit, F act) { store_frag16(base, acc, h, limit, act); }
 
 // LDS pixel stride for CK channels of T: one 16-byte slot of padding makes the stride an odd
 // number of slots, so the 16 lanes of a ds_read_b128 group (consecutive pixels, same channel
@@ -155,6 +177,9 @@ struct DeformParams {
 
 int launch_conv3x3_f32(const ConvParams &p, hipStream_t s);
 int launch_conv3x3_bf16(const ConvParams &p, hipStream_t s);
+int launch_conv3x3_f16(const ConvParams &p, hipStream_t s);
 int launch_deform_f32(const DeformParams &p, hipStream_t s);
 int launch_deform_bf16(const DeformParams &p, hipStream_t s);
-bool deform_bf16_can_fuse_offset_conv(int ck, int nf, int cin_real, int off_ck, int off_nf);
+int launch_deform_f16(const DeformParams &p, hipStream_t s);
+// 16-bit dtypes at the reference width: the whole ModulatedDeformConvPack is one launch (deform_lds.inl)
+bool deform16_can_fuse_offset_conv(int ck, int nf, int cin_real, int off_ck, int off_nf);

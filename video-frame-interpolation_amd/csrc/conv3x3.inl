@@ -362,3 +362,18 @@ template <typename T> static int launch_conv_any(const ConvParams &p, hipStream_
 #undef X
     return -2;  // no instantiation
 }
+
+// 16-bit launcher (bf16 / f16): full-resolution single-chunk layers go to the persistent, weights-resident kernel
+// (CK, NF, waves): 64->64, 64->32 / 64->2, 67->27 of the mid_channels = 64 model.
+template <typename T> static int launch_conv16(const ConvParams &p, hipStream_t s, bool no_persistent)
+{
+    if (!no_persistent && p.stride == 1 && p.nchunk == 1 && p.npass == 1) {
+        // measured at B=8 x 720p in bf16 (us per launch, tile-per-workgroup -> persistent): 64->64 670 -> 644,
+        // 64->32 / 64->2 414 -> 370, 67->27 685 -> 557.  NOT used where it loses: 67->64 with 4 waves
+        // (771 -> 915: one 4-wave workgroup per CU cannot overlap its own phases), 6->64, 32->3 (no gain).
+        if (p.ck == 64 && p.nf == 2) return launch_conv_persist<T, 64, 2, 8>(p, s);
+        if (p.ck == 64 && p.nf == 1) return launch_conv_persist<T, 64, 1, 8>(p, s);
+        if (p.ck == 80 && p.nf == 1) return launch_conv_persist<T, 80, 1, 8>(p, s);
+    }
+    return launch_conv_any<T>(p, s);
+}

@@ -1,7 +1,7 @@
 #include "conv3x3.inl"
 #include <cstdlib>
-int launch_conv3x3_bf16(const ConvParams &p, hipStream_t s)
+int launch_conv3x3_f16(const ConvParams &p, hipStream_t s)
 {
     static const bool off = getenv("EMAVFI_NO_PERSISTENT_CONV") != nullptr;  // A/B switch for measurements
-    return launch_conv16<bf16_t>(p, s, off);
+    return launch_conv16<half_t>(p, s, off);
 }

@@ -133,6 +133,25 @@ __device__ __forceinline__ bf16x8 blend4_dot2(const uint4 (&v)[4], const BlendW 
     }
     return bf16x8{(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)a[4], (bf16_t)a[5], (bf16_t)a[6], (bf16_t)a[7]};
 }
+// f16: fp32 blend with fp32 weights on v_fma_mix_f32, which reads an f16 half of a packed register directly
+// (op_sel_hi marks source 0 as f16, op_sel picks its high half) - no unpack.  Written as asm because hipcc
+// otherwise prefers 2 x v_cvt_f32_f16 + v_pk_fma_f32 per channel pair (3 instructions instead of 2).
+__device__ __forceinline__ f16x8 blend4(const uint4 (&v)[4], const float (&w)[4], half_t)
+{
+    float a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const unsigned d[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(a[2 * q]) : "v"(d[q]), "v"(w[c]));
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a[2 * q + 1]) : "v"(d[q]), "v"(w[c]));
+        }
+    }
+    return f16x8{(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)a[4], (half_t)a[5], (half_t)a[6], (half_t)a[7]};
+}
 __device__ __forceinline__ f32x4 blend4(const uint4 (&v)[4], const float (&w)[4], float)
 {
     f32x4 a = {0.f, 0.f, 0.f, 0.f};

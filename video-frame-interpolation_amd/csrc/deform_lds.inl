@@ -1,4 +1,4 @@
-// bf16 modulated deformable conv with the input window staged in LDS (the "tiled gather with LDS
+// bf16 / f16 modulated deformable conv with the input window staged in LDS (the "tiled gather with LDS
 // halo" of BASELINE.json).  Same operator and fragment scheme as deform.inl; what changes is
 // where the bilinear taps are fetched from:
 //
@@ -58,10 +58,15 @@ __device__ __forceinline__ OmTap load_om(const float *__restrict__ om, int tap, 
     return t;
 }
 
-template <int CK, int NF, int CS, int R, int RPW, bool FUSE_OFF>
+template <typename T, int CK, int NF, int CS, int R, int RPW, bool FUSE_OFF>
 __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const DeformParams p)
 {
     using C = DeformLdsCfg<CK, NF, CS, R, RPW>;
+    using vec = typename DT<T>::vec;  // vec or f16x8
+    // bf16 blends on the dot-product unit (corner weights rounded to bf16); f16 blends in fp32 - the compiler folds
+    // the f16->f32 conversions into v_fma_mix_f32, so there is no unpack to save and the weights stay fp32
+    constexpr bool DOT2 = EMAVFI_DEFORM_DOT2 && std::is_same<T, bf16_t>::value;
+    static_assert(sizeof(T) == 2, "the LDS-window kernel is for the 16-bit dtypes");
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -104,10 +109,10 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
     // weights never touch LDS: every wave loads its MFMA A fragments straight from the packed blob (135 KiB,
     // L2/L1 resident, one k-group ahead) - no weight ring, no per-tap barrier, the waves run decoupled
     const char *wlane = (const char *)p.w + lane * 16;
-    bf16x8 wq[2][NF];  // [kg & 1]; the next tap's first k-group arrives in wq[1] (KG is odd) and moves to wq[0]
+    vec wq[2][NF];  // [kg & 1]; the next tap's first k-group arrives in wq[1] (KG is odd) and moves to wq[0]
     static_assert((C::KG & 1) == 1, "cross-tap prefetch slot assumes an odd k-group count");
 #pragma unroll
-    for (int n = 0; n < NF; ++n) wq[1][n] = *reinterpret_cast<const bf16x8 *>(wlane + n * 1024);
+    for (int n = 0; n < NF; ++n) wq[1][n] = *reinterpret_cast<const vec *>(wlane + n * 1024);
 #endif
 
     f32x16 acc[RPW][NF];
@@ -133,12 +138,12 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
     const char *gx = gplane + h * 16;
     // offset_conv weight fragments of the first two taps ride along with the window DMA
     const char *owl = (const char *)p.off_w + lane * 16;
-    bf16x8 ow[FUSE_OFF ? 3 : 1][C::KG];
+    vec ow[FUSE_OFF ? 3 : 1][C::KG];
     if constexpr (FUSE_OFF) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int kg = 0; kg < C::KG; ++kg) ow[t][kg] = *reinterpret_cast<const bf16x8 *>(owl + (t * C::KG + kg) * 1024);
+            for (int kg = 0; kg < C::KG; ++kg) ow[t][kg] = *reinterpret_cast<const vec *>(owl + (t * C::KG + kg) * 1024);
     }
     __syncthreads();  // hipcc drains the DMA (vmcnt(0)) ahead of the barrier
 
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
         for (int tap = 0; tap < 9; ++tap) {
             if (tap < 7) {  // two taps ahead (L2 latency is ~3 taps of MFMA time for one wave)
 #pragma unroll
-                for (int kg = 0; kg < C::KG; ++kg) ow[(tap + 2) % 3][kg] = *reinterpret_cast<const bf16x8 *>(owl + ((tap + 2) * C::KG + kg) * 1024);
+                for (int kg = 0; kg < C::KG; ++kg) ow[(tap + 2) % 3][kg] = *reinterpret_cast<const vec *>(owl + ((tap + 2) * C::KG + kg) * 1024);
             }
             const int i = tap / 3, j = tap - 3 * i;
 #pragma unroll
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
 #pragma unroll
                 for (int kg = 0; kg < C::KG; ++kg) {
                     const int slot = (2 * kg + h < C::SP) ? 2 * kg + h : C::SP - 1;
-                    const bf16x8 xv = *reinterpret_cast<const bf16x8 *>(xp + slot * 16);
+                    const vec xv = *reinterpret_cast<const vec *>(xp + slot * 16);
                     mma_kg(oacc[m], ow[tap % 3][kg], xv);
                 }
             }
@@ -251,9 +256,7 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
         SampleTap st[RPW];
         unsigned lo[RPW][4];
         bool inside[RPW], all_inside[RPW];
-#if EMAVFI_DEFORM_DOT2
-        BlendW bw[RPW];
-#endif
+        BlendW bw[DOT2 ? RPW : 1];
 #pragma unroll
         for (int m = 0; m < RPW; ++m) {
             int yc0, yc1, xc0, xc1;
@@ -267,9 +270,7 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
             lo[m][0] = __umul24(q0 + lx0, (unsigned)C::PSB); lo[m][1] = __umul24(q0 + lx1, (unsigned)C::PSB);
             lo[m][2] = __umul24(q1 + lx0, (unsigned)C::PSB); lo[m][3] = __umul24(q1 + lx1, (unsigned)C::PSB);
             all_inside[m] = __all(inside[m]);
-#if EMAVFI_DEFORM_DOT2
-            bw[m] = blend_weights_bf16(st[m].w);
-#endif
+            if constexpr (DOT2) bw[m] = blend_weights_bf16(st[m].w);
         }
         // software pipeline over the RPW*KG (row, k-group) steps: the four corner pieces of step s+1
         // are in flight while step s is blended and contracted
@@ -301,26 +302,24 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
             if (m == 0) {  // fetch the next k-group's fragments (or the next tap's first) while this one is used
                 if (kg + 1 < C::KG) {
 #pragma unroll
-                    for (int n = 0; n < NF; ++n) wq[(kg + 1) & 1][n] = *reinterpret_cast<const bf16x8 *>(wtap + ((kg + 1) * NF + n) * 1024);
+                    for (int n = 0; n < NF; ++n) wq[(kg + 1) & 1][n] = *reinterpret_cast<const vec *>(wtap + ((kg + 1) * NF + n) * 1024);
                 } else if (tap < 8) {
 #pragma unroll
-                    for (int n = 0; n < NF; ++n) wq[1][n] = *reinterpret_cast<const bf16x8 *>(wtap + C::WTAP + n * 1024);
+                    for (int n = 0; n < NF; ++n) wq[1][n] = *reinterpret_cast<const vec *>(wtap + C::WTAP + n * 1024);
                 }
             }
 #else
             const int m = sidx / C::KG, kg = sidx - m * C::KG;
 #endif
-#if EMAVFI_DEFORM_DOT2
-            const bf16x8 xf = blend4_dot2(vb[sidx & 1], bw[m]);
-#else
-            const bf16x8 xf = blend4(vb[sidx & 1], st[m].w, bf16_t{});
-#endif
+            vec xf;
+            if constexpr (DOT2) xf = blend4_dot2(vb[sidx & 1], bw[m]);
+            else xf = blend4(vb[sidx & 1], st[m].w, T{});
 #pragma unroll
             for (int n = 0; n < NF; ++n) {
 #if EMAVFI_DEFORM_WREG
                 mma_kg(acc[m][n], wq[kg & 1][n], xf);
 #else
-                const bf16x8 wv = *reinterpret_cast<const bf16x8 *>(wb + (kg * NF + n) * 1024);
+                const vec wv = *reinterpret_cast<const vec *>(wb + (kg * NF + n) * 1024);
                 mma_kg(acc[m][n], wv, xf);
 #endif
             }
@@ -341,24 +340,40 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
 #pragma unroll
     for (int m = 0; m < RPW; ++m) {
         if (!in_img[m]) continue;
-        bf16_t *op = reinterpret_cast<bf16_t *>(p.out) + (((size_t)b * H + py_y[m]) * W + px_x) * p.out_ps;
+        T *op = reinterpret_cast<T *>(p.out) + (((size_t)b * H + py_y[m]) * W + px_x) * p.out_ps;
 #pragma unroll
         for (int n = 0; n < NF; ++n)
             if (p.cstore - n * 32 > 0) store_frag(op + n * 32, acc[m][n], h, p.cstore - n * 32, [](float v, int) { return v; });
     }
 }
 
-template <int CK, int NF, int CS, int R, int RPW, bool FUSE_OFF> static int launch_deform_lds(const DeformParams &p, hipStream_t s)
+template <typename T, int CK, int NF, int CS, int R, int RPW, bool FUSE_OFF> static int launch_deform_lds(const DeformParams &p, hipStream_t s)
 {
     using C = DeformLdsCfg<CK, NF, CS, R, RPW>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&deform_lds_kernel<CK, NF, CS, R, RPW, FUSE_OFF>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&deform_lds_kernel<T, CK, NF, CS, R, RPW, FUSE_OFF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
     dim3 grid((p.W + C::TCOLS - 1) / C::TCOLS, (p.H + C::TROWS - 1) / C::TROWS, p.B);
-    deform_lds_kernel<CK, NF, CS, R, RPW, FUSE_OFF><<<grid, C::THREADS, C::LDS_BYTES, s>>>(p);
+    deform_lds_kernel<T, CK, NF, CS, R, RPW, FUSE_OFF><<<grid, C::THREADS, C::LDS_BYTES, s>>>(p);
     return (int)hipGetLastError();
+}
+
+#ifndef EMAVFI_DEFORM_RPW
+#define EMAVFI_DEFORM_RPW 2  // rows per wave; 1 (16 waves, <=128 VGPRs) spills and is 7x slower
+#endif
+// the reference width (mid_channels 64 -> 67 channels, k-groups to 80): LDS-staged window of 72 channels
+static inline bool deform16_lds_shape(int ck, int nf, int cin_real) { return ck == 80 && nf == 3 && cin_real <= 72; }
+
+template <typename T> static int launch_deform16(const DeformParams &p, hipStream_t s)
+{
+    if (deform16_lds_shape(p.ck, p.nf, p.cin_real)) {
+        if (p.off_w) return launch_deform_lds<T, 80, 3, 72, 2, EMAVFI_DEFORM_RPW, true>(p, s);
+        return launch_deform_lds<T, 80, 3, 72, 2, EMAVFI_DEFORM_RPW, false>(p, s);
+    }
+    if (p.off_w) return -1;  // the host only asks for fusion after deform16_can_fuse_offset_conv()
+    return launch_deform_any<T>(p, s);
 }

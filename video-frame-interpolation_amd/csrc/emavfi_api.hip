@@ -109,7 +109,7 @@ Layer mk(int param, int cout, int cin_raw, int stride = 1, int cin_off = 0, int 
 bool build_plan(Plan &P, int in_ch, int mid, int nb, int dtype)
 {
     P.why = "";
-    if (dtype != EMAVFI_F32 && dtype != EMAVFI_BF16) { P.why = "dtype must be EMAVFI_F32 or EMAVFI_BF16"; return false; }
+    if (dtype != EMAVFI_F32 && dtype != EMAVFI_BF16 && dtype != EMAVFI_F16) { P.why = "dtype must be EMAVFI_F32, EMAVFI_BF16 or EMAVFI_F16"; return false; }
     if (in_ch < 1 || in_ch > 4) { P.why = "in_channels must be 1..4"; return false; }
     if (nb < 1 || nb > kMaxBlocks) { P.why = "num_blocks must be 1..8"; return false; }
     if (mid < 8 || mid % 8 != 0) { P.why = "mid_channels must be a positive multiple of 8"; return false; }
@@ -173,7 +173,7 @@ int run_conv(const Plan &P, const Layer &L, const void *packed, const void *in, 
     c.B = B; c.nchunk = L.nchunk; c.npass = L.npass; c.cstore = cstore;
     c.epi = epi; c.nplanes = nplanes; c.bias_mode = bias_table ? 1 : 0;
     c.ck = L.ck; c.nf = L.nf; c.stride = L.stride;
-    return P.dtype == EMAVFI_F32 ? launch_conv3x3_f32(c, s) : launch_conv3x3_bf16(c, s);
+    return P.dtype == EMAVFI_F32 ? launch_conv3x3_f32(c, s) : P.dtype == EMAVFI_F16 ? launch_conv3x3_f16(c, s) : launch_conv3x3_bf16(c, s);
 }
 
 int run_deform(const Plan &P, const Layer &L, const void *packed, const void *x, int x_ps, float *om, void *out,
@@ -189,7 +189,7 @@ int run_deform(const Plan &P, const Layer &L, const void *packed, const void *x,
     d.bias = (const float *)((const char *)packed + L.b_off);
     d.zeros = zeros ? zeros : (const char *)packed + P.zero_off;
     d.x_ps = x_ps; d.out_ps = out_ps; d.H = H; d.W = W; d.B = B; d.cstore = cstore; d.cin_real = L.cin_take; d.ck = L.ck; d.nf = L.nf;
-    return P.dtype == EMAVFI_F32 ? launch_deform_f32(d, s) : launch_deform_bf16(d, s);
+    return P.dtype == EMAVFI_F32 ? launch_deform_f32(d, s) : P.dtype == EMAVFI_F16 ? launch_deform_f16(d, s) : launch_deform_bf16(d, s);
 }
 
 int pack_layer(const Layer &L, const void *const *params, void *packed, int dtype, hipStream_t s)
@@ -242,7 +242,7 @@ struct Recorder {
     bool dry = false;                        // enumerate only, launch nothing
 };
 
-const char *dtype_name(int dtype) { return dtype == EMAVFI_F32 ? "f32" : "bf16"; }
+const char *dtype_name(int dtype) { return dtype == EMAVFI_F32 ? "f32" : dtype == EMAVFI_F16 ? "f16" : "bf16"; }
 
 std::string conv_name(const Plan &P, const Layer &L)
 {
@@ -369,8 +369,8 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
     for (int i = 0; i < P.nb; ++i) {
         conv_work(P, P.off[i], B, H, W, 4.0, fl, by);
         const double cf = mid + 3;
-        const bool fused = dtype == EMAVFI_BF16 && P.off[i].nchunk == 1 && P.off[i].npass == 1 && P.off[i].stride == 1 &&
-                           deform_bf16_can_fuse_offset_conv(P.dcn[i].ck, P.dcn[i].nf, P.dcn[i].cin_take, P.off[i].ck, P.off[i].nf);
+        const bool fused = dtype != EMAVFI_F32 && P.off[i].nchunk == 1 && P.off[i].npass == 1 && P.off[i].stride == 1 &&
+                           deform16_can_fuse_offset_conv(P.dcn[i].ck, P.dcn[i].nf, P.dcn[i].cin_take, P.off[i].ck, P.off[i].nf);
         if (fused) {
             // one launch for the whole pack (ema_vfi.py:54-60): offset_conv on the staged window, then the DCN;
             // the input is read once and the offsets / masks never leave the registers
@@ -577,7 +577,7 @@ size_t emavfi_conv3x3_workspace_bytes(int B, int Cin, int Cout, int H, int W, in
 int emavfi_conv3x3(const float *x, const float *weight, const float *bias, float *y, int B, int Cin, int Cout, int H, int W,
                    int stride, int act, int dtype, void *workspace, size_t workspace_bytes, void *stream)
 {
-    if (dtype != EMAVFI_F32 && dtype != EMAVFI_BF16) return fail(EMAVFI_E_ARG, "conv3x3: bad dtype %d", dtype);
+    if (dtype != EMAVFI_F32 && dtype != EMAVFI_BF16 && dtype != EMAVFI_F16) return fail(EMAVFI_E_ARG, "conv3x3: bad dtype %d", dtype);
     if (!x || !weight || !y || !workspace) return fail(EMAVFI_E_ARG, "conv3x3: null pointer");
     if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || (stride != 1 && stride != 2)) return fail(EMAVFI_E_ARG, "conv3x3: bad shape");
     if (act < EMAVFI_ACT_NONE || act > EMAVFI_ACT_TANH01) return fail(EMAVFI_E_ARG, "conv3x3: bad activation %d", act);
@@ -630,7 +630,7 @@ int emavfi_deform_conv2d(const float *x, const float *offset, const float *mask,
                          float *y, int B, int C, int O, int H, int W, int dtype, void *workspace, size_t workspace_bytes,
                          void *stream)
 {
-    if (dtype != EMAVFI_F32 && dtype != EMAVFI_BF16) return fail(EMAVFI_E_ARG, "deform_conv2d: bad dtype %d", dtype);
+    if (dtype != EMAVFI_F32 && dtype != EMAVFI_BF16 && dtype != EMAVFI_F16) return fail(EMAVFI_E_ARG, "deform_conv2d: bad dtype %d", dtype);
     if (!x || !offset || !mask || !weight || !y || !workspace) return fail(EMAVFI_E_ARG, "deform_conv2d: null pointer");
     if (B < 1 || C < 1 || O < 1 || H < 1 || W < 1) return fail(EMAVFI_E_ARG, "deform_conv2d: bad shape");
     if ((size_t)H * W >= ((size_t)1 << 24)) return fail(EMAVFI_E_ARG, "deform_conv2d: H*W must be < 2^24");

@@ -55,6 +55,8 @@ int launch_pack_conv(const float *w, const float *bias, void *wp, float *bp, con
 {
     if (dtype == 0)
         pack_conv_kernel<float><<<256, 256, 0, s>>>(w, bias, (float *)wp, bp, d);
+    else if (dtype == 2)
+        pack_conv_kernel<half_t><<<256, 256, 0, s>>>(w, bias, (half_t *)wp, bp, d);
     else
         pack_conv_kernel<bf16_t><<<256, 256, 0, s>>>(w, bias, (bf16_t *)wp, bp, d);
     return (int)hipGetLastError();
@@ -118,6 +120,7 @@ int launch_pack_input(const float *f1, const float *f2, void *dst, int B, int C,
 {
     const int grid = (int)std::min<size_t>(((size_t)B * H * W + 255) / 256, 65535 * 4);
     if (dtype == 0) pack_input_kernel<float><<<grid, 256, 0, s>>>(f1, f2, (float *)dst, B, C, H, W, cpad);
+    else if (dtype == 2) pack_input_kernel<half_t><<<grid, 256, 0, s>>>(f1, f2, (half_t *)dst, B, C, H, W, cpad);
     else pack_input_kernel<bf16_t><<<grid, 256, 0, s>>>(f1, f2, (bf16_t *)dst, B, C, H, W, cpad);
     return (int)hipGetLastError();
 }
@@ -146,6 +149,7 @@ int launch_nchw_to_cl(const float *src, void *dst, int B, int C, int H, int W, i
 {
     const int grid = (int)std::min<size_t>(((size_t)B * H * W + 255) / 256, 65535 * 4);
     if (dtype == 0) nchw_to_cl_kernel<float><<<grid, 256, 0, s>>>(src, (float *)dst, B, C, H, W, ps);
+    else if (dtype == 2) nchw_to_cl_kernel<half_t><<<grid, 256, 0, s>>>(src, (half_t *)dst, B, C, H, W, ps);
     else nchw_to_cl_kernel<bf16_t><<<grid, 256, 0, s>>>(src, (bf16_t *)dst, B, C, H, W, ps);
     return (int)hipGetLastError();
 }
@@ -153,6 +157,7 @@ int launch_cl_to_nchw(const void *src, float *dst, int B, int C, int H, int W, i
 {
     const int grid = (int)std::min<size_t>(((size_t)B * H * W + 255) / 256, 65535 * 4);
     if (dtype == 0) cl_to_nchw_kernel<float><<<grid, 256, 0, s>>>((const float *)src, dst, B, C, H, W, ps, coff);
+    else if (dtype == 2) cl_to_nchw_kernel<half_t><<<grid, 256, 0, s>>>((const half_t *)src, dst, B, C, H, W, ps, coff);
     else cl_to_nchw_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t *)src, dst, B, C, H, W, ps, coff);
     return (int)hipGetLastError();
 }
@@ -206,6 +211,7 @@ int launch_pool_partial(const void *src, float *part, int B, int npix, int cp, i
 {
     dim3 grid(nparts, B);
     if (dtype == 0) pool_partial_kernel<float><<<grid, 256, 0, s>>>((const float *)src, part, npix, cp, ps, nparts);
+    else if (dtype == 2) pool_partial_kernel<half_t><<<grid, 256, 0, s>>>((const half_t *)src, part, npix, cp, ps, nparts);
     else pool_partial_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t *)src, part, npix, cp, ps, nparts);
     return (int)hipGetLastError();
 }
@@ -500,11 +506,13 @@ int launch_warp_fused(const float *frame2, const float *flow, void *dst, int B, 
     if ((W & 3) == 0 && C == 3) {
         const int nwg = ((W + 63) / 64) * ((H + 31) / 32) * B;
         if (dtype == 0) warp_tiled_kernel<3, float><<<nwg, 256, 0, s>>>(frame2, flow, nullptr, B, H, W, dst, ps, coff);
+        else if (dtype == 2) warp_tiled_kernel<3, half_t><<<nwg, 256, 0, s>>>(frame2, flow, nullptr, B, H, W, dst, ps, coff);
         else warp_tiled_kernel<3, bf16_t><<<nwg, 256, 0, s>>>(frame2, flow, nullptr, B, H, W, dst, ps, coff);
         return (int)hipGetLastError();
     }
     const int grid = (int)std::min<size_t>(((size_t)B * H * W + 255) / 256, 256 * 64);
     if (dtype == 0) warp_fused_kernel<float><<<grid, 256, 0, s>>>(frame2, flow, (float *)dst, B, C, H, W, ps, coff);
+    else if (dtype == 2) warp_fused_kernel<half_t><<<grid, 256, 0, s>>>(frame2, flow, (half_t *)dst, B, C, H, W, ps, coff);
     else warp_fused_kernel<bf16_t><<<grid, 256, 0, s>>>(frame2, flow, (bf16_t *)dst, B, C, H, W, ps, coff);
     return (int)hipGetLastError();
 }

@@ -91,8 +91,10 @@ class ModulatedDeformConvPack(nn.Module):
 class EMA_VFI(nn.Module):
     """MI355X-native EMA-VFI.  ``compute_dtype``: ``"fp32"`` (parity mode: exact-fp32 MFMA,
     <= 1e-3 max-abs vs the reference CPU forward), ``"bf16"`` (bf16 convs, fp32 warp / offsets /
-    accumulation) or ``None`` = fp32 unless autocast is active (the reference runs its convs in
-    half precision under ``torch.cuda.amp.autocast()``, inference.py:159)."""
+    accumulation; BASELINE.json configs[2]), ``"fp16"`` (the same data flow in IEEE half) or ``None`` =
+    fp32 unless autocast is active, then the autocast dtype: under the reference's own
+    ``torch.cuda.amp.autocast()`` (inference.py:159, float16 by default) the convolutions run in fp16 as
+    they would there, under ``torch.autocast("cuda", dtype=torch.bfloat16)`` in bf16."""
 
     def __init__(self, in_channels=3, mid_channels=64, num_blocks=3, compute_dtype=None):
         super().__init__()
@@ -176,7 +178,11 @@ class EMA_VFI(nn.Module):
     def _resolve_dtype(self) -> int:
         if self.compute_dtype is not None:
             return _lib.dtype_code(self.compute_dtype)
-        return _lib.BF16 if torch.is_autocast_enabled() else _lib.F32
+        if not torch.is_autocast_enabled():
+            return _lib.F32
+        get = getattr(torch, "get_autocast_dtype", None)
+        auto = get("cuda") if get is not None else torch.get_autocast_gpu_dtype()
+        return _lib.BF16 if auto == torch.bfloat16 else _lib.F16
 
     # ------------------------------------------------------------------ forward
     def forward(self, frame1, frame2, return_taps=False, _events=None):
