@@ -32,7 +32,7 @@ def test_host_queries_and_error_codes():
     L = lib.load()
     assert L.emavfi_param_count(3) == 40
     for mid in (8, 16, 32, 64):
-        for dt in (lib.F32, lib.BF16):
+        for dt in (lib.F32, lib.BF16, lib.F16):
             assert L.emavfi_supported(3, mid, 3, dt) == 0
             assert L.emavfi_packed_bytes(3, mid, 3, dt) > 0
     assert L.emavfi_supported(3, 7, 3, lib.F32) == -2 and "multiple of 8" in lib.last_error()
@@ -43,6 +43,13 @@ def test_host_queries_and_error_codes():
     raw = sum(int(torch.tensor(s).prod()) for s in synth.param_shapes().values()) * 4
     assert L.emavfi_packed_bytes(3, 64, 3, lib.F32) >= raw
     assert L.emavfi_packed_bytes(3, 64, 3, lib.BF16) < L.emavfi_packed_bytes(3, 64, 3, lib.F32)
+    # the two 16-bit modes share every size; the dtype codes are the header's
+    assert L.emavfi_packed_bytes(3, 64, 3, lib.F16) == L.emavfi_packed_bytes(3, 64, 3, lib.BF16)
+    assert L.emavfi_workspace_bytes(3, 64, 3, 2, 96, 128, lib.F16) == L.emavfi_workspace_bytes(3, 64, 3, 2, 96, 128, lib.BF16)
+    hdr = open(os.path.join(ROOT, "include", "emavfi.h")).read()
+    for name, code in (("EMAVFI_F32", lib.F32), ("EMAVFI_BF16", lib.BF16), ("EMAVFI_F16", lib.F16)):
+        assert f"#define {name} {code}\n" in hdr
+    assert lib.dtype_code("fp16") == lib.F16 and lib.dtype_code("half") == lib.F16 and lib.dtype_code("bfloat16") == lib.BF16
     assert L.emavfi_workspace_bytes(3, 64, 3, 8, 720, 1280, lib.BF16) < 8 << 30
     assert L.emavfi_workspace_bytes(3, 64, 3, 0, 720, 1280, lib.BF16) == 0
     # argument validation happens before any device work
