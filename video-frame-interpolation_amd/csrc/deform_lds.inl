@@ -29,6 +29,9 @@
 #ifndef EMAVFI_DEFORM_WREG
 #define EMAVFI_DEFORM_WREG 1
 #endif
+#ifndef EMAVFI_DEFORM_SHARE_GEOMETRY
+#define EMAVFI_DEFORM_SHARE_GEOMETRY 1
+#endif
 
 template <int CK, int NF, int CS, int R, int RPW> struct DeformLdsCfg {
     static constexpr int WAVES = 16 / RPW, THREADS = 64 * WAVES;
@@ -252,25 +255,75 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
 #if !EMAVFI_DEFORM_WREG
         const char *wb = lds_w + cur * C::WTAP + lane * 16;
 #endif
-        // sampling geometry of this lane's two pixels for this tap
+        // sampling geometry of this lane's RPW pixels for this tap
         SampleTap st[RPW];
         unsigned lo[RPW][4];
         bool inside[RPW], all_inside[RPW];
         BlendW bw[DOT2 ? RPW : 1];
-#pragma unroll
-        for (int m = 0; m < RPW; ++m) {
+        // one row's geometry: positions, corner weights, global offsets (st), window-local LDS offsets (lw),
+        // whether all four corners lie inside the staged window
+        auto geometry = [&](const OmTap &o, int y, SampleTap &t, unsigned (&lw)[4]) -> bool {
             int yc0, yc1, xc0, xc1;
-            st[m] = sample_tap_vals(now[m].dy, now[m].dx, now[m].mk, tap, py_y[m], px_x, H, W, ps_bytes, &yc0, &yc1, &xc0, &xc1);
-            inside[m] = yc0 >= ty0 && yc1 <= ty0 + C::TR - 1 && xc0 >= tx0 && xc1 <= tx0 + C::TC - 1;
+            t = sample_tap_vals(o.dy, o.dx, o.mk, tap, y, px_x, H, W, ps_bytes, &yc0, &yc1, &xc0, &xc1);
             // window-local corner offsets, clamped into the window so every lane's LDS read is in
             // bounds; lanes that are not `inside` overwrite what they read with the global gather
             const int ly0 = min(max(yc0 - ty0, 0), C::TR - 1), ly1 = min(max(yc1 - ty0, 0), C::TR - 1);
             const int lx0 = min(max(xc0 - tx0, 0), C::TC - 1), lx1 = min(max(xc1 - tx0, 0), C::TC - 1);
             const unsigned q0 = __umul24((unsigned)ly0, (unsigned)C::TC), q1 = __umul24((unsigned)ly1, (unsigned)C::TC);
-            lo[m][0] = __umul24(q0 + lx0, (unsigned)C::PSB); lo[m][1] = __umul24(q0 + lx1, (unsigned)C::PSB);
-            lo[m][2] = __umul24(q1 + lx0, (unsigned)C::PSB); lo[m][3] = __umul24(q1 + lx1, (unsigned)C::PSB);
-            all_inside[m] = __all(inside[m]);
-            if constexpr (DOT2) bw[m] = blend_weights_bf16(st[m].w);
+            lw[0] = __umul24(q0 + lx0, (unsigned)C::PSB); lw[1] = __umul24(q0 + lx1, (unsigned)C::PSB);
+            lw[2] = __umul24(q1 + lx0, (unsigned)C::PSB); lw[3] = __umul24(q1 + lx1, (unsigned)C::PSB);
+            return yc0 >= ty0 && yc1 <= ty0 + C::TR - 1 && xc0 >= tx0 && xc1 <= tx0 + C::TC - 1;
+        };
+        if constexpr (RPW == 2 && EMAVFI_DEFORM_SHARE_GEOMETRY) {
+            // The two half-lanes of a pixel column need the same numbers for both rows: half h computes row h
+            // only, and one v_permlane32_swap per dword hands both halves both rows (swap(x, x) = {row 0's, row 1's}).
+            OmTap oh;
+            oh.dy = h ? now[1].dy : now[0].dy; oh.dx = h ? now[1].dx : now[0].dx; oh.mk = h ? now[1].mk : now[0].mk;
+            SampleTap th;
+            unsigned lh[4];
+            const bool ih = geometry(oh, py_y[0] + h, th, lh);
+            auto both = [&](unsigned x, unsigned &r0, unsigned &r1) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+                r0 = sw[0]; r1 = sw[1];
+            };
+            unsigned i0, i1;
+            both(ih ? 1u : 0u, i0, i1);
+            inside[0] = i0 != 0; inside[1] = i1 != 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                both(lh[c], lo[0][c], lo[1][c]);
+                both(th.o[c], st[0].o[c], st[1].o[c]);
+            }
+            if constexpr (DOT2) {
+                // corner weights travel as two packed bf16 pairs
+                typedef __attribute__((ext_vector_type(2))) __bf16 pair_t;
+                unsigned p01[2], p23[2];
+                both(__builtin_bit_cast(unsigned, pair_t{(bf16_t)th.w[0], (bf16_t)th.w[1]}), p01[0], p01[1]);
+                both(__builtin_bit_cast(unsigned, pair_t{(bf16_t)th.w[2], (bf16_t)th.w[3]}), p23[0], p23[1]);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    bw[m].lo[0] = p01[m] & 0xffffu; bw[m].hi[0] = p01[m] << 16;
+                    bw[m].lo[1] = p01[m] >> 16;     bw[m].hi[1] = p01[m] & 0xffff0000u;
+                    bw[m].lo[2] = p23[m] & 0xffffu; bw[m].hi[2] = p23[m] << 16;
+                    bw[m].lo[3] = p23[m] >> 16;     bw[m].hi[3] = p23[m] & 0xffff0000u;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    unsigned w0, w1;
+                    both(__float_as_uint(th.w[c]), w0, w1);
+                    st[0].w[c] = __uint_as_float(w0); st[1].w[c] = __uint_as_float(w1);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) all_inside[m] = __all(inside[m]);
+        } else {
+#pragma unroll
+            for (int m = 0; m < RPW; ++m) {
+                inside[m] = geometry(now[m], py_y[m], st[m], lo[m]);
+                all_inside[m] = __all(inside[m]);
+                if constexpr (DOT2) bw[m] = blend_weights_bf16(st[m].w);
+            }
         }
         // software pipeline over the RPW*KG (row, k-group) steps: the four corner pieces of step s+1
         // are in flight while step s is blended and contracted
