@@ -120,10 +120,16 @@ __device__ __forceinline__ BlendW blend_weights_bf16(const float (&w)[4])
 __device__ __forceinline__ bf16x8 blend4_dot2(const uint4 (&v)[4], const BlendW &w)
 {
     float a[8];
+    {   // first corner: the three-source form with a literal 0 addend (no accumulator to clear first)
+        const unsigned d[4] = {v[0].x, v[0].y, v[0].z, v[0].w};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) a[j] = 0.0f;
+        for (int q = 0; q < 4; ++q) {
+            asm("v_dot2_f32_bf16 %0, %1, %2, 0" : "=v"(a[2 * q]) : "v"(d[q]), "v"(w.lo[0]));
+            asm("v_dot2_f32_bf16 %0, %1, %2, 0" : "=v"(a[2 * q + 1]) : "v"(d[q]), "v"(w.hi[0]));
+        }
+    }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 1; c < 4; ++c) {
         const unsigned d[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -139,10 +145,16 @@ __device__ __forceinline__ bf16x8 blend4_dot2(const uint4 (&v)[4], const BlendW 
 __device__ __forceinline__ f16x8 blend4(const uint4 (&v)[4], const float (&w)[4], half_t)
 {
     float a[8];
+    {   // first corner: literal 0 addend (no accumulator to clear first)
+        const unsigned d[4] = {v[0].x, v[0].y, v[0].z, v[0].w};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) a[j] = 0.0f;
+        for (int q = 0; q < 4; ++q) {
+            asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(a[2 * q]) : "v"(d[q]), "v"(w[0]));
+            asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(a[2 * q + 1]) : "v"(d[q]), "v"(w[0]));
+        }
+    }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 1; c < 4; ++c) {
         const unsigned d[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
