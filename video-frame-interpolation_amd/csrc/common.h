@@ -168,6 +168,11 @@ struct DeformParams {
     // offset_conv (3x3, cin -> 27, packed like a (CK, nf=1) conv layer) on the staged window and WRITES om
     const void *off_w;
     const float *off_bias;
+    // split input (bf16/f16 LDS kernel only): channels [64, 72) of every pixel come from the compact channels-last
+    // buffer x_tail[px][tail_ps = 8] instead of x (the warp writes 16 contiguous bytes per pixel there instead of 6
+    // useful bytes into every 160-byte fusion pixel); channels 72.. are zero
+    const void *x_tail;
+    int tail_ps;
     int x_ps, out_ps;
     int H, W, B;
     int cstore;

@@ -86,6 +86,9 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
     const int ty0 = blockIdx.y * C::TROWS - 1 - R, tx0 = blockIdx.x * C::TCOLS - 1 - R;
     const char *gplane = (const char *)p.x + (size_t)b * H * W * ps_bytes;
     const char *zeros = (const char *)p.zeros;
+    const unsigned tail_bytes = (unsigned)p.tail_ps * 2u;
+    const char *tplane = p.x_tail ? (const char *)p.x_tail + (size_t)b * H * W * tail_bytes : nullptr;
+    static_assert(CS == 72, "the split-input path assumes the tail starts at channel 64 = the last staged slot");
 
     // ---- DMA the input window (zero outside the image) and tap 0's weights ----
 #pragma unroll
@@ -98,6 +101,7 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
             const int gy = ty0 + ly, gxx = tx0 + lx;
             const bool ok = sl < C::NSLOT && gy >= 0 && gy < H && gxx >= 0 && gxx < W;
             const char *src = ok ? gplane + (size_t)(gy * W + gxx) * ps_bytes + pc * 16 : zeros;
+            if (tplane && ok && pc == C::SP - 1) src = tplane + (size_t)(gy * W + gxx) * tail_bytes;  // channels 64..71
             __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)(lds_x + j * 1024), 16, 0, 0);
         }
     }
@@ -341,7 +345,11 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
             if (!all_inside[m]) {   // wave-uniform: some lane reaches past the window
                 if (!inside[m]) {   // one divergent region per step
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const uint4 *>(gx + st[m].o[c] + (unsigned)(kg * 32));
+                    for (int c = 0; c < 4; ++c) {
+                        const char *src = gx + st[m].o[c] + (unsigned)(kg * 32);
+                        if (kg == C::KG - 1 && tplane) src = h ? zeros : tplane + (st[m].o[c] / ps_bytes) * tail_bytes;  // tail = 8 channels
+                        v[c] = *reinterpret_cast<const uint4 *>(src);
+                    }
                 }
             }
         };

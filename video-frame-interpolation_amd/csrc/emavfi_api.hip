@@ -177,10 +177,12 @@ int run_conv(const Plan &P, const Layer &L, const void *packed, const void *in, 
 }
 
 int run_deform(const Plan &P, const Layer &L, const void *packed, const void *x, int x_ps, float *om, void *out,
-               int out_ps, int cstore, int B, int H, int W, hipStream_t s, const void *zeros = nullptr, const Layer *off = nullptr)
+               int out_ps, int cstore, int B, int H, int W, hipStream_t s, const void *zeros = nullptr, const Layer *off = nullptr,
+               const void *x_tail = nullptr, int tail_ps = 0)
 {
     DeformParams d{};
     d.x = x; d.om = om; d.out = out;
+    d.x_tail = x_tail; d.tail_ps = tail_ps;
     if (off) {  // fused ModulatedDeformConvPack: the kernel computes om itself
         d.off_w = (const char *)packed + off->w_off;
         d.off_bias = (const float *)((const char *)packed + off->b_off);
@@ -359,24 +361,35 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
         if (hipMemcpyAsync(taps[2], f.flow, npx * 2 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
             return fail(EMAVFI_E_LAUNCH, "tap flow copy failed");
 
-    // --- warp frame2 by the flow into channels [mid, fpad) of the fusion buffer (ema_vfi.py:130,134)
+    // --- warp frame2 by the flow into channels [mid, fpad) of the fusion buffer (ema_vfi.py:130,134).
+    // When the first pack runs as the one-launch LDS kernel, those 16 channels go to a compact buffer of their own
+    // (8 channels = 16 bytes per pixel, in the packed-input buffer, free since conv1) and the kernel's window DMA picks
+    // them up from there: contiguous 16-byte pixels instead of 6 useful bytes scattered into every 160-byte fusion pixel.
+    auto pack_fuses = [&](int i) {
+        return dtype != EMAVFI_F32 && P.off[i].nchunk == 1 && P.off[i].npass == 1 && P.off[i].stride == 1 &&
+               deform16_can_fuse_offset_conv(P.dcn[i].ck, P.dcn[i].nf, P.dcn[i].cin_take, P.off[i].ck, P.off[i].nf);
+    };
+    const bool split_tail = P.nb > 0 && pack_fuses(0) && P.fpad - mid == 16;
     EMAVFI_STEP(rec, std::string("warp_fused<") + dtype_name(dtype) + ">", 24.0 * px, px * (8.0 + 4.0 * C + C * e),
-                launch_warp_fused(frame2, f.flow, f.fu0, B, C, H, W, P.fpad, mid, dtype, s));
-    if (!rec.dry && taps && taps[3]) EMAVFI_TRY(launch_cl_to_nchw(f.fu0, taps[3], B, C, H, W, P.fpad, mid, dtype, s), "tap warped");
+                split_tail ? launch_warp_fused(frame2, f.flow, f.in16, B, C, H, W, 8, 0, dtype, s)
+                           : launch_warp_fused(frame2, f.flow, f.fu0, B, C, H, W, P.fpad, mid, dtype, s));
+    if (!rec.dry && taps && taps[3])
+        EMAVFI_TRY(split_tail ? launch_cl_to_nchw(f.in16, taps[3], B, C, H, W, 8, 0, dtype, s)
+                              : launch_cl_to_nchw(f.fu0, taps[3], B, C, H, W, P.fpad, mid, dtype, s), "tap warped");
 
     // --- multi-attention fusion: num_blocks x ModulatedDeformConvPack, no activation (ema_vfi.py:136-138)
     void *x = f.fu0, *y = f.fu1;
     for (int i = 0; i < P.nb; ++i) {
         conv_work(P, P.off[i], B, H, W, 4.0, fl, by);
         const double cf = mid + 3;
-        const bool fused = dtype != EMAVFI_F32 && P.off[i].nchunk == 1 && P.off[i].npass == 1 && P.off[i].stride == 1 &&
-                           deform16_can_fuse_offset_conv(P.dcn[i].ck, P.dcn[i].nf, P.dcn[i].cin_take, P.off[i].ck, P.off[i].nf);
+        const bool fused = pack_fuses(i);
         if (fused) {
             // one launch for the whole pack (ema_vfi.py:54-60): offset_conv on the staged window, then the DCN;
             // the input is read once and the offsets / masks never leave the registers
             EMAVFI_STEP(rec, deform_name(P, P.dcn[i]) + " offset_conv+dcn_v2", fl + 2.0 * 9.0 * cf * cf * px,
                         px * (2.0 * cf * e) + 9.0 * cf * (cf + 27.0) * e,
-                        run_deform(P, P.dcn[i], packed, x, P.fpad, f.om, y, P.fpad, P.fpad, B, H, W, s, nullptr, &P.off[i]));
+                        run_deform(P, P.dcn[i], packed, x, P.fpad, f.om, y, P.fpad, P.fpad, B, H, W, s, nullptr, &P.off[i],
+                                   i == 0 && split_tail ? f.in16 : nullptr, 8));
         } else {
             EMAVFI_STEP(rec, conv_name(P, P.off[i]) + " offset_conv", fl, by,
                         run_conv(P, P.off[i], packed, x, P.fpad, H, W, f.om, 32, 0, 32, EPI_OM, B, s));

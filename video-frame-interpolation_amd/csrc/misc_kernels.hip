@@ -457,6 +457,14 @@ __global__ __launch_bounds__(256) void warp_tiled_kernel(const float *__restrict
                     store4(o + 12, 0.0f, 0.0f, 0.0f, 0.0f);
                     continue;
                 }
+                if constexpr (sizeof(T) == 2) {
+                    if (ps == 8 && coff == 0) {  // compact 8-channel tail of the fusion input: one 16-byte store per pixel
+                        typedef __attribute__((ext_vector_type(8))) T vec8;
+                        const T z = (T)0.0f;
+                        *reinterpret_cast<vec8 *>(o) = vec8{(T)v[0][q], C > 1 ? (T)v[C > 1 ? 1 : 0][q] : z, C > 2 ? (T)v[C > 2 ? 2 : 0][q] : z, z, z, z, z, z};
+                        continue;
+                    }
+                }
 #pragma unroll
                 for (int c = 0; c < C; ++c) o[c] = (T)v[c][q];
                 for (int c = C; c < ps - coff; ++c) o[c] = (T)0.0f;
