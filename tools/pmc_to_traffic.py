@@ -17,9 +17,9 @@ def per_kernel(path, counter):
 
 
 def label(k):
-    m = re.search(r"deform_lds_kernel<(\d+), (\d+)", k) or re.match(r"_Z17deform_lds_kernelILi(\d+)ELi(\d+)", k)
-    if m:
-        return f"deform<bf16,ck={m.group(1)},nf={m.group(2)}>"
+    m = re.match(r"_Z17deform_lds_kernelI(DF16b|DF16_)Li(\d+)ELi(\d+)", k)
+    if m:  # the LDS-window kernel (one launch per ModulatedDeformConvPack when its last template argument is true)
+        return f"deform<{'bf16' if m.group(1) == 'DF16b' else 'f16'},ck={m.group(2)},nf={m.group(3)}>"
     m = re.match(r"_Z14conv3x3_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)EEv", k)
     if m:
         return f"conv3x3<{'bf16' if m.group(1) == 'DF16b' else 'f32'},ck={m.group(2)},nf={m.group(3)},s={m.group(4)}>"
