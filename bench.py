@@ -255,6 +255,23 @@ def main():
             res["device_ms_per_step_sum_of_kernels"] = round(total_ms / args.steps, 3)
         if world == 1:
             res["roofline_warp"] = warp_roofline(hip, B, H, W)
+            if args.dtype == "bf16":
+                # reported beside, never part of `value`: the same workload in the arithmetic the reference's
+                # torch.cuda.amp.autocast() selects on a GPU (fp16 convolutions, EMAVFI_F16)
+                alt = EMA_VFI(compute_dtype="fp16").to(dev).eval()
+                alt.load_state_dict(sd, strict=True)
+                with torch.no_grad():
+                    for _ in range(max(args.warmup, 1)):
+                        alt(f1, f2)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(args.steps):
+                        alt(f1, f2)
+                    torch.cuda.synchronize()
+                    el = time.perf_counter() - t1
+                res["also_fp16_autocast_arithmetic"] = {"value": round(B * args.steps / el, 2), "unit": "frames/s",
+                                                        "ms_per_step": round(el / args.steps * 1e3, 3), "steps": args.steps}
+                del alt
             if args.cpu_rows > 0:
                 res["cpu_baseline"] = cpu_baseline(sd, args.cpu_rows, W, dev)
                 res["accuracy_vs_cpu_oracle"] = cpu_baseline.accuracy

@@ -30,8 +30,9 @@
  *    deformable kernel rounds the four bilinear corner weights to bf16 too.
  *    EMAVFI_F16 is the same data flow in IEEE half precision - the arithmetic
  *    torch.cuda.amp.autocast() gives the reference's convolutions on a GPU
- *    (inference.py:159) - with fp32 corner weights; values beyond +-65504
- *    overflow to inf exactly as they would there.  Flow, warp coordinates,
+ *    (inference.py:159); its fused deformable kernel blends the four corners
+ *    in packed f16; values beyond +-65504 overflow to inf exactly as they
+ *    would there.  Flow, warp coordinates,
  *    deformable offsets / masks / sampling positions, the pooled context
  *    vector and the output are fp32 in every mode.
  *  - The model is identified by the reference constructor's three integers

@@ -63,6 +63,8 @@ def test_bench_json_contract():
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb and cb["unit"] == "frames/s"
     assert r["accuracy_vs_cpu_oracle"]["fp32"]["max_abs"] <= 1e-3
+    assert r["accuracy_vs_cpu_oracle"]["fp16"]["psnr_db"] >= r["accuracy_vs_cpu_oracle"]["bf16"]["psnr_db"]
+    assert r["also_fp16_autocast_arithmetic"]["value"] > 0     # reported beside `value`, never instead of it
 
 
 @pytest.mark.gpu

@@ -139,6 +139,35 @@ __device__ __forceinline__ bf16x8 blend4_dot2(const uint4 (&v)[4], const BlendW 
     }
     return bf16x8{(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)a[4], (bf16_t)a[5], (bf16_t)a[6], (bf16_t)a[7]};
 }
+// f16, packed: v_pk_mul_f16 / v_pk_fma_f16 on the channel pairs as they sit in the registers, corner weights as
+// (w, w) f16 pairs - 16 instructions per 8-channel piece, the result is already the packed MFMA operand (no
+// conversion).  Accumulation in f16: four terms of one sign pattern, error ~2^-10 relative, the size of the final
+// rounding the fp32 blend needs anyway.
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+struct BlendWh { f16x2_t pk[4]; };
+__device__ __forceinline__ BlendWh blend_weights_f16(const float (&w)[4])
+{
+    BlendWh r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r.pk[c] = f16x2_t{(half_t)w[c], (half_t)w[c]};
+    return r;
+}
+__device__ __forceinline__ f16x8 blend4_pk(const uint4 (&v)[4], const BlendWh &w)
+{
+    f16x2_t a[4];
+    {
+        const unsigned d[4] = {v[0].x, v[0].y, v[0].z, v[0].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = __builtin_bit_cast(f16x2_t, d[q]) * w.pk[0];
+    }
+#pragma unroll
+    for (int c = 1; c < 4; ++c) {
+        const unsigned d[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d[q]), w.pk[c], a[q]);
+    }
+    return f16x8{a[0][0], a[0][1], a[1][0], a[1][1], a[2][0], a[2][1], a[3][0], a[3][1]};
+}
 // f16: fp32 blend with fp32 weights on v_fma_mix_f32, which reads an f16 half of a packed register directly
 // (op_sel_hi marks source 0 as f16, op_sel picks its high half) - no unpack.  Written as asm because hipcc
 // otherwise prefers 2 x v_cvt_f32_f16 + v_pk_fma_f32 per channel pair (3 instructions instead of 2).

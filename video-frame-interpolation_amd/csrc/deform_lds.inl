@@ -23,6 +23,9 @@
 #include "deform.inl"
 #include <type_traits>
 
+#ifndef EMAVFI_DEFORM_PKF16
+#define EMAVFI_DEFORM_PKF16 1  // f16: blend on v_pk_fma_f16 (0 = fp32 blend on v_fma_mix_f32)
+#endif
 #ifndef EMAVFI_DEFORM_DOT2
 #define EMAVFI_DEFORM_DOT2 1
 #endif
@@ -66,9 +69,10 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
 {
     using C = DeformLdsCfg<CK, NF, CS, R, RPW>;
     using vec = typename DT<T>::vec;  // vec or f16x8
-    // bf16 blends on the dot-product unit (corner weights rounded to bf16); f16 blends in fp32 - the compiler folds
-    // the f16->f32 conversions into v_fma_mix_f32, so there is no unpack to save and the weights stay fp32
+    // bf16 blends on the dot-product unit (corner weights rounded to bf16); f16 blends packed (v_pk_fma_f16, corner
+    // weights rounded to f16) - or, with EMAVFI_DEFORM_PKF16=0, in fp32 on v_fma_mix_f32 with fp32 weights
     constexpr bool DOT2 = EMAVFI_DEFORM_DOT2 && std::is_same<T, bf16_t>::value;
+    constexpr bool PKH = EMAVFI_DEFORM_PKF16 && std::is_same<T, half_t>::value;
     static_assert(sizeof(T) == 2, "the LDS-window kernel is for the 16-bit dtypes");
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
@@ -264,6 +268,7 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
         unsigned lo[RPW][4];
         bool inside[RPW], all_inside[RPW];
         BlendW bw[DOT2 ? RPW : 1];
+        BlendWh bh[PKH ? RPW : 1];
         // one row's geometry: positions, corner weights, global offsets (st), window-local LDS offsets (lw),
         // whether all four corners lie inside the staged window
         auto geometry = [&](const OmTap &o, int y, SampleTap &t, unsigned (&lw)[4]) -> bool {
@@ -311,6 +316,17 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
                     bw[m].lo[2] = p23[m] & 0xffffu; bw[m].hi[2] = p23[m] << 16;
                     bw[m].lo[3] = p23[m] >> 16;     bw[m].hi[3] = p23[m] & 0xffff0000u;
                 }
+            } else if constexpr (PKH) {
+                // corner weights travel as two packed f16 pairs, then each is doubled to (w, w)
+                unsigned p01[2], p23[2];
+                both(__builtin_bit_cast(unsigned, f16x2_t{(half_t)th.w[0], (half_t)th.w[1]}), p01[0], p01[1]);
+                both(__builtin_bit_cast(unsigned, f16x2_t{(half_t)th.w[2], (half_t)th.w[3]}), p23[0], p23[1]);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const f16x2_t a = __builtin_bit_cast(f16x2_t, p01[m]), b2 = __builtin_bit_cast(f16x2_t, p23[m]);
+                    bh[m].pk[0] = f16x2_t{a[0], a[0]}; bh[m].pk[1] = f16x2_t{a[1], a[1]};
+                    bh[m].pk[2] = f16x2_t{b2[0], b2[0]}; bh[m].pk[3] = f16x2_t{b2[1], b2[1]};
+                }
             } else {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -327,6 +343,7 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
                 inside[m] = geometry(now[m], py_y[m], st[m], lo[m]);
                 all_inside[m] = __all(inside[m]);
                 if constexpr (DOT2) bw[m] = blend_weights_bf16(st[m].w);
+                if constexpr (PKH) bh[m] = blend_weights_f16(st[m].w);
             }
         }
         // software pipeline over the RPW*KG (row, k-group) steps: the four corner pieces of step s+1
@@ -374,6 +391,7 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
 #endif
             vec xf;
             if constexpr (DOT2) xf = blend4_dot2(vb[sidx & 1], bw[m]);
+            else if constexpr (PKH) xf = blend4_pk(vb[sidx & 1], bh[m]);
             else xf = blend4(vb[sidx & 1], st[m].w, T{});
 #pragma unroll
             for (int n = 0; n < NF; ++n) {
