@@ -358,3 +358,33 @@ def test_fused_pack_is_bit_identical_to_two_launches():
         assert r.returncode == 0, r.stderr[-2000:]
         shas.append([l for l in r.stdout.splitlines() if l.startswith("SHA")])
     assert len(shas[0]) == 2 and shas[0] == shas[1]
+
+
+def test_forward_is_capturable_in_a_hip_graph():
+    """The forward only enqueues kernels on the stream it is given and allocates nothing once its workspace exists, so
+    it can be captured with torch.cuda.graph (hipGraph) and replayed on new frame contents - what a launch-bound small
+    configuration (one 256x256 pair = 20 launches) wants."""
+    sd = synth.synthetic_state_dict(seed=0)
+    m = make_model(sd, dtype="bf16")
+    a1, a2 = synth.synthetic_frames(31, 1, 256, 256, "natural")
+    b1, b2 = synth.synthetic_frames(32, 1, 256, 256, "natural")
+    s1, s2 = a1.to(DEV).clone(), a2.to(DEV).clone()
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):            # warm-up on the capture stream: packs weights, sizes the workspace
+            for _ in range(2):
+                eager_a = m(s1, s2).clone()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = m(s1, s2)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager_a)
+        s1.copy_(b1.to(DEV)); s2.copy_(b2.to(DEV))
+        graph.replay()
+        torch.cuda.synchronize()
+        replay_b = out.clone()
+        eager_b = m(b1.to(DEV), b2.to(DEV))
+    assert torch.equal(replay_b, eager_b)
