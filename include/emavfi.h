@@ -128,7 +128,8 @@ int emavfi_warp(const float *frame2, const float *flow, float *out,
  *   promotion makes it there).  denormalize = 0 skips the x*std+mean step, which the reference applies to an
  *   output that is already in [0,1].
  * `mean` and `std` are HOST pointers to C values (C <= 4): fp32 for preprocess (torchvision builds fp32
- * tensors), float64 for postprocess (numpy's np.array([...]) constants); the frame pointers are device pointers. */
+ * tensors), float64 for postprocess (numpy's np.array([...]) constants); the frame pointers are device pointers -
+ * the uint8 side may also be pinned (device-mapped) host memory, which the kernel then reads / writes over PCIe. */
 int emavfi_preprocess_u8(const unsigned char *frames_hwc, float *out_nchw, int B, int H, int W, int C,
                          const float *mean, const float *std, void *stream);
 int emavfi_postprocess_u8(const float *frames_nchw, unsigned char *out_hwc, int B, int H, int W, int C,

@@ -203,23 +203,32 @@ def _stats(mean, std, C, ctype=ctypes.c_float):
     return (ctype * C)(*mean), (ctype * C)(*std)
 
 
-def preprocess_u8(frames_hwc, mean=IMAGENET_MEAN, std=IMAGENET_STD):
-    """ToTensor + Normalize of reference inference.py:38-41 on the GPU: uint8 [B,H,W,C] -> fp32 [B,C,H,W]."""
+def _pinned_or_cuda(t, what):
+    if not (t.is_cuda or (t.device.type == "cpu" and t.is_pinned())):
+        raise RuntimeError(f"{what}: a ROCm tensor or a PINNED host tensor (read / written by the kernel over PCIe) is expected")
+
+
+def preprocess_u8(frames_hwc, mean=IMAGENET_MEAN, std=IMAGENET_STD, device=None):
+    """ToTensor + Normalize of reference inference.py:38-41 on the GPU: uint8 [B,H,W,C] -> fp32 [B,C,H,W].
+    `frames_hwc` may be a pinned host tensor: the kernel then reads it in place over PCIe (no separate H2D copy;
+    `device` names the GPU) - the caller keeps it unchanged until the kernel has run."""
     import torch
-    _require_cuda(frames_hwc)
+    _pinned_or_cuda(frames_hwc, "preprocess_u8")
     if frames_hwc.dtype != torch.uint8 or frames_hwc.dim() != 4:
         raise ValueError("preprocess_u8: uint8 [B,H,W,C] tensor expected")
-    x = frames_hwc.contiguous()
+    x = frames_hwc if frames_hwc.is_contiguous() else frames_hwc.contiguous()
+    dev = x.device if x.is_cuda else torch.device(device if device is not None else "cuda")
     B, H, W, C = x.shape
     m, s = _stats(mean, std, C)
-    out = torch.empty(B, C, H, W, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    out = torch.empty(B, C, H, W, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
         check(load().emavfi_preprocess_u8(x.data_ptr(), out.data_ptr(), B, H, W, C, m, s, _stream()), "emavfi_preprocess_u8")
     return out
 
 
-def postprocess_u8(frames_nchw, denormalize=True, mean=IMAGENET_MEAN, std=IMAGENET_STD):
-    """denormalize_frame of reference inference.py:51-58 on the GPU: fp32 [B,C,H,W] -> uint8 [B,H,W,C]."""
+def postprocess_u8(frames_nchw, denormalize=True, mean=IMAGENET_MEAN, std=IMAGENET_STD, out=None):
+    """denormalize_frame of reference inference.py:51-58 on the GPU: fp32 [B,C,H,W] -> uint8 [B,H,W,C].
+    `out` may be a pinned host tensor [B,H,W,C]: the kernel then writes the frames straight into host memory."""
     import torch
     _require_cuda(frames_nchw)
     x = _f32c(frames_nchw)
@@ -227,7 +236,12 @@ def postprocess_u8(frames_nchw, denormalize=True, mean=IMAGENET_MEAN, std=IMAGEN
         raise ValueError("postprocess_u8: [B,C,H,W] tensor expected")
     B, C, H, W = x.shape
     m, s = _stats(mean, std, C, ctypes.c_double)  # numpy's float64 constants (inference.py:55)
-    out = torch.empty(B, H, W, C, dtype=torch.uint8, device=x.device)
+    if out is None:
+        out = torch.empty(B, H, W, C, dtype=torch.uint8, device=x.device)
+    else:
+        _pinned_or_cuda(out, "postprocess_u8(out=)")
+        if out.dtype != torch.uint8 or tuple(out.shape) != (B, H, W, C) or not out.is_contiguous():
+            raise ValueError("postprocess_u8: out must be a contiguous uint8 [B,H,W,C] tensor")
     with torch.cuda.device(x.device):
         check(load().emavfi_postprocess_u8(x.data_ptr(), out.data_ptr(), B, H, W, C, m, s, 1 if denormalize else 0, _stream()),
               "emavfi_postprocess_u8")

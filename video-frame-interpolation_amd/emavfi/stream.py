@@ -17,9 +17,12 @@ What changes is how the work is scheduled, not what is computed:
   * ToTensor/Normalize and denormalize/clip/uint8 run on the GPU (emavfi_preprocess_u8 / _postprocess_u8);
   * the ``interpolation_factor`` identical forwards of a pair are computed once and emitted that many
     times (bit-identical to recomputing them);
-  * a three-stage pipeline on three streams - upload of batch k+1, compute of batch k, download of batch
-    k-1 - through preallocated pinned host buffers; consecutive pairs share a frame, so a batch of n
-    pairs uploads n+1 frames (frame_interval 1), not 2n.
+  * uint8 frames cross PCIe inside the pre/post-processing kernels themselves: emavfi_preprocess_u8 reads the
+    batch's distinct frames straight out of a pinned host buffer and emavfi_postprocess_u8 writes the result
+    frames straight into one (zero-copy; there is no separate H2D/D2H copy to schedule - copies queued beside
+    kernels that fill every CU were seen to wait tens of milliseconds).  Two buffer slots: the host fills slot
+    k+1 and drains slot k-1 while the GPU works on slot k; consecutive pairs share a frame, so a batch of n
+    pairs reads n+1 frames (frame_interval 1), not 2n.
 ``mode="recursive"`` (opt-in, not in the reference, which has no timestep input) replaces the repeated
 identical prediction by recursive midpoints: factor 1 -> [1/2]; factor 3 -> [1/4, 1/2, 3/4]; factor 7 -> eighths.
 ``reference_quirks=False`` drops the de-normalisation of the already-[0,1] model output (appendix A of
@@ -53,8 +56,6 @@ class FrameInterpolator:
         self.device = torch.device(device) if device is not None else next(model.parameters()).device
         if self.device.type != "cuda":
             raise RuntimeError("FrameInterpolator needs the model on a ROCm device (no CPU path)")
-        self._up = torch.cuda.Stream(device=self.device)
-        self._down = torch.cuda.Stream(device=self.device)
         self._shape = None
 
     # ---- the reference's frame selection (inference.py:158-201), as (pairs, tail) over frame indices
@@ -77,7 +78,7 @@ class FrameInterpolator:
         pairs, last = self.schedule(n_frames, self.interval)
         return 0 if last is None else len(pairs) * (self.factor + 1) + 1
 
-    # ---- buffers: two slots, each (pinned uint8 in, device uint8 in, pinned uint8 out)
+    # ---- buffers: two slots of pinned host memory the kernels read / write in place
     def _alloc(self, shape):
         if self._shape == shape:
             return
@@ -88,33 +89,29 @@ class FrameInterpolator:
         for _ in range(2):
             self._slots.append({
                 "h_in": torch.empty(2 * nb, H, W, C, dtype=torch.uint8).pin_memory(),
-                "d_in": torch.empty(2 * nb, H, W, C, dtype=torch.uint8, device=self.device),
                 "h_pred": torch.empty(nb * nout, H, W, C, dtype=torch.uint8).pin_memory(),
                 "h_src": torch.empty(nb, H, W, C, dtype=torch.uint8).pin_memory(),
-                "up": torch.cuda.Event(), "consumed": torch.cuda.Event(), "done": torch.cuda.Event(),
-                "down": torch.cuda.Event(),
+                "consumed": torch.cuda.Event(), "done": torch.cuda.Event(),
             })
 
-    def _stage_upload(self, slot, frames, chunk):
-        """Copy the distinct frames of `chunk` into the slot's pinned buffer and start the H2D copy.
-        Returns (number of uploaded frames, index tensors of each pair's first / second frame)."""
+    def _stage(self, slot, frames, chunk):
+        """Copy the distinct frames of `chunk` into the slot's pinned input buffer.
+        Returns (number of staged frames, positions of each pair's first / second frame)."""
         order, pos = [], {}
         for a, b in chunk:
             for f in (a, b):
                 if f not in pos:
                     pos[f] = len(order)
                     order.append(f)
-        slot["up"].synchronize()          # the previous H2D out of this pinned buffer has finished
+        slot["consumed"].synchronize()    # the preprocess kernel of this slot's previous batch has read the buffer
+        # plain single-threaded memcpy: a torch CPU copy_ fans out over the intra-op thread pool, which on a
+        # CPU-share-limited box (more threads than granted cores) was seen to stall for 40-160 ms at a time
+        h_in = slot["h_in"].numpy()
         for i, f in enumerate(order):
-            slot["h_in"][i].copy_(torch.from_numpy(frames[f]))
-        n = len(order)
-        with torch.cuda.stream(self._up):
-            self._up.wait_event(slot["consumed"])   # the main stream is done with this slot's device buffer
-            slot["d_in"][:n].copy_(slot["h_in"][:n], non_blocking=True)
-            slot["up"].record(self._up)
+            np.copyto(h_in[i], frames[f])
         # positions stay on the host: a device index tensor would be a synchronous pageable copy on the
         # main stream, i.e. the host would block behind the compute it has just enqueued
-        return n, [pos[a] for a, _ in chunk], [pos[b] for _, b in chunk]
+        return len(order), [pos[a] for a, _ in chunk], [pos[b] for _, b in chunk]
 
     @staticmethod
     def _rows(x, idx):
@@ -159,7 +156,7 @@ class FrameInterpolator:
         npred = self.factor if self.mode == "recursive" else 1
 
         def drain(slot, chunk):
-            slot["down"].synchronize()            # this batch's download has landed in the pinned buffers
+            slot["done"].synchronize()            # this batch's frames have been written into the pinned buffers
             pred_h, src_h = slot["h_pred"].numpy(), slot["h_src"].numpy()
             for k, (a, _) in enumerate(chunk):
                 if self.mode == "recursive":
@@ -170,31 +167,22 @@ class FrameInterpolator:
                         yield pred_h[k].copy()
                 yield src_h[k].copy() if self.quirks else frames[a]
 
-        staged = self._stage_upload(self._slots[0], frames, chunks[0]) if chunks else None
+        staged = self._stage(self._slots[0], frames, chunks[0]) if chunks else None
         prev = None
         for ci, chunk in enumerate(chunks):
             slot = self._slots[ci & 1]
             nup, ia, ib = staged
             n = len(chunk)
-            main.wait_event(slot["up"])
-            x = _lib.preprocess_u8(slot["d_in"][:nup])                  # distinct frames, normalised once
+            x = _lib.preprocess_u8(slot["h_in"][:nup], device=self.device)   # distinct frames, read over PCIe, normalised once
             slot["consumed"].record(main)
             x1, x2 = self._rows(x, ia), self._rows(x, ib)
-            pred = self._predict(x1, x2)                                 # [n, k, 3, H, W]
-            pred_u8 = _lib.postprocess_u8(pred.reshape(-1, *pred.shape[2:]), denormalize=self.quirks)
-            src_u8 = _lib.postprocess_u8(x1, denormalize=True) if self.quirks else None
+            pred = self._predict(x1, x2)                                      # [n, k, 3, H, W]
+            _lib.postprocess_u8(pred.reshape(-1, *pred.shape[2:]), denormalize=self.quirks, out=slot["h_pred"][:n * npred])
+            if self.quirks:
+                _lib.postprocess_u8(x1, denormalize=True, out=slot["h_src"][:n])
             slot["done"].record(main)
-            with torch.cuda.stream(self._down):       # download behind the compute, on its own stream
-                self._down.wait_event(slot["done"])
-                slot["h_pred"][:n * npred].copy_(pred_u8, non_blocking=True)
-                if src_u8 is not None:
-                    slot["h_src"][:n].copy_(src_u8, non_blocking=True)
-                slot["down"].record(self._down)
-            pred_u8.record_stream(self._down)         # keep the device tensors alive for the copy stream
-            if src_u8 is not None:
-                src_u8.record_stream(self._down)
             if ci + 1 < len(chunks):                  # host-side staging of the next batch overlaps this batch's compute
-                staged = self._stage_upload(self._slots[(ci + 1) & 1], frames, chunks[ci + 1])
+                staged = self._stage(self._slots[(ci + 1) & 1], frames, chunks[ci + 1])
             if prev is not None:                      # emit the previous batch (its slot is reused only after this)
                 yield from drain(*prev)
             prev = (slot, chunk)
