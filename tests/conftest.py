@@ -17,6 +17,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle runs on torch's intra-op pool: cap it, a pool wider than the cores this process is granted
+    # (container CPU shares) stalls for tens of milliseconds per op
+    import torch
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
 
 
 def have_gpu():
