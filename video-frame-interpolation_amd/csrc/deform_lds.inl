@@ -18,8 +18,11 @@
 //   * every lane gathers its own MFMA operand pieces with ds_read_b128; a tap whose four corners
 //     do not all lie inside the window (|offset| > R) falls back to the global gather of
 //     deform.inl for that lane - results are identical either way;
-//   * the tap's packed weights are double buffered in LDS and DMA'd one tap ahead (one barrier
-//     per tap); the next tap's (dy, dx, mask) are fetched one tap ahead as well.
+//   * packed weights never touch LDS: every wave loads its MFMA A fragments straight from the blob (L2/L1
+//     resident) one k-group ahead, so after the window barrier the waves run decoupled (no per-tap barrier);
+//   * with DeformParams::off_w set the kernel is the whole ModulatedDeformConvPack: it first runs the pack's
+//     offset_conv on the staged window and keeps (dy, dx, mask) in registers; otherwise it reads them from
+//     p.om one tap ahead.
 #include "deform.inl"
 #include <type_traits>
 
@@ -28,9 +31,6 @@
 #endif
 #ifndef EMAVFI_DEFORM_DOT2
 #define EMAVFI_DEFORM_DOT2 1
-#endif
-#ifndef EMAVFI_DEFORM_WREG
-#define EMAVFI_DEFORM_WREG 1
 #endif
 #ifndef EMAVFI_DEFORM_SHARE_GEOMETRY
 #define EMAVFI_DEFORM_SHARE_GEOMETRY 1
@@ -48,7 +48,7 @@ template <int CK, int NF, int CS, int R, int RPW> struct DeformLdsCfg {
     static constexpr int NSLOT = TR * TC * SP;
     static constexpr int NINST = (NSLOT + 63) / 64;
     static constexpr int LDS_TILE = NINST * 1024;
-    static constexpr int LDS_BYTES = LDS_TILE + (EMAVFI_DEFORM_WREG ? 0 : 2 * WTAP);
+    static constexpr int LDS_BYTES = LDS_TILE;  // the window only: weights go L2 -> registers
     static constexpr int KB = (KG % 5 == 0) ? 5 : ((KG % 3 == 0) ? 3 : ((KG % 2 == 0) ? 2 : 1));
     static_assert(CS % 8 == 0 && CS <= CK, "staged channels: whole 16-byte slots, at most CK");
     static_assert((SP & 1) == 1, "odd slot stride keeps neighbouring-pixel gathers conflict free");
@@ -78,9 +78,6 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
     typedef __attribute__((address_space(3))) void lptr_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *lds_x = smem;
-#if !EMAVFI_DEFORM_WREG
-    char *lds_w = smem + C::LDS_TILE;
-#endif
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -109,14 +106,6 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
             __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)(lds_x + j * 1024), 16, 0, 0);
         }
     }
-#if !EMAVFI_DEFORM_WREG
-#pragma unroll
-    for (int i = 0; i < (C::WINST + C::WAVES - 1) / C::WAVES; ++i) {
-        const int j = i * C::WAVES + wave;
-        if (j < C::WINST)
-            __builtin_amdgcn_global_load_lds((gptr_t *)((const char *)p.w + j * 1024 + lane * 16), (lptr_t *)(lds_w + j * 1024), 16, 0, 0);
-    }
-#else
     // weights never touch LDS: every wave loads its MFMA A fragments straight from the packed blob (135 KiB,
     // L2/L1 resident, one k-group ahead) - no weight ring, no per-tap barrier, the waves run decoupled
     const char *wlane = (const char *)p.w + lane * 16;
@@ -124,7 +113,6 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
     static_assert((C::KG & 1) == 1, "cross-tap prefetch slot assumes an odd k-group count");
 #pragma unroll
     for (int n = 0; n < NF; ++n) wq[1][n] = *reinterpret_cast<const vec *>(wlane + n * 1024);
-#endif
 
     f32x16 acc[RPW][NF];
 #pragma unroll
@@ -203,26 +191,11 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
             }
     }
 
-#if !EMAVFI_DEFORM_WREG
-    int cur = 0;
-#endif
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
-#if !EMAVFI_DEFORM_WREG
-        if (tap < 8) {
-#pragma unroll
-            for (int i = 0; i < (C::WINST + C::WAVES - 1) / C::WAVES; ++i) {
-                const int j = i * C::WAVES + wave;
-                if (j < C::WINST)
-                    __builtin_amdgcn_global_load_lds((gptr_t *)((const char *)p.w + (size_t)(tap + 1) * C::WTAP + j * 1024 + lane * 16),
-                                                     (lptr_t *)(lds_w + (cur ^ 1) * C::WTAP + j * 1024), 16, 0, 0);
-            }
-        }
-#else
 #pragma unroll
         for (int n = 0; n < NF; ++n) wq[0][n] = wq[1][n];
         const char *wtap = wlane + (size_t)tap * C::WTAP;
-#endif
         OmTap now[RPW];
         if constexpr (FUSE_OFF) {
             // value of channel c of this lane's pixel, wherever its half-lane keeps it: a = b = reg, swap a.hi <-> b.lo
@@ -260,9 +233,6 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
                 for (int m = 0; m < RPW; ++m) nxt[m] = load_om(om[m], tap + 1, in_img[m]);
             }
         }
-#if !EMAVFI_DEFORM_WREG
-        const char *wb = lds_w + cur * C::WTAP + lane * 16;
-#endif
         // sampling geometry of this lane's RPW pixels for this tap
         SampleTap st[RPW];
         unsigned lo[RPW][4];
@@ -349,11 +319,7 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
         // software pipeline over the RPW*KG (row, k-group) steps: the four corner pieces of step s+1
         // are in flight while step s is blended and contracted
         auto gather = [&](int sidx, uint4 (&v)[4]) {
-#if EMAVFI_DEFORM_WREG
             const int kg = sidx / RPW, m = sidx - kg * RPW;   // k-group outer: one weight fragment set serves RPW rows
-#else
-            const int m = sidx / C::KG, kg = sidx - m * C::KG;
-#endif
             // slot of this lane's piece in the staged pixel; pieces past the staged channels
             // (zero weights) re-read the last slot
             const int slot = (2 * kg + h < C::SP) ? 2 * kg + h : C::SP - 1;
@@ -375,7 +341,6 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
 #pragma unroll
         for (int sidx = 0; sidx < RPW * C::KG; ++sidx) {
             if (sidx + 1 < RPW * C::KG) gather(sidx + 1, vb[(sidx + 1) & 1]);
-#if EMAVFI_DEFORM_WREG
             const int kg = sidx / RPW, m = sidx - kg * RPW;
             if (m == 0) {  // fetch the next k-group's fragments (or the next tap's first) while this one is used
                 if (kg + 1 < C::KG) {
@@ -386,21 +351,13 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
                     for (int n = 0; n < NF; ++n) wq[1][n] = *reinterpret_cast<const vec *>(wtap + C::WTAP + n * 1024);
                 }
             }
-#else
-            const int m = sidx / C::KG, kg = sidx - m * C::KG;
-#endif
             vec xf;
             if constexpr (DOT2) xf = blend4_dot2(vb[sidx & 1], bw[m]);
             else if constexpr (PKH) xf = blend4_pk(vb[sidx & 1], bh[m]);
             else xf = blend4(vb[sidx & 1], st[m].w, T{});
 #pragma unroll
             for (int n = 0; n < NF; ++n) {
-#if EMAVFI_DEFORM_WREG
                 mma_kg(acc[m][n], wq[kg & 1][n], xf);
-#else
-                const vec wv = *reinterpret_cast<const vec *>(wb + (kg * NF + n) * 1024);
-                mma_kg(acc[m][n], wv, xf);
-#endif
             }
         }
         // retire the tap's accumulator chains before the next tap's geometry code (common.h)
@@ -408,12 +365,6 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
         for (int m = 0; m < RPW; ++m)
 #pragma unroll
             for (int n = 0; n < NF; ++n) mfma_retire(acc[m][n]);
-#if !EMAVFI_DEFORM_WREG
-        if (tap < 8) {
-            __syncthreads();  // drains the next tap's weight DMA; everyone is done with buffer `cur`
-            cur ^= 1;
-        }
-#endif
     }
 
 #pragma unroll
