@@ -71,6 +71,17 @@ def test_preprocess_and_postprocess_bit_exact():
     got = lib.preprocess_u8(torch.from_numpy(u8).cuda()).cpu()
     ref = torch.stack([ref_preprocess(f) for f in u8])
     assert torch.equal(got, ref)
+    # H*W % 4 == 0 takes the 4-pixels-per-thread kernels; a pinned host buffer is read / written in place
+    v8 = g.integers(0, 256, (2, 36, 52, 3), dtype=np.uint8)
+    pin = torch.from_numpy(v8).pin_memory()
+    for src in (torch.from_numpy(v8).cuda(), pin):
+        assert torch.equal(lib.preprocess_u8(src, device="cuda:0").cpu(), torch.stack([ref_preprocess(f) for f in v8]))
+    y = torch.from_numpy(g.normal(0.4, 0.6, (2, 3, 36, 52)).astype(np.float32))
+    out_pin = torch.empty(2, 36, 52, 3, dtype=torch.uint8).pin_memory()
+    lib.postprocess_u8(y.cuda(), denormalize=True, out=out_pin)
+    torch.cuda.synchronize()
+    assert np.array_equal(out_pin.numpy(), np.stack([ref_denormalize(t) for t in y]))
+    assert np.array_equal(lib.postprocess_u8(y.cuda(), denormalize=True).cpu().numpy(), out_pin.numpy())
     x = torch.from_numpy(g.normal(0.4, 0.6, (2, 3, 19, 31)).astype(np.float32))
     x[0, 0, 0, 0], x[0, 1, 0, 0] = 5.0, -5.0
     for denorm in (True, False):
@@ -139,3 +150,22 @@ def test_recursive_mode_emits_distinct_midpoints():
     assert np.array_equal(got[3], frames[0])
     with pytest.raises(ValueError):
         FrameInterpolator(model, 2, mode="recursive")
+
+
+@pytest.mark.gpu
+def test_copy_out_false_yields_the_same_frames_as_views():
+    """copy_out=False hands out views into the pinned result buffers (valid until the generator is advanced):
+    consumed one at a time they are the frames copy_out=True returns."""
+    sd = synth.synthetic_state_dict(seed=3, mid_channels=8)
+    m = EMA_VFI(mid_channels=8, compute_dtype="fp32").cuda().eval()
+    m.load_state_dict(sd)
+    a, _ = synth.synthetic_frames_u8(5, 1, 24, 40, "natural")
+    frames = [np.roll(a[0], 2 * i, axis=1) for i in range(7)]
+    for quirks in (True, False):
+        ref = list(FrameInterpolator(m, interpolation_factor=2, batch_pairs=2, reference_quirks=quirks).run(frames))
+        n = 0
+        for k, f in enumerate(FrameInterpolator(m, interpolation_factor=2, batch_pairs=2, reference_quirks=quirks,
+                                                copy_out=False).run(frames)):
+            assert np.array_equal(f, ref[k]), (quirks, k)
+            n += 1
+        assert n == len(ref)

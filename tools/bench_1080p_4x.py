@@ -17,7 +17,7 @@ with torch.no_grad():
 print(f"forward B=4 x 1920x1080 bf16: {dt*1e3:.2f} ms = {4/dt:.1f} forward passes/s (inputs resident in HBM)")
 f1, _ = synth.synthetic_frames_u8(3, 1, 1080, 1920, "natural")
 frames = [np.roll(f1[0], 3 * i, axis=1) for i in range(33)]       # 32 pairs
-fi = FrameInterpolator(model, interpolation_factor=3, batch_pairs=4, reference_quirks=False, mode="recursive")
+fi = FrameInterpolator(model, interpolation_factor=3, batch_pairs=4, reference_quirks=False, mode="recursive", copy_out=False)
 sum(1 for _ in fi.run(frames[:9])); torch.cuda.synchronize(); t0 = time.perf_counter()
 n = sum(1 for _ in fi.run(frames)); torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print(f"4x recursive, 32 pairs -> {n} frames out in {dt*1e3:.1f} ms = {32*3/dt:.1f} interpolated frames/s, "

@@ -566,11 +566,67 @@ __global__ void postprocess_u8_kernel(const float *__restrict__ src, unsigned ch
         }
     }
 }
+// C = 3, H*W % 4 == 0: one thread = 4 consecutive pixels = 12 contiguous bytes (three dword accesses on the uint8 side,
+// three 16-byte accesses on the fp32 planes).  Same per-element arithmetic as the scalar kernels; what changes is the
+// access width - the uint8 side may be pinned host memory reached over PCIe, where single-byte accesses crawl.
+__global__ void preprocess_u8x4_kernel(const unsigned *__restrict__ src, float *__restrict__ dst, int B, size_t plane, Stats4 st)
+{
+    const size_t groups = plane / 4, total = (size_t)B * groups;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = g / groups, pix = (g - b * groups) * 4;
+        const unsigned w0 = src[g * 3], w1 = src[g * 3 + 1], w2 = src[g * 3 + 2];
+        const unsigned char by[12] = {(unsigned char)w0, (unsigned char)(w0 >> 8), (unsigned char)(w0 >> 16), (unsigned char)(w0 >> 24),
+                                      (unsigned char)w1, (unsigned char)(w1 >> 8), (unsigned char)(w1 >> 16), (unsigned char)(w1 >> 24),
+                                      (unsigned char)w2, (unsigned char)(w2 >> 8), (unsigned char)(w2 >> 16), (unsigned char)(w2 >> 24)};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            f32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v = (float)by[q * 3 + c] / 255.0f;
+                o[q] = (v - st.mean[c]) / st.stdv[c];
+            }
+            *reinterpret_cast<f32x4 *>(dst + (b * 3 + c) * plane + pix) = o;
+        }
+    }
+}
+__global__ void postprocess_u8x4_kernel(const float *__restrict__ src, unsigned *__restrict__ dst, int B, size_t plane, Stats4d st,
+                                        int denorm)
+{
+    const size_t groups = plane / 4, total = (size_t)B * groups;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = g / groups, pix = (g - b * groups) * 4;
+        unsigned char by[12];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const f32x4 x = *reinterpret_cast<const f32x4 *>(src + (b * 3 + c) * plane + pix);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                double v = (double)x[q];
+                if (denorm) v = v * st.stdv[c] + st.mean[c];
+                v = fmin(fmax(v, 0.0), 1.0) * 255.0;
+                by[q * 3 + c] = (unsigned char)v;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            dst[g * 3 + k] = (unsigned)by[4 * k] | ((unsigned)by[4 * k + 1] << 8) | ((unsigned)by[4 * k + 2] << 16) | ((unsigned)by[4 * k + 3] << 24);
+    }
+}
+static bool u8x4_ok(const void *u8, const void *f32, int H, int W, int C)
+{
+    return C == 3 && ((size_t)H * W) % 4 == 0 && ((uintptr_t)u8 & 3) == 0 && ((uintptr_t)f32 & 15) == 0;
+}
 int launch_preprocess_u8(const unsigned char *src, float *dst, int B, int H, int W, int C, const float *mean, const float *stdv,
                          hipStream_t s)
 {
     Stats4 st{};
     for (int c = 0; c < C && c < 4; ++c) { st.mean[c] = mean[c]; st.stdv[c] = stdv[c]; }
+    if (u8x4_ok(src, dst, H, W, C)) {
+        const int grid = (int)std::min<size_t>(((size_t)B * H * W / 4 + 255) / 256, 65535 * 4);
+        preprocess_u8x4_kernel<<<grid, 256, 0, s>>>((const unsigned *)src, dst, B, (size_t)H * W, st);
+        return (int)hipGetLastError();
+    }
     const int grid = (int)std::min<size_t>(((size_t)B * H * W + 255) / 256, 65535 * 4);
     preprocess_u8_kernel<<<grid, 256, 0, s>>>(src, dst, B, H, W, C, st);
     return (int)hipGetLastError();
@@ -580,6 +636,11 @@ int launch_postprocess_u8(const float *src, unsigned char *dst, int B, int H, in
 {
     Stats4d st{};
     for (int c = 0; c < C && c < 4; ++c) { st.mean[c] = mean[c]; st.stdv[c] = stdv[c]; }
+    if (u8x4_ok(dst, src, H, W, C)) {
+        const int grid4 = (int)std::min<size_t>(((size_t)B * H * W / 4 + 255) / 256, 65535 * 4);
+        postprocess_u8x4_kernel<<<grid4, 256, 0, s>>>(src, (unsigned *)dst, B, (size_t)H * W, st, denorm);
+        return (int)hipGetLastError();
+    }
     const int grid = (int)std::min<size_t>(((size_t)B * H * W + 255) / 256, 65535 * 4);
     postprocess_u8_kernel<<<grid, 256, 0, s>>>(src, dst, B, H, W, C, st, denorm);
     return (int)hipGetLastError();

@@ -40,7 +40,7 @@ from . import lib as _lib
 
 class FrameInterpolator:
     def __init__(self, model, interpolation_factor: int = 1, frame_interval: int = 1, batch_pairs: int = 8,
-                 reference_quirks: bool = True, mode: str = "reference", device=None):
+                 reference_quirks: bool = True, mode: str = "reference", device=None, copy_out: bool = True):
         if interpolation_factor < 0 or frame_interval < 1 or batch_pairs < 1:
             raise ValueError("interpolation_factor >= 0, frame_interval >= 1, batch_pairs >= 1 required")
         if mode not in ("reference", "recursive"):
@@ -57,6 +57,11 @@ class FrameInterpolator:
         if self.device.type != "cuda":
             raise RuntimeError("FrameInterpolator needs the model on a ROCm device (no CPU path)")
         self._shape = None
+        self._norm = None
+        # False: yield views into the pinned result buffers instead of fresh arrays (valid until the generator is
+        # advanced again - enough for a writer that consumes each frame at once; saves a page-faulting 2.8-6 MB
+        # allocation + copy per frame)
+        self.copy_out = bool(copy_out)
 
     # ---- the reference's frame selection (inference.py:158-201), as (pairs, tail) over frame indices
     @staticmethod
@@ -124,12 +129,15 @@ class FrameInterpolator:
     def _predict(self, x1, x2):
         """[n, k, 3, H, W] predictions per pair: k = 1 (reference mode) or `factor` recursive midpoints."""
         with torch.no_grad():
-            mid = self.model(x1, x2)
             if self.mode == "reference" or self.factor <= 1:
-                return mid.unsqueeze(1)
-            # the model consumes normalised frames and returns [0,1] images: re-normalise midpoints to recurse
-            mean = torch.tensor(_lib.IMAGENET_MEAN, device=mid.device).view(1, 3, 1, 1)
-            std = torch.tensor(_lib.IMAGENET_STD, device=mid.device).view(1, 3, 1, 1)
+                return self.model(x1, x2).unsqueeze(1)
+            # the model consumes normalised frames and returns [0,1] images: re-normalise midpoints to recurse.
+            # The constants are created once: torch.tensor(..., device=) is a synchronous pageable copy, i.e. the host
+            # would block behind the forward it has just enqueued and stop staging / draining beside it.
+            if self._norm is None:
+                self._norm = (torch.tensor(_lib.IMAGENET_MEAN, device=x1.device).view(1, 3, 1, 1),
+                              torch.tensor(_lib.IMAGENET_STD, device=x1.device).view(1, 3, 1, 1))
+            mean, std = self._norm
 
             def rec(a, b, depth):
                 m = self.model(a, b)
@@ -158,14 +166,15 @@ class FrameInterpolator:
         def drain(slot, chunk):
             slot["done"].synchronize()            # this batch's frames have been written into the pinned buffers
             pred_h, src_h = slot["h_pred"].numpy(), slot["h_src"].numpy()
+            own = (lambda v: v.copy()) if self.copy_out else (lambda v: v)
             for k, (a, _) in enumerate(chunk):
                 if self.mode == "recursive":
                     for j in range(npred):
-                        yield pred_h[k * npred + j].copy()
+                        yield own(pred_h[k * npred + j])
                 else:
                     for _ in range(self.factor):
-                        yield pred_h[k].copy()
-                yield src_h[k].copy() if self.quirks else frames[a]
+                        yield own(pred_h[k])
+                yield own(src_h[k]) if self.quirks else frames[a]
 
         staged = self._stage(self._slots[0], frames, chunks[0]) if chunks else None
         prev = None
