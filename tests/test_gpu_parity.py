@@ -388,3 +388,24 @@ def test_forward_is_capturable_in_a_hip_graph():
         replay_b = out.clone()
         eager_b = m(b1.to(DEV), b2.to(DEV))
     assert torch.equal(replay_b, eager_b)
+
+
+def test_forward_fuzz_sizes_16bit_against_fp32_path():
+    """30 seeded random shapes (1..150 per side, batch 1..3): the bf16 and fp16 paths (one-launch packs, compact warp
+    tail, persistent convs, every tile remainder) stay close to the exact-fp32 path, which the oracle tests pin."""
+    import random
+    rnd = random.Random(20260101)
+    sd = synth.synthetic_state_dict(seed=0)
+    m32, mb, mh = make_model(sd, dtype="fp32"), make_model(sd, dtype="bf16"), make_model(sd, dtype="fp16")
+    worst = {"bf16": 0.0, "fp16": 0.0}
+    for k in range(30):
+        B, H, W = rnd.randint(1, 3), rnd.randint(1, 150), rnd.randint(1, 150)
+        f1, f2 = synth.synthetic_frames(1000 + k, B, H, W, "natural" if k % 3 else "stress")
+        with torch.no_grad():
+            ref = m32(f1.to(DEV), f2.to(DEV))
+            for name, m, tol in (("bf16", mb, 0.2), ("fp16", mh, 0.04)):
+                out = m(f1.to(DEV), f2.to(DEV))
+                err = (out - ref).abs().max().item()
+                assert torch.isfinite(out).all() and err <= tol, (name, B, H, W, err)
+                worst[name] = max(worst[name], err)
+    print("worst max-abs vs fp32 path:", worst)
