@@ -31,12 +31,27 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
 REF = "/root/reference"
 sys.path.insert(0, os.path.join(ROOT, "video-frame-interpolation_amd"))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, REF)
+
+import importlib.util  # noqa: E402
 
 from emavfi import synth  # noqa: E402
 from oracle import emavfi_oracle as oracle  # noqa: E402
 
-import src.models.ema_vfi as ref  # noqa: E402  (the reference module)
+
+def load_reference_module():
+    """The reference's src/models/ema_vfi.py, loaded BY FILE PATH.  `import src.models.ema_vfi` must not be used:
+    this repository ships its own `src/` package (the drop-in import path of inference.py:4), which would win over
+    the reference's namespace package and hand back the HIP-backed class instead of the reference."""
+    path = os.path.join(REF, "src", "models", "ema_vfi.py")
+    spec = importlib.util.spec_from_file_location("ref_ema_vfi", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert os.path.realpath(mod.__file__).startswith(os.path.realpath(REF) + os.sep), mod.__file__
+    assert mod.EMA_VFI.__module__ == "ref_ema_vfi"
+    return mod
+
+
+ref = load_reference_module()
 
 
 class DeformConv2dStandIn(torch.nn.Module):
@@ -55,6 +70,7 @@ class DeformConv2dStandIn(torch.nn.Module):
 
 ref.DeformConv2d = DeformConv2dStandIn
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = HERE  # --out DIR (or make_golden.OUT = ...) writes elsewhere: tests/test_oracle_golden.py regenerates into tmp_path
 
 
 def run_reference(sd, f1, f2, mid, num_blocks=3):
@@ -110,7 +126,7 @@ def tiny(name, H, W, kind, seed):
     arrays = {"frame1": f1.numpy(), "frame2": f2.numpy()}
     arrays.update({"sd." + k: v.numpy() for k, v in sd.items()})
     arrays.update({"tap." + k: v.numpy() for k, v in taps.items()})
-    np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
     print(f"  {name}: flow range [{taps['flow'].min():.2f}, {taps['flow'].max():.2f}], "
           f"out range [{taps['out'].min():.3f}, {taps['out'].max():.3f}]")
 
@@ -137,7 +153,7 @@ def cfg1():
     arrays = {"triplet_u8": u8, "out": taps["out"].numpy(), "flow": taps["flow"].numpy().astype(np.float32)}
     for k in ("feat", "ctx", "flow", "warped", "fused_0", "fused_1", "fused_2", "out"):
         arrays["stats." + k] = stage_stats(taps[k])
-    np.savez_compressed(os.path.join(HERE, "cfg1_rubberwhale_256.npz"), **arrays)
+    np.savez_compressed(os.path.join(OUT, "cfg1_rubberwhale_256.npz"), **arrays)
 
 
 def large():
@@ -157,13 +173,19 @@ def large():
             arrays[f"{tag}.pos.{k}"] = pos
             arrays[f"{tag}.val.{k}"] = v[torch.from_numpy(pos)].numpy()
             arrays[f"{tag}.stats.{k}"] = stage_stats(taps[k])
-    np.savez_compressed(os.path.join(HERE, "large_checks.npz"), **arrays)
+    np.savez_compressed(os.path.join(OUT, "large_checks.npz"), **arrays)
 
 
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count())
-    which = sys.argv[1:] or ["tiny", "cfg1", "large"]
+    argv = sys.argv[1:]
+    if "--out" in argv:
+        i = argv.index("--out")
+        OUT = os.path.abspath(argv[i + 1])
+        os.makedirs(OUT, exist_ok=True)
+        del argv[i:i + 2]
+    which = argv or ["tiny", "cfg1", "large"]
     if "tiny" in which:
         tiny("tiny_mid8_24x40", 24, 40, "natural", 11)
         tiny("tiny_mid8_23x37", 23, 37, "stress", 12)
@@ -171,4 +193,4 @@ if __name__ == "__main__":
         cfg1()
     if "large" in which:
         large()
-    print("golden vectors written to", HERE)
+    print("golden vectors written to", OUT)

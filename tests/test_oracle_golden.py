@@ -55,3 +55,29 @@ def test_large_256_stress_samples():
     for k in STAGES:
         got = taps[k].contiguous().view(-1)[torch.from_numpy(g[f"256s.pos.{k}"])].numpy()
         assert np.abs(got - g[f"256s.val.{k}"]).max() <= 2e-5 * max(1.0, np.abs(got).max()), k
+
+
+@pytest.mark.skipif(not __import__("os").path.exists("/root/reference/src/models/ema_vfi.py"),
+                    reason="the reference only exists in the authoring container")
+def test_generator_runs_the_reference_and_reproduces_the_committed_fixture(tmp_path):
+    """tests/golden/make_golden.py at HEAD: loads the REFERENCE's ema_vfi.py by file path (not this repository's own
+    src/ package), runs its forward, and the regenerated tiny fixture equals the committed one bit for bit."""
+    import os
+    import subprocess
+    import sys
+    from conftest import GOLDEN
+    script = os.path.join(GOLDEN, "make_golden.py")
+    r = subprocess.run([sys.executable, script, "--out", str(tmp_path), "tiny"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    for name in ("tiny_mid8_24x40.npz", "tiny_mid8_23x37.npz"):
+        new, old = np.load(tmp_path / name), np.load(os.path.join(GOLDEN, name))
+        assert sorted(new.files) == sorted(old.files)
+        for k in old.files:
+            assert new[k].dtype == old[k].dtype and np.array_equal(new[k], old[k]), (name, k)
+    # the module the generator ran is the reference's file, not the drop-in class of this repository
+    probe = ("import sys; sys.argv=['x']; import importlib.util as u; s=u.spec_from_file_location('mg', r'%s'); "
+             "m=u.module_from_spec(s); s.loader.exec_module(m); print(m.ref.__file__); print(m.ref.EMA_VFI.__module__)" % script)
+    r = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    lines = r.stdout.strip().splitlines()
+    assert lines[-2].startswith("/root/reference/") and lines[-1] == "ref_ema_vfi"
