@@ -15,6 +15,11 @@ for p in (ROOT, PKG):
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+# packed-weight cache: a per-session directory, so the suite neither reads nor leaves files under ~/.cache
+import tempfile  # noqa: E402
+os.environ.setdefault("EMAVFI_CACHE_DIR", tempfile.mkdtemp(prefix="emavfi_cache_"))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # the CPU oracle runs on torch's intra-op pool: cap it, a pool wider than the cores this process is granted

@@ -251,8 +251,48 @@ def test_forward_bf16_psnr():
         out = m(f1.to(DEV), f2.to(DEV)).cpu()
     ref = oracle.forward(sd, f1, f2)
     p = psnr(out, ref)
-    print(f"bf16 vs fp32 oracle: PSNR {p:.1f} dB, max-abs {(out - ref).abs().max().item():.3e}")
-    assert p >= 30.0
+    err = (out - ref).abs().max().item()
+    print(f"bf16 vs fp32 oracle: PSNR {p:.1f} dB, max-abs {err:.3e}")
+    # measured 58.7 dB / 9e-3 with the round-1 kernels; bf16 storage (8 significant bits) through 19 layers
+    assert p >= 52.0 and err <= 2.5e-2
+
+
+@pytest.mark.parametrize("dtype,min_psnr,max_abs", [("bf16", 50.0, 3e-2), ("fp16", 65.0, 6e-3)])
+def test_forward_720p_16bit_vs_reference_run(dtype, min_psnr, max_abs):
+    """The headline arithmetic at the headline size: the 1280x720 pixels sampled from the REFERENCE's own fp32 run
+    (tests/golden/large_checks.npz) replayed in bf16 and fp16.  PSNR over the 4096 sampled output pixels and their
+    max-abs error; bounds follow from the storage precision (bf16: 8 significant bits, fp16: 11), not from the oracle."""
+    g = load_golden("large_checks.npz")
+    B, H, W, seed, kind = (int(v) for v in g["720.meta"])
+    f1, f2 = synth.synthetic_frames(seed, B, H, W, "stress" if kind else "natural")
+    m = make_model(synth.synthetic_state_dict(seed=0), dtype=dtype)
+    with torch.no_grad():
+        out, taps = m(f1.to(DEV), f2.to(DEV), return_taps=True)
+    got = out.contiguous().view(-1).cpu()[torch.from_numpy(g["720.pos.out"])]
+    ref = torch.from_numpy(g["720.val.out"])
+    p, err = psnr(got, ref), (got - ref).abs().max().item()
+    print(f"{dtype} 1280x720 vs reference-run samples: PSNR {p:.1f} dB, max-abs {err:.3e}")
+    assert p >= min_psnr and err <= max_abs
+    # intermediate stages stay within the storage type's relative precision of the reference run
+    tol = {"bf16": 4e-2, "fp16": 5e-3}[dtype]
+    for k in ("feat", "flow", "fused_2"):
+        gk = taps[k].contiguous().view(-1).cpu()[torch.from_numpy(g[f"720.pos.{k}"])]
+        rk = torch.from_numpy(g[f"720.val.{k}"])
+        assert (gk - rk).abs().max().item() <= tol * max(1.0, rk.abs().max().item()), k
+
+
+def test_batch8_720p_sample_matches_its_own_fp32_run():
+    """BASELINE configs[2] as benchmarked (B=8 x 1280x720, bf16 / fp16): one sample of the batch against the SAME sample
+    run alone in the exact-fp32 mode (which the oracle and reference-run tests pin)."""
+    sd = synth.synthetic_state_dict(seed=0)
+    f1, f2 = synth.fast_frames(5, 8, 720, 1280, device=DEV)
+    with torch.no_grad():
+        ref = make_model(sd, dtype="fp32")(f1[6:7].contiguous(), f2[6:7].contiguous())
+        for dtype, min_psnr, max_abs in (("bf16", 50.0, 4e-2), ("fp16", 65.0, 8e-3)):
+            out = make_model(sd, dtype=dtype)(f1, f2)[6:7]
+            p, err = psnr(out, ref), (out - ref).abs().max().item()
+            print(f"{dtype} B=8 720p sample 6 vs its fp32 run: PSNR {p:.1f} dB, max-abs {err:.3e}")
+            assert p >= min_psnr and err <= max_abs
 
 
 def test_forward_fp16_autocast_parity_mode():
@@ -328,36 +368,48 @@ def test_reload_state_dict_repacks():
 
 
 _FUSION_AB = r"""
-import hashlib, sys, torch
+import sys, numpy as np, torch
 sys.path[:0] = [r"%(pkg)s"]
 from emavfi import EMA_VFI, synth
-for dt in ("bf16", "fp16"):
+f1, f2 = synth.synthetic_frames(22, 2, 75, 131, "natural")
+for dt in ("bf16", "fp16", "fp32"):
     m = EMA_VFI(compute_dtype=dt).to("cuda:0").eval()
     m.load_state_dict(synth.synthetic_state_dict(seed=21, mid_channels=64))
-    f1, f2 = synth.synthetic_frames(22, 2, 75, 131, "natural")
     with torch.no_grad():
         out = m(f1.cuda(), f2.cuda()).cpu()
-    print("SHA", dt, hashlib.sha256(out.numpy().tobytes()).hexdigest())
+    np.save(r"%(out)s" + "_" + dt + ".npy", out.numpy())
 """
 
 
-def test_fused_pack_is_bit_identical_to_two_launches():
+def test_fused_pack_equals_the_two_launch_path(tmp_path):
     """bf16 / fp16 at the reference width run offset_conv inside the deform kernel (one launch per
-    ModulatedDeformConvPack).  Same arithmetic in the same order as conv3x3(EPI_OM) + deform: the frames must be
-    bit-identical to the two-launch path (EMAVFI_NO_FUSED_OFFSET=1), ragged size included."""
+    ModulatedDeformConvPack, csrc/deform_pack.inl); EMAVFI_NO_FUSED_OFFSET=1 runs conv3x3(EPI_OM) + the deform kernel
+    reading the offsets from memory.  Ragged size on purpose.
+      fp16: same arithmetic in the same order -> the frames are bit-identical.
+      bf16: the one-launch pack runs its offset_conv on the f16 image of the window (f16 MFMA on exactly converted bf16
+            values; values below 2^-14 lose trailing bits) while the stand-alone conv is a bf16 MFMA on the bf16 tensor,
+            so the offsets differ in the last bits: the two frames must agree to a fraction of a bf16 output step and
+            be equally close to the exact-fp32 frame (which the oracle tests pin)."""
     import os
     import subprocess
     import sys
     from conftest import PKG
-    code = _FUSION_AB % {"pkg": PKG}
-    shas = []
-    for extra in ({}, {"EMAVFI_NO_FUSED_OFFSET": "1"}):
+    outs = []
+    for tag, extra in (("fused", {}), ("split", {"EMAVFI_NO_FUSED_OFFSET": "1"})):
         env = dict(os.environ, **extra)
-        env.pop("EMAVFI_NO_FUSED_OFFSET", None) if not extra else None
+        if not extra:
+            env.pop("EMAVFI_NO_FUSED_OFFSET", None)
+        code = _FUSION_AB % {"pkg": PKG, "out": str(tmp_path / tag)}
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stderr[-2000:]
-        shas.append([l for l in r.stdout.splitlines() if l.startswith("SHA")])
-    assert len(shas[0]) == 2 and shas[0] == shas[1]
+        outs.append({dt: torch.from_numpy(np.load(str(tmp_path / tag) + f"_{dt}.npy")) for dt in ("bf16", "fp16", "fp32")})
+    fused, split = outs
+    assert torch.equal(fused["fp32"], split["fp32"])          # fp32 never fuses: identical runs
+    assert torch.equal(fused["fp16"], split["fp16"])
+    d = (fused["bf16"] - split["bf16"]).abs().max().item()
+    pf, ps = psnr(fused["bf16"], fused["fp32"]), psnr(split["bf16"], fused["fp32"])
+    print(f"bf16 fused vs two launches: max-abs {d:.3e}; PSNR vs fp32 frame: fused {pf:.2f} dB, two launches {ps:.2f} dB")
+    assert d <= 4e-3 and pf >= 52.0 and pf >= ps - 0.5
 
 
 def test_forward_is_capturable_in_a_hip_graph():

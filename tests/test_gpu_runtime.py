@@ -1,0 +1,207 @@
+"""Host-side contracts of the drop-in boundary on a real GPU (SURVEY.md section 8b "re-entrant ... safe for one
+process per GPU", 8e "one weight broadcast, shards equal the single-GPU result"): per-stream workspaces, captured
+graphs surviving workspace growth, installed (broadcast) weight blobs, and a two-process shard run."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import PKG, ROOT
+from emavfi import EMA_VFI, lib, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def make_model(sd, mid=64, dtype="fp32"):
+    m = EMA_VFI(mid_channels=mid, compute_dtype=dtype).to(DEV).eval()
+    m.load_state_dict(sd, strict=True)
+    return m
+
+
+def test_captured_graph_survives_workspace_growth():
+    """A hipGraph bakes the workspace address in.  Growing the workspace of the same stream afterwards must not free
+    the captured buffer: the replay still has to produce the eager result while other tensors churn the allocator."""
+    lib.release_workspaces()
+    sd = synth.synthetic_state_dict(seed=0)
+    m = make_model(sd, dtype="bf16")
+    a1, a2 = (t.to(DEV) for t in synth.synthetic_frames(41, 1, 128, 160, "natural"))
+    big1, big2 = (t.to(DEV) for t in synth.synthetic_frames(42, 3, 200, 264, "natural"))
+    side = torch.cuda.Stream()
+    with torch.no_grad():
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                eager_small = m(a1, a2).clone()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            out = m(a1, a2)
+        key = (0, side.cuda_stream)
+        captured_ptr = lib._ws_cache[key].data_ptr()
+        # same stream, larger problem: the cached workspace must grow
+        with torch.cuda.stream(side):
+            eager_big = m(big1, big2).clone()
+        side.synchronize()
+        assert lib._ws_cache[key].data_ptr() != captured_ptr, "the larger forward was expected to re-allocate"
+        assert any(b.data_ptr() == captured_ptr for b in lib._ws_graph_held), "captured workspace must be kept alive"
+        # churn: anything the allocator hands out now must not alias the captured workspace
+        junk = [torch.full((64 << 20,), 1.0e30, device=DEV) for _ in range(4)]
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager_small)
+        with torch.cuda.stream(side):
+            again_big = m(big1, big2)
+        side.synchronize()
+        assert torch.equal(again_big, eager_big)
+        del junk
+    del graph
+    lib.release_workspaces()
+
+
+def test_two_streams_run_forwards_concurrently():
+    """Two streams enqueue forwards back to back without host synchronisation; each stream has its own workspace, so
+    the interleaved results equal the serial ones bit for bit (a shared scratch buffer would be a data race)."""
+    lib.release_workspaces()
+    sd = synth.synthetic_state_dict(seed=0)
+    m = make_model(sd, dtype="bf16")
+    xa = [t.to(DEV) for t in synth.synthetic_frames(51, 2, 192, 256, "natural")]
+    xb = [t.to(DEV) for t in synth.synthetic_frames(52, 1, 360, 640, "stress")]
+    with torch.no_grad():
+        ref_a, ref_b = m(*xa).clone(), m(*xb).clone()
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        outs_a, outs_b = [], []
+        for _ in range(6):
+            with torch.cuda.stream(s1):
+                outs_a.append(m(*xa))
+            with torch.cuda.stream(s2):
+                outs_b.append(m(*xb))
+        torch.cuda.synchronize()
+    assert len({k for k in lib._ws_cache if k[1] in (s1.cuda_stream, s2.cuda_stream)}) == 2
+    for o in outs_a:
+        assert torch.equal(o, ref_a)
+    for o in outs_b:
+        assert torch.equal(o, ref_b)
+    lib.release_workspaces()
+
+
+def test_installed_blob_is_pinned_until_a_state_dict_is_loaded():
+    """share_model_weights() installs rank 0's packed blob on the other ranks, whose own nn.Parameters stay random:
+    the blob must survive .to() / dtype-preserving moves, an in-place edit must raise (it cannot be honoured), and
+    load_state_dict() makes the parameters authoritative again."""
+    sd = synth.synthetic_state_dict(seed=3, mid_channels=8)
+    sd2 = synth.synthetic_state_dict(seed=4, mid_channels=8)
+    f1, f2 = (t.to(DEV) for t in synth.synthetic_frames(9, 1, 24, 40, "natural"))
+    src = make_model(sd, mid=8, dtype="bf16")
+    with torch.no_grad():
+        want = src(f1, f2)
+        blob = src.packed_weights(lib.BF16, torch.device(DEV)).clone()
+        other = EMA_VFI(mid_channels=8, compute_dtype="bf16").to(DEV).eval()     # random parameters, never loaded
+        other.load_packed_weights("bf16", blob)
+        assert torch.equal(other(f1, f2), want)
+        other.to(DEV)
+        other.float()
+        assert torch.equal(other(f1, f2), want)                                 # still the installed blob
+        with pytest.raises(RuntimeError, match="no packed weights"):
+            other.compute_dtype = "fp32"
+            other(f1, f2)
+        other.compute_dtype = "bf16"
+        other.feat_ext_conv1[0].bias.data.add_(1.0)
+        with pytest.raises(RuntimeError, match="modified in place"):
+            other(f1, f2)
+        other.load_state_dict(sd2)
+        got2 = other(f1, f2)
+        assert torch.equal(got2, make_model(sd2, mid=8, dtype="bf16")(f1, f2))
+        with pytest.raises(ValueError, match="uint8 blob"):
+            other.load_packed_weights("bf16", blob[:-16])
+
+
+_RANK_SCRIPT = r"""
+import os, sys
+sys.path[:0] = [r"%(pkg)s"]
+import numpy as np, torch
+from emavfi import EMA_VFI, synth, dist as vdist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+vdist.init("gloo", dev)
+f1, f2 = synth.synthetic_frames(77, %(n)d, %(h)d, %(w)d, "natural")
+for dt in ("fp32", "bf16"):
+    model = EMA_VFI(compute_dtype=dt).to(dev).eval()      # every rank starts from its own random init
+    if rank == 0:
+        model.load_state_dict(synth.synthetic_state_dict(seed=0))
+    vdist.share_model_weights(model, dt, dev)             # the path's one collective
+    lo, hi = vdist.shard_range(%(n)d, rank, world)
+    with torch.no_grad():
+        out = model(f1[lo:hi].to(dev), f2[lo:hi].to(dev)).cpu().numpy()
+    np.save(os.path.join(r"%(out)s", f"shard_{dt}_{rank}.npy"), out)
+    np.save(os.path.join(r"%(out)s", f"range_{dt}_{rank}.npy"), np.array([lo, hi]))
+vdist.barrier()
+torch.distributed.destroy_process_group()
+"""
+
+
+def test_two_rank_shards_equal_the_single_process_forward(tmp_path):
+    """BASELINE configs[3] logic on one GPU: two fresh processes (gloo, both on cuda:0), rank 0 packs and broadcasts the
+    blob, rank 1 runs its shard_range slice from the RECEIVED blob; the concatenated shards equal a single-process
+    forward of all pairs bit for bit.  (RCCL itself needs one device per rank; the driver's multi-GPU run covers it.)"""
+    n, h, w = 5, 96, 160
+    code = _RANK_SCRIPT % {"pkg": PKG, "n": n, "h": h, "w": w, "out": str(tmp_path)}
+    port = 29500 + (os.getpid() % 400)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        try:
+            so, se = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, se[-3000:]
+    f1, f2 = synth.synthetic_frames(77, n, h, w, "natural")
+    sd = synth.synthetic_state_dict(seed=0)
+    for dt in ("fp32", "bf16"):
+        with torch.no_grad():
+            whole = make_model(sd, dtype=dt)(f1.to(DEV), f2.to(DEV)).cpu().numpy()
+        ranges = [tuple(np.load(tmp_path / f"range_{dt}_{r}.npy")) for r in range(2)]
+        assert ranges == [(0, 3), (3, 5)]
+        got = np.concatenate([np.load(tmp_path / f"shard_{dt}_{r}.npy") for r in range(2)])
+        assert got.shape == whole.shape and np.array_equal(got, whole), dt
+
+
+def test_packed_blob_is_cached_on_disk_by_content(tmp_path, monkeypatch):
+    """the packed blob is cached keyed by a content hash of the state_dict + dtype + library build; a
+    second construction with the same weights performs NO emavfi_pack_weights call, other weights or another dtype do."""
+    monkeypatch.setenv("EMAVFI_CACHE_DIR", str(tmp_path))
+    monkeypatch.setenv("EMAVFI_CACHE", "1")
+    L = lib.load()
+    calls = []
+    real = L.emavfi_pack_weights
+
+    def counting(*a):
+        calls.append(1)
+        return real(*a)
+
+    monkeypatch.setattr(L, "emavfi_pack_weights", counting)
+    sd = synth.synthetic_state_dict(seed=5, mid_channels=8)
+    f1, f2 = (t.to(DEV) for t in synth.synthetic_frames(9, 1, 24, 40, "natural"))
+    with torch.no_grad():
+        a = make_model(sd, mid=8, dtype="bf16")(f1, f2)
+        assert len(calls) == 1 and len(list(tmp_path.glob("packed_*.bin"))) == 1
+        b = make_model(sd, mid=8, dtype="bf16")(f1, f2)               # fresh module, same content: cache hit
+        assert len(calls) == 1 and torch.equal(a, b)
+        make_model(sd, mid=8, dtype="fp32")(f1, f2)                   # another dtype: its own entry
+        assert len(calls) == 2
+        make_model(synth.synthetic_state_dict(seed=6, mid_channels=8), mid=8, dtype="bf16")(f1, f2)   # other weights
+        assert len(calls) == 3 and len(list(tmp_path.glob("packed_*.bin"))) == 3
+        monkeypatch.setenv("EMAVFI_CACHE", "0")                      # disabled: packs again, writes nothing
+        make_model(sd, mid=8, dtype="bf16")(f1, f2)
+        assert len(calls) == 4 and len(list(tmp_path.glob("packed_*.bin"))) == 3

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Diagnostic: where a fused deformable-conv pack spends its wave cycles (in-kernel s_memtime stamps).
+Needs the stamped build:  make -C video-frame-interpolation_amd/csrc TAG=_stamps EXTRA=-DEMAVFI_DEFORM_STAMPS=1
+  EMAVFI_LIB=video-frame-interpolation_amd/emavfi/lib/libemavfi_stamps.so python tools/deform_stamps.py [bf16|fp16]
+Shares only - a stamped build's run time is not the product's (its fences forbid overlaps)."""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "video-frame-interpolation_amd"))
+import torch  # noqa: E402
+from emavfi import EMA_VFI, lib, synth  # noqa: E402
+
+dtype = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+import numpy as np  # noqa: E402
+
+ROWS = 16384
+L = lib.load()
+fn = L.emavfi_debug_deform_stamps
+fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+m = EMA_VFI(compute_dtype=dtype).to("cuda:0").eval()
+m.load_state_dict(synth.synthetic_state_dict(seed=0))
+f1, f2 = synth.fast_frames(100, 8, 720, 1280, device="cuda:0")
+buf = np.zeros((ROWS, 8), dtype=np.uint64)
+with torch.no_grad():
+    for _ in range(2):
+        m(f1, f2)
+    assert fn(None, ROWS, 1) == 0
+    m(f1, f2)   # each pack overwrites the rows: what is read back is the LAST pack of this forward
+assert fn(buf.ctypes.data, ROWS, 0) == 0
+v = buf[buf[:, 6] == 1].astype(np.float64)
+names = ["prologue (window DMA + barrier)", "offset_conv (90 MFMAs/wave)", "pick + geometry (9 taps)",
+         "gather + blend + MFMA steps (9 taps)", "epilogue stores (drained)", "total"]
+print(f"{dtype}: {len(v)} waves sampled (median cycles per wave and tile)")
+tot = np.median(v[:, 5])
+for i, n in enumerate(names):
+    print(f"  {n:42s} {np.median(v[:, i]):10.0f}  {100.0 * np.median(v[:, i]) / tot:5.1f} %   (p10 {np.percentile(v[:, i], 10):.0f}, p90 {np.percentile(v[:, i], 90):.0f})")
+print(f"  per tap: geometry {np.median(v[:, 2]) / 9:.0f}, steps {np.median(v[:, 3]) / 9:.0f} cycles")

@@ -178,7 +178,13 @@ struct DeformParams {
     int cstore;
     int cin_real;  // real (unpadded) input channels
     int ck, nf;    // host-side template selectors
+    unsigned long long *stamps;  // diagnostic build (-DEMAVFI_DEFORM_STAMPS=1) only, else null
 };
+#define DEFORM_STAMP_STRIDE 14
+#define DEFORM_STAMP_ROWS 16384
+
+// compute units of the CURRENT device (persistent kernels size their grid by it); cached per device, thread-safe
+int device_cu_count();
 
 int launch_conv3x3_f32(const ConvParams &p, hipStream_t s);
 int launch_conv3x3_bf16(const ConvParams &p, hipStream_t s);

@@ -22,6 +22,7 @@
 // LDS pixel stride is an odd number of 16-byte slots (LdsPix), so the ds_read_b128 operand
 // fetches of 32 consecutive pixels are bank-conflict free for stride 1.
 #include "common.h"
+#include <mutex>
 
 template <typename T, int CK, int NF, int S> struct ConvCfg {
     using D = DT<T>;
@@ -222,13 +223,13 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvParams p)
 template <typename T, int CK, int NF, int S> static int launch_conv_inst(const ConvParams &p, hipStream_t s)
 {
     using C = ConvCfg<T, CK, NF, S>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_kernel<T, CK, NF, S>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    static std::once_flag once;  // the library is re-entrant: launchers may be called from several threads
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_kernel<T, CK, NF, S>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    });
+    if (attr_err != hipSuccess) return (int)attr_err;
     dim3 grid((p.Wout + 31) / 32, (p.Hout + C::TH - 1) / C::TH, p.B * p.npass);
     conv3x3_kernel<T, CK, NF, S><<<grid, 256, C::LDS_BYTES, s>>>(p);
     return (int)hipGetLastError();
@@ -331,20 +332,25 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_persist_kernel(const ConvP
 template <typename T, int CK, int NF, int WAVES> static int launch_conv_persist(const ConvParams &p, hipStream_t s)
 {
     using C = ConvPersistCfg<T, CK, NF, WAVES>;
+    static std::once_flag once;
     static int wg_per_cu = 0;  // resident workgroups per CU: registers and LDS both limit it
-    if (!wg_per_cu) {
+    static hipError_t init_err = hipSuccess;
+    std::call_once(once, [] {
         const void *fn = reinterpret_cast<const void *>(&conv3x3_persist_kernel<T, CK, NF, WAVES>);
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
+        init_err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (init_err != hipSuccess) return;
         int n = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3x3_persist_kernel<T, CK, NF, WAVES>, 64 * WAVES, C::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
+        init_err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3x3_persist_kernel<T, CK, NF, WAVES>, 64 * WAVES, C::LDS_BYTES);
+        if (init_err != hipSuccess) return;
         // a persistent grid must not exceed what is resident: queued workgroups would only start
         // when others have finished their whole tile list
         wg_per_cu = n < 1 ? 1 : (n > C::WG_PER_CU ? C::WG_PER_CU : n);
-    }
+    });
+    if (init_err != hipSuccess) return (int)init_err;
+    const int ncu = device_cu_count();
+    if (ncu <= 0) return (int)hipErrorInvalidDevice;
     const int ntiles = ((p.Wout + 31) / 32) * ((p.Hout + C::TH - 1) / C::TH) * p.B;
-    const int resident = 256 * wg_per_cu;  // MI355X: 256 CUs
+    const int resident = ncu * wg_per_cu;
     conv3x3_persist_kernel<T, CK, NF, WAVES><<<ntiles < resident ? ntiles : resident, 64 * WAVES, C::LDS_BYTES, s>>>(p);
     return (int)hipGetLastError();
 }

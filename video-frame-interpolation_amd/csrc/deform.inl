@@ -24,6 +24,7 @@
 // The gather reads global memory through L1/L2 (each input pixel is re-read by ~36 corner
 // fetches of neighbouring pixels / taps; HBM sees it about once).
 #include "common.h"
+#include <mutex>
 
 template <typename T, int CK, int NF> struct DeformCfg {
     using D = DT<T>;
@@ -117,13 +118,17 @@ __device__ __forceinline__ BlendW blend_weights_bf16(const float (&w)[4])
     }
     return r;
 }
+// NQ = dwords of the piece that are blended (channels 2*NQ.. of the result are 0)
+template <int NQ = 4>
 __device__ __forceinline__ bf16x8 blend4_dot2(const uint4 (&v)[4], const BlendW &w)
 {
     float a[8];
+#pragma unroll
+    for (int j = 2 * NQ; j < 8; ++j) a[j] = 0.0f;
     {   // first corner: the three-source form with a literal 0 addend (no accumulator to clear first)
         const unsigned d[4] = {v[0].x, v[0].y, v[0].z, v[0].w};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             asm("v_dot2_f32_bf16 %0, %1, %2, 0" : "=v"(a[2 * q]) : "v"(d[q]), "v"(w.lo[0]));
             asm("v_dot2_f32_bf16 %0, %1, %2, 0" : "=v"(a[2 * q + 1]) : "v"(d[q]), "v"(w.hi[0]));
         }
@@ -132,7 +137,7 @@ __device__ __forceinline__ bf16x8 blend4_dot2(const uint4 (&v)[4], const BlendW 
     for (int c = 1; c < 4; ++c) {
         const unsigned d[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             a[2 * q] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, d[q]), __builtin_bit_cast(bf16x2_t, w.lo[c]), a[2 * q], false);
             a[2 * q + 1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, d[q]), __builtin_bit_cast(bf16x2_t, w.hi[c]), a[2 * q + 1], false);
         }
@@ -152,19 +157,22 @@ __device__ __forceinline__ BlendWh blend_weights_f16(const float (&w)[4])
     for (int c = 0; c < 4; ++c) r.pk[c] = f16x2_t{(half_t)w[c], (half_t)w[c]};
     return r;
 }
+template <int NQ = 4>
 __device__ __forceinline__ f16x8 blend4_pk(const uint4 (&v)[4], const BlendWh &w)
 {
     f16x2_t a[4];
+#pragma unroll
+    for (int q = NQ; q < 4; ++q) a[q] = f16x2_t{(half_t)0.0f, (half_t)0.0f};
     {
         const unsigned d[4] = {v[0].x, v[0].y, v[0].z, v[0].w};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) a[q] = __builtin_bit_cast(f16x2_t, d[q]) * w.pk[0];
+        for (int q = 0; q < NQ; ++q) a[q] = __builtin_bit_cast(f16x2_t, d[q]) * w.pk[0];
     }
 #pragma unroll
     for (int c = 1; c < 4; ++c) {
         const unsigned d[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) a[q] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d[q]), w.pk[c], a[q]);
+        for (int q = 0; q < NQ; ++q) a[q] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d[q]), w.pk[c], a[q]);
     }
     return f16x8{a[0][0], a[0][1], a[1][0], a[1][1], a[2][0], a[2][1], a[3][0], a[3][1]};
 }
@@ -312,13 +320,13 @@ __global__ __launch_bounds__(256, 2) void deform_kernel(const DeformParams p)
 template <typename T, int CK, int NF> static int launch_deform_inst(const DeformParams &p, hipStream_t s)
 {
     using C = DeformCfg<T, CK, NF>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&deform_kernel<T, CK, NF>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&deform_kernel<T, CK, NF>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    });
+    if (attr_err != hipSuccess) return (int)attr_err;
     dim3 grid((p.W + 31) / 32, (p.H + 7) / 8, p.B);
     deform_kernel<T, CK, NF><<<grid, 256, C::LDS_BYTES, s>>>(p);
     return (int)hipGetLastError();

@@ -1,5 +1,5 @@
 #include <cstdlib>
-#include "deform_lds.inl"
+#include "deform_pack.inl"
 
 bool deform16_can_fuse_offset_conv(int ck, int nf, int cin_real, int off_ck, int off_nf)
 {
@@ -8,3 +8,4 @@ bool deform16_can_fuse_offset_conv(int ck, int nf, int cin_real, int off_ck, int
 }
 
 int launch_deform_bf16(const DeformParams &p, hipStream_t s) { return launch_deform16<bf16_t>(p, s); }
+

@@ -24,6 +24,7 @@
 //     offset_conv on the staged window and keeps (dy, dx, mask) in registers; otherwise it reads them from
 //     p.om one tap ahead.
 #include "deform.inl"
+#include <mutex>
 #include <type_traits>
 
 #ifndef EMAVFI_DEFORM_PKF16
@@ -34,6 +35,13 @@
 #endif
 #ifndef EMAVFI_DEFORM_SHARE_GEOMETRY
 #define EMAVFI_DEFORM_SHARE_GEOMETRY 1
+#endif
+// A/B switches (timing experiments; the defaults are the product)
+#ifndef EMAVFI_DEFORM_XCD_ORDER
+#define EMAVFI_DEFORM_XCD_ORDER 1   // 0: plain row-major tile order
+#endif
+#ifndef EMAVFI_DEFORM_TRIM_TAIL
+#define EMAVFI_DEFORM_TRIM_TAIL 1   // 0: blend all four dwords of the last k-group
 #endif
 
 template <int CK, int NF, int CS, int R, int RPW> struct DeformLdsCfg {
@@ -57,6 +65,42 @@ template <int CK, int NF, int CS, int R, int RPW> struct DeformLdsCfg {
 
 struct OmTap { float dy, dx, mk; };
 
+// Diagnostic build only (-DEMAVFI_DEFORM_STAMPS=1; cdna_hip_programming.md section 7, in-kernel stamps): s_memtime at the
+// seams of the kernel, per-wave segment sums written to DeformParams::stamps (a buffer the diagnostic build of
+// emavfi_api.hip allocates), read back with emavfi_debug_deform_stamps().  Never part of the shipped library: no stamp
+// executes there and the symbol does not exist.
+#ifndef EMAVFI_DEFORM_STAMPS
+#define EMAVFI_DEFORM_STAMPS 0
+#endif
+#if EMAVFI_DEFORM_STAMPS
+__device__ __forceinline__ unsigned long long deform_stamp()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define DEFORM_STAMP(var) const unsigned long long var = deform_stamp()
+#else
+#define DEFORM_STAMP(var)
+#endif
+
+// LDS reads through explicit address-space-3 pointers (ds_read_b128 / ds_read_b64, never flat_load)
+typedef __attribute__((address_space(3))) const char lds_cchar_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+__device__ __forceinline__ uint4 lds_read16(lds_cchar_t *p)
+{
+    const u32x4_t t = *reinterpret_cast<__attribute__((address_space(3))) const u32x4_t *>(p);
+    return make_uint4(t[0], t[1], t[2], t[3]);
+}
+__device__ __forceinline__ uint2 lds_read8(lds_cchar_t *p)
+{
+    const u32x2_t t = *reinterpret_cast<__attribute__((address_space(3))) const u32x2_t *>(p);
+    return make_uint2(t[0], t[1]);
+}
+
 __device__ __forceinline__ OmTap load_om(const float *__restrict__ om, int tap, bool in_image)
 {
     OmTap t;
@@ -64,7 +108,10 @@ __device__ __forceinline__ OmTap load_om(const float *__restrict__ om, int tap, 
     return t;
 }
 
-template <typename T, int CK, int NF, int CS, int R, int RPW, bool FUSE_OFF>
+// TQ = dwords of the LAST k-group's 16-byte piece that can hold real channels (cin_real <= 64 + 2 * TQ): the reference
+// width (67) has 3 real channels there, so only 2 of the piece's 4 dwords are gathered and blended (8-byte LDS reads,
+// half the blend instructions of that k-group); the other channels of the k-group only ever meet zero weights.
+template <typename T, int CK, int NF, int CS, int R, int RPW, bool FUSE_OFF, int TQ>
 __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const DeformParams p)
 {
     using C = DeformLdsCfg<CK, NF, CS, R, RPW>;
@@ -76,21 +123,49 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
     static_assert(sizeof(T) == 2, "the LDS-window kernel is for the 16-bit dtypes");
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
+    typedef __attribute__((address_space(3))) const char lchar_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *lds_x = smem;
+    // LDS reads go through an explicit address-space-3 pointer: with a generic pointer hipcc merged the window read and
+    // the global fallback of a tap's first gather into flat_load (slower, and it counts on both vmcnt and lgkmcnt)
+    lchar_t *lds_r = (lchar_t *)smem;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z;
     const int H = p.H, W = p.W;
+    // XCD-aware tile order (placement only affects speed).  Workgroups are dealt round-robin over the 8 XCDs, so
+    // blockIdx % 8 labels an XCD group; each group gets a contiguous run of tiles, and inside an image tiles are walked
+    // in strips of SROWS tile rows, column by column: the ~32 tiles an XCD has in flight form a compact 2-D block whose
+    // window halos (1.75x the tile on its own) are re-read from that XCD's L2 instead of from HBM.
+    const int ntx = (W + C::TCOLS - 1) / C::TCOLS, nty = (H + C::TROWS - 1) / C::TROWS, nt = ntx * nty;
+    int tile_x, tile_y, b;
+    if (EMAVFI_DEFORM_XCD_ORDER) {
+        constexpr int SROWS = 4;
+        const int nwg = gridDim.x, grp = blockIdx.x & 7, kk = blockIdx.x >> 3, qq = nwg >> 3, rr = nwg & 7;
+        const int wg = (grp < rr ? grp * (qq + 1) : rr * (qq + 1) + (grp - rr) * qq) + kk;
+        b = wg / nt;
+        const int t = wg - b * nt, strip = t / (SROWS * ntx), tt = t - strip * SROWS * ntx;
+        const int rows = min(SROWS, nty - strip * SROWS);
+        tile_x = tt / rows;
+        tile_y = strip * SROWS + (tt - tile_x * rows);
+    } else {
+        b = blockIdx.x / nt;
+        const int t = blockIdx.x - b * nt;
+        tile_y = t / ntx;
+        tile_x = t - tile_y * ntx;
+    }
     const unsigned ps_bytes = (unsigned)p.x_ps * 2u;
-    const int ty0 = blockIdx.y * C::TROWS - 1 - R, tx0 = blockIdx.x * C::TCOLS - 1 - R;
+    const int ty0 = tile_y * C::TROWS - 1 - R, tx0 = tile_x * C::TCOLS - 1 - R;
     const char *gplane = (const char *)p.x + (size_t)b * H * W * ps_bytes;
     const char *zeros = (const char *)p.zeros;
     const unsigned tail_bytes = (unsigned)p.tail_ps * 2u;
     const char *tplane = p.x_tail ? (const char *)p.x_tail + (size_t)b * H * W * tail_bytes : nullptr;
     static_assert(CS == 72, "the split-input path assumes the tail starts at channel 64 = the last staged slot");
 
+    DEFORM_STAMP(ts_begin);
+#if EMAVFI_DEFORM_STAMPS
+    unsigned long long sum_geom = 0, sum_steps = 0;
+#endif
     // ---- DMA the input window (zero outside the image) and tap 0's weights ----
 #pragma unroll
     for (int i = 0; i < (C::NINST + C::WAVES - 1) / C::WAVES; ++i) {
@@ -122,14 +197,14 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[m][n][i] = p.bias[n * 32 + acc_channel(i, h)];
 
-    const int px_x = blockIdx.x * C::TCOLS + r;
+    const int px_x = tile_x * C::TCOLS + r;
     int py_y[RPW];
     bool in_img[RPW];
     const float *om[RPW];
     OmTap nxt[RPW];
 #pragma unroll
     for (int m = 0; m < RPW; ++m) {
-        py_y[m] = blockIdx.y * C::TROWS + wave * RPW + m;
+        py_y[m] = tile_y * C::TROWS + wave * RPW + m;
         in_img[m] = py_y[m] < H && px_x < W;
         om[m] = p.om + (((size_t)b * H + (in_img[m] ? py_y[m] : 0)) * W + (in_img[m] ? px_x : 0)) * 32;
         if (!FUSE_OFF) nxt[m] = load_om(om[m], 0, in_img[m]);
@@ -145,6 +220,7 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
             for (int kg = 0; kg < C::KG; ++kg) ow[t][kg] = *reinterpret_cast<const vec *>(owl + (t * C::KG + kg) * 1024);
     }
     __syncthreads();  // hipcc drains the DMA (vmcnt(0)) ahead of the barrier
+    DEFORM_STAMP(ts_window);
 
     // fused: this lane's half of its pixels' (dy, dx, mask) values stays in registers in accumulator layout:
     // channel c sits in half-lane (c >> 2) & 1, register (c & 3) + 4 * (c >> 3)
@@ -169,11 +245,11 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
             const int i = tap / 3, j = tap - 3 * i;
 #pragma unroll
             for (int m = 0; m < RPW; ++m) {
-                const char *xp = lds_x + (((wave * RPW + m) + i + R) * C::TC + (r + j + R)) * C::PSB;
+                lchar_t *xp = lds_r + (((wave * RPW + m) + i + R) * C::TC + (r + j + R)) * C::PSB;
 #pragma unroll
                 for (int kg = 0; kg < C::KG; ++kg) {
                     const int slot = (2 * kg + h < C::SP) ? 2 * kg + h : C::SP - 1;
-                    const vec xv = *reinterpret_cast<const vec *>(xp + slot * 16);
+                    const vec xv = *reinterpret_cast<__attribute__((address_space(3))) const vec *>(xp + slot * 16);
                     mma_kg(oacc[m], ow[tap % 3][kg], xv);
                 }
             }
@@ -191,8 +267,10 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
             }
     }
 
+    DEFORM_STAMP(ts_offconv);
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
+        DEFORM_STAMP(ts_tap);
 #pragma unroll
         for (int n = 0; n < NF; ++n) wq[0][n] = wq[1][n];
         const char *wtap = wlane + (size_t)tap * C::WTAP;
@@ -323,19 +401,31 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
             // slot of this lane's piece in the staged pixel; pieces past the staged channels
             // (zero weights) re-read the last slot
             const int slot = (2 * kg + h < C::SP) ? 2 * kg + h : C::SP - 1;
+            const bool tail = kg == C::KG - 1;  // compile-time after unrolling
+            if (tail && TQ == 2) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const uint4 *>(lds_x + lo[m][c] + (unsigned)(slot * 16));
+                for (int c = 0; c < 4; ++c) {
+                    const uint2 t2 = lds_read8(lds_r + lo[m][c] + (unsigned)(slot * 16));
+                    v[c] = make_uint4(t2.x, t2.y, 0u, 0u);
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = lds_read16(lds_r + lo[m][c] + (unsigned)(slot * 16));
+            }
             if (!all_inside[m]) {   // wave-uniform: some lane reaches past the window
                 if (!inside[m]) {   // one divergent region per step
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const char *src = gx + st[m].o[c] + (unsigned)(kg * 32);
-                        if (kg == C::KG - 1 && tplane) src = h ? zeros : tplane + (st[m].o[c] / ps_bytes) * tail_bytes;  // tail = 8 channels
+                        // last k-group: channels 64..71 come from the compact tail when the input is split; the h = 1
+                        // half (channels 72..79: zero weights) reads the zero page - those channels of x may be unwritten
+                        if (tail) src = h ? zeros : (tplane ? tplane + (st[m].o[c] / ps_bytes) * tail_bytes : src);
                         v[c] = *reinterpret_cast<const uint4 *>(src);
                     }
                 }
             }
         };
+        DEFORM_STAMP(ts_geom);
         uint4 vb[2][4];
         gather(0, vb[0]);
 #pragma unroll
@@ -352,9 +442,15 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
                 }
             }
             vec xf;
-            if constexpr (DOT2) xf = blend4_dot2(vb[sidx & 1], bw[m]);
-            else if constexpr (PKH) xf = blend4_pk(vb[sidx & 1], bh[m]);
-            else xf = blend4(vb[sidx & 1], st[m].w, T{});
+            if (kg == C::KG - 1 && TQ == 2) {  // folded at compile time
+                if constexpr (DOT2) xf = blend4_dot2<2>(vb[sidx & 1], bw[m]);
+                else if constexpr (PKH) xf = blend4_pk<2>(vb[sidx & 1], bh[m]);
+                else xf = blend4(vb[sidx & 1], st[m].w, T{});
+            } else {
+                if constexpr (DOT2) xf = blend4_dot2<4>(vb[sidx & 1], bw[m]);
+                else if constexpr (PKH) xf = blend4_pk<4>(vb[sidx & 1], bh[m]);
+                else xf = blend4(vb[sidx & 1], st[m].w, T{});
+            }
 #pragma unroll
             for (int n = 0; n < NF; ++n) {
                 mma_kg(acc[m][n], wq[kg & 1][n], xf);
@@ -365,7 +461,13 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
         for (int m = 0; m < RPW; ++m)
 #pragma unroll
             for (int n = 0; n < NF; ++n) mfma_retire(acc[m][n]);
+#if EMAVFI_DEFORM_STAMPS
+        DEFORM_STAMP(ts_end);
+        sum_geom += ts_geom - ts_tap;
+        sum_steps += ts_end - ts_geom;
+#endif
     }
+    DEFORM_STAMP(ts_loop);
 
 #pragma unroll
     for (int m = 0; m < RPW; ++m) {
@@ -375,20 +477,34 @@ __global__ __launch_bounds__(64 * (16 / RPW)) void deform_lds_kernel(const Defor
         for (int n = 0; n < NF; ++n)
             if (p.cstore - n * 32 > 0) store_frag(op + n * 32, acc[m][n], h, p.cstore - n * 32, [](float v, int) { return v; });
     }
+#if EMAVFI_DEFORM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DEFORM_STAMP(ts_done);
+    // every DEFORM_STAMP_STRIDE-th workgroup records; one private row of 8 values per wave (no atomics)
+    if (p.stamps && lane == 0 && blockIdx.x % DEFORM_STAMP_STRIDE == 0) {
+        const unsigned row = (blockIdx.x / DEFORM_STAMP_STRIDE) * C::WAVES + wave;
+        if (row < DEFORM_STAMP_ROWS) {
+            unsigned long long *o = p.stamps + (size_t)row * 8;
+            o[0] = ts_window - ts_begin; o[1] = ts_offconv - ts_window; o[2] = sum_geom; o[3] = sum_steps;
+            o[4] = ts_done - ts_loop; o[5] = ts_done - ts_begin; o[6] = 1; o[7] = ts_begin;
+        }
+    }
+#endif
 }
 
-template <typename T, int CK, int NF, int CS, int R, int RPW, bool FUSE_OFF> static int launch_deform_lds(const DeformParams &p, hipStream_t s)
+template <typename T, int CK, int NF, int CS, int R, int RPW, bool FUSE_OFF, int TQ> static int launch_deform_lds(const DeformParams &p, hipStream_t s)
 {
     using C = DeformLdsCfg<CK, NF, CS, R, RPW>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&deform_lds_kernel<T, CK, NF, CS, R, RPW, FUSE_OFF>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
-    dim3 grid((p.W + C::TCOLS - 1) / C::TCOLS, (p.H + C::TROWS - 1) / C::TROWS, p.B);
-    deform_lds_kernel<T, CK, NF, CS, R, RPW, FUSE_OFF><<<grid, C::THREADS, C::LDS_BYTES, s>>>(p);
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&deform_lds_kernel<T, CK, NF, CS, R, RPW, FUSE_OFF, TQ>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    });
+    if (attr_err != hipSuccess) return (int)attr_err;
+    const long long nwg = (long long)((p.W + C::TCOLS - 1) / C::TCOLS) * ((p.H + C::TROWS - 1) / C::TROWS) * p.B;
+    if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    deform_lds_kernel<T, CK, NF, CS, R, RPW, FUSE_OFF, TQ><<<(unsigned)nwg, C::THREADS, C::LDS_BYTES, s>>>(p);
     return (int)hipGetLastError();
 }
 
@@ -401,8 +517,12 @@ static inline bool deform16_lds_shape(int ck, int nf, int cin_real) { return ck 
 template <typename T> static int launch_deform16(const DeformParams &p, hipStream_t s)
 {
     if (deform16_lds_shape(p.ck, p.nf, p.cin_real)) {
-        if (p.off_w) return launch_deform_lds<T, 80, 3, 72, 2, EMAVFI_DEFORM_RPW, true>(p, s);
-        return launch_deform_lds<T, 80, 3, 72, 2, EMAVFI_DEFORM_RPW, false>(p, s);
+        if (EMAVFI_DEFORM_TRIM_TAIL && p.cin_real <= 68) {  // the reference width: 3 real channels in the last k-group
+            if (p.off_w) return launch_deform_lds<T, 80, 3, 72, 2, EMAVFI_DEFORM_RPW, true, 2>(p, s);
+            return launch_deform_lds<T, 80, 3, 72, 2, EMAVFI_DEFORM_RPW, false, 2>(p, s);
+        }
+        if (p.off_w) return launch_deform_lds<T, 80, 3, 72, 2, EMAVFI_DEFORM_RPW, true, 4>(p, s);
+        return launch_deform_lds<T, 80, 3, 72, 2, EMAVFI_DEFORM_RPW, false, 4>(p, s);
     }
     if (p.off_w) return -1;  // the host only asks for fusion after deform16_can_fuse_offset_conv()
     return launch_deform_any<T>(p, s);

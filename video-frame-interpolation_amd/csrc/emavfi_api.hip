@@ -47,6 +47,7 @@ struct Layer {
     int cin_pad = 0, ck = 0, nchunk = 0, nf = 0, npass = 0, coutpad = 0;
     size_t w_off = 0, b_off = 0, w_bytes = 0;
     bool deform = false;
+    bool f16_of_bf16 = false;  // bf16 model, layer consumed by deform_pack_kernel: bf16-rounded weights stored as f16
 };
 
 bool conv_geometry(Layer &L, int esize)
@@ -87,12 +88,17 @@ bool deform_geometry(Layer &L, int esize)
     return false;
 }
 
+// shape served by deform_pack_kernel (keep in sync with deform16_lds_shape in deform_pack.inl)
+bool deform16_lds_shape_host(int ck, int nf, int cin_real) { return ck == 80 && nf == 3 && cin_real <= 72; }
+
 constexpr int kMaxBlocks = 8;
 
 struct Plan {
     int in_ch, mid, nb, dtype, esize;
     int fpad, p_mid;  // padded fusion / feature widths
     Layer conv1, blk[kMaxBlocks], c0, c1, c2, m0, m1, m2, off[kMaxBlocks], dcn[kMaxBlocks], r0, r1, r2;
+    Layer offh[kMaxBlocks];  // bf16 model at the reference width: second copy of offset_conv for the one-launch pack
+    bool has_offh;
     int lin_param;
     size_t ctx_off, zero_off, total;
     const char *why;
@@ -110,7 +116,9 @@ bool build_plan(Plan &P, int in_ch, int mid, int nb, int dtype)
 {
     P.why = "";
     if (dtype != EMAVFI_F32 && dtype != EMAVFI_BF16 && dtype != EMAVFI_F16) { P.why = "dtype must be EMAVFI_F32, EMAVFI_BF16 or EMAVFI_F16"; return false; }
-    if (in_ch < 1 || in_ch > 4) { P.why = "in_channels must be 1..4"; return false; }
+    // the reference's fusion width is the literal mid_channels + 3 (ema_vfi.py:97): with any other in_channels its
+    // forward raises a channel mismatch at the first attention block, so this build refuses instead of padding / dropping
+    if (in_ch != 3) { P.why = "in_channels must be 3 (the reference's fusion width is mid_channels + 3, ema_vfi.py:97)"; return false; }
     if (nb < 1 || nb > kMaxBlocks) { P.why = "num_blocks must be 1..8"; return false; }
     if (mid < 8 || mid % 8 != 0) { P.why = "mid_channels must be a positive multiple of 8"; return false; }
     P.in_ch = in_ch; P.mid = mid; P.nb = nb; P.dtype = dtype; P.esize = dtype == EMAVFI_F32 ? 4 : 2;
@@ -148,6 +156,19 @@ bool build_plan(Plan &P, int in_ch, int mid, int nb, int dtype)
     ok = ok && place(P.m0, false) && place(P.m1, false) && place(P.m2, false);
     for (int i = 0; i < nb && ok; ++i) ok = place(P.off[i], false) && place(P.dcn[i], true);
     ok = ok && place(P.r0, false) && place(P.r1, false) && place(P.r2, false);
+    // The one-launch pack kernel (deform_pack.inl) keeps its window in f16 on chip whatever the storage type: in a bf16
+    // model its two weight sets are the bf16-rounded values stored as f16.  The stand-alone offset_conv (conv3x3, used
+    // when the pack is not fused) still reads the bf16 copy.
+    P.has_offh = false;
+    if (ok && dtype == EMAVFI_BF16 && nb > 0 && deform16_lds_shape_host(P.dcn[0].ck, P.dcn[0].nf, P.dcn[0].cin_take)) {
+        P.has_offh = true;
+        for (int i = 0; i < nb && ok; ++i) {
+            P.dcn[i].f16_of_bf16 = true;
+            P.offh[i] = P.off[i];
+            P.offh[i].f16_of_bf16 = true;
+            P.offh[i].w_off = o; o = rup256(o + P.offh[i].w_bytes);  // shares off[i]'s bias
+        }
+    }
     if (!ok) { P.why = "no kernel instantiation for these channel widths (built: mid_channels 8, 16, 32, 64)"; return false; }
     if (256 % rup(4 * mid, 16) != 0) { P.why = "4*mid_channels must divide 256 for the pooling kernel"; return false; }
     P.ctx_off = o;
@@ -176,6 +197,17 @@ int run_conv(const Plan &P, const Layer &L, const void *packed, const void *in, 
     return P.dtype == EMAVFI_F32 ? launch_conv3x3_f32(c, s) : P.dtype == EMAVFI_F16 ? launch_conv3x3_f16(c, s) : launch_conv3x3_bf16(c, s);
 }
 
+#if defined(EMAVFI_DEFORM_STAMPS) && EMAVFI_DEFORM_STAMPS
+// diagnostic build only (never the shipped library): a lazily allocated stamp buffer and its reader
+unsigned long long *debug_stamp_buffer()
+{
+    static unsigned long long *buf = nullptr;
+    if (!buf && hipMalloc(&buf, (size_t)DEFORM_STAMP_ROWS * 8 * sizeof(unsigned long long)) == hipSuccess)
+        (void)hipMemset(buf, 0, (size_t)DEFORM_STAMP_ROWS * 8 * sizeof(unsigned long long));
+    return buf;
+}
+#endif
+
 int run_deform(const Plan &P, const Layer &L, const void *packed, const void *x, int x_ps, float *om, void *out,
                int out_ps, int cstore, int B, int H, int W, hipStream_t s, const void *zeros = nullptr, const Layer *off = nullptr,
                const void *x_tail = nullptr, int tail_ps = 0)
@@ -183,7 +215,7 @@ int run_deform(const Plan &P, const Layer &L, const void *packed, const void *x,
     DeformParams d{};
     d.x = x; d.om = om; d.out = out;
     d.x_tail = x_tail; d.tail_ps = tail_ps;
-    if (off) {  // fused ModulatedDeformConvPack: the kernel computes om itself
+    if (off) {  // fused ModulatedDeformConvPack: the kernel computes om itself (off = the copy in the kernel's on-chip type)
         d.off_w = (const char *)packed + off->w_off;
         d.off_bias = (const float *)((const char *)packed + off->b_off);
     }
@@ -191,14 +223,17 @@ int run_deform(const Plan &P, const Layer &L, const void *packed, const void *x,
     d.bias = (const float *)((const char *)packed + L.b_off);
     d.zeros = zeros ? zeros : (const char *)packed + P.zero_off;
     d.x_ps = x_ps; d.out_ps = out_ps; d.H = H; d.W = W; d.B = B; d.cstore = cstore; d.cin_real = L.cin_take; d.ck = L.ck; d.nf = L.nf;
+#if defined(EMAVFI_DEFORM_STAMPS) && EMAVFI_DEFORM_STAMPS
+    d.stamps = debug_stamp_buffer();
+#endif
     return P.dtype == EMAVFI_F32 ? launch_deform_f32(d, s) : P.dtype == EMAVFI_F16 ? launch_deform_f16(d, s) : launch_deform_bf16(d, s);
 }
 
 int pack_layer(const Layer &L, const void *const *params, void *packed, int dtype, hipStream_t s)
 {
-    PackDesc d{L.cout, L.cin_raw, L.cin_off, L.cin_take, L.ck, L.nchunk, L.nf, L.npass, L.perm};
+    PackDesc d{L.cout, L.cin_raw, L.cin_off, L.cin_take, L.ck, L.nchunk, L.nf, L.npass, L.perm, L.f16_of_bf16 ? 1 : 0};
     return launch_pack_conv((const float *)params[L.param], (const float *)params[L.param + 1], (char *)packed + L.w_off,
-                            (float *)((char *)packed + L.b_off), d, dtype, s);
+                            (float *)((char *)packed + L.b_off), d, L.f16_of_bf16 ? (int)EMAVFI_F16 : dtype, s);
 }
 
 struct Workspace {
@@ -388,7 +423,11 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
             // the input is read once and the offsets / masks never leave the registers
             EMAVFI_STEP(rec, deform_name(P, P.dcn[i]) + " offset_conv+dcn_v2", fl + 2.0 * 9.0 * cf * cf * px,
                         px * (2.0 * cf * e) + 9.0 * cf * (cf + 27.0) * e,
-                        run_deform(P, P.dcn[i], packed, x, P.fpad, f.om, y, P.fpad, P.fpad, B, H, W, s, nullptr, &P.off[i],
+                        // a pack whose consumer is another one-launch pack stores 72 channels (9 sixteen-byte slots = all
+                        // its consumer's window DMA reads); the last pack feeds reconstruction.0, which reads all fpad
+                        run_deform(P, P.dcn[i], packed, x, P.fpad, f.om, y, P.fpad,
+                                   (i + 1 < P.nb && pack_fuses(i + 1) && P.fpad == 80) ? 72 : P.fpad, B, H, W, s, nullptr,
+                                   P.has_offh ? &P.offh[i] : &P.off[i],
                                    i == 0 && split_tail ? f.in16 : nullptr, 8));
         } else {
             EMAVFI_STEP(rec, conv_name(P, P.off[i]) + " offset_conv", fl, by,
@@ -418,6 +457,19 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
 }  // namespace
 
 extern "C" {
+
+#if defined(EMAVFI_DEFORM_STAMPS) && EMAVFI_DEFORM_STAMPS
+// rows of {prologue, offset_conv, geometry, steps, epilogue, total, valid, start time} per sampled wave
+int emavfi_debug_deform_stamps(unsigned long long *out, int rows, int reset)
+{
+    unsigned long long *buf = debug_stamp_buffer();
+    if (!buf || rows > DEFORM_STAMP_ROWS) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    if (out && hipMemcpy(out, buf, (size_t)rows * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -3;
+    if (reset && hipMemset(buf, 0, (size_t)DEFORM_STAMP_ROWS * 8 * sizeof(unsigned long long)) != hipSuccess) return -4;
+    return 0;
+}
+#endif
 
 int emavfi_version(void) { return EMAVFI_VERSION; }
 const char *emavfi_last_error(void) { return g_err; }
@@ -460,6 +512,7 @@ int emavfi_pack_weights(int in_channels, int mid_channels, int num_blocks, const
     EMAVFI_TRY(pack_layer(P.m2, params, packed, dtype, s), "pack motion2");
     for (int i = 0; i < P.nb; ++i) {
         EMAVFI_TRY(pack_layer(P.off[i], params, packed, dtype, s), "pack offset_conv");
+        if (P.has_offh) EMAVFI_TRY(pack_layer(P.offh[i], params, packed, dtype, s), "pack offset_conv (f16 fragments)");
         EMAVFI_TRY(pack_layer(P.dcn[i], params, packed, dtype, s), "pack dcn_v2");
     }
     EMAVFI_TRY(pack_layer(P.r0, params, packed, dtype, s), "pack recon0");
@@ -611,7 +664,7 @@ int emavfi_conv3x3(const float *x, const float *weight, const float *bias, float
     hipStream_t s = (hipStream_t)stream;
     L.w_off = (char *)wp - (char *)workspace;
     L.b_off = (char *)bp - (char *)workspace;
-    PackDesc d{L.cout, L.cin_raw, 0, L.cin_take, L.ck, L.nchunk, L.nf, L.npass, 0};
+    PackDesc d{L.cout, L.cin_raw, 0, L.cin_take, L.ck, L.nchunk, L.nf, L.npass, 0, 0};
     if (hipMemsetAsync(zpage, 0, 256, s) != hipSuccess) return fail(EMAVFI_E_LAUNCH, "conv3x3: zero page memset failed");
     EMAVFI_TRY(launch_pack_conv(weight, bias, wp, bp, d, dtype, s), "conv3x3 pack");
     EMAVFI_TRY(launch_nchw_to_cl(x, xcl, B, Cin, H, W, L.cin_pad, dtype, s), "conv3x3 layout in");
@@ -630,6 +683,10 @@ size_t emavfi_deform_conv2d_workspace_bytes(int B, int C, int O, int H, int W, i
     Layer L = mk(0, O, C);
     if (B < 1 || C < 1 || O < 1 || H < 1 || W < 1 || !deform_geometry(L, e)) {
         fail(EMAVFI_E_UNSUPPORTED, "deform_conv2d: no kernel instantiation for C=%d O=%d", C, O);
+        return 0;
+    }
+    if ((size_t)H * W >= ((size_t)1 << 24) || (size_t)H * W * L.ck * e >= ((size_t)1 << 32)) {
+        fail(EMAVFI_E_ARG, "deform_conv2d: H*W must be < 2^24 and one sample's input plane < 4 GiB");
         return 0;
     }
     Workspace ws{nullptr, 0, 0};
@@ -651,6 +708,8 @@ int emavfi_deform_conv2d(const float *x, const float *offset, const float *mask,
     P.dtype = dtype; P.esize = dtype == EMAVFI_F32 ? 4 : 2;
     Layer L = mk(0, O, C);
     if (!deform_geometry(L, P.esize)) return fail(EMAVFI_E_UNSUPPORTED, "deform_conv2d: no kernel instantiation for C=%d O=%d", C, O);
+    if ((size_t)H * W * L.ck * P.esize >= ((size_t)1 << 32))
+        return fail(EMAVFI_E_ARG, "deform_conv2d: one sample's input plane must be < 4 GiB (32-bit byte offsets in the gather)");
     const size_t px = (size_t)B * H * W;
     const int ops = rup(O, 16);
     Workspace ws{(char *)workspace, workspace_bytes, 0};
@@ -664,9 +723,11 @@ int emavfi_deform_conv2d(const float *x, const float *offset, const float *mask,
     hipStream_t s = (hipStream_t)stream;
     L.w_off = (char *)wp - (char *)workspace;
     L.b_off = (char *)bp - (char *)workspace;
-    PackDesc d{L.cout, L.cin_raw, 0, L.cin_take, L.ck, 1, L.nf, 1, 0};
+    // the 16-bit LDS-window kernel contracts in f16 on chip: a bf16 call packs its bf16-rounded weights as f16 fragments
+    const bool h_of_b = dtype == EMAVFI_BF16 && deform16_lds_shape_host(L.ck, L.nf, L.cin_take);
+    PackDesc d{L.cout, L.cin_raw, 0, L.cin_take, L.ck, 1, L.nf, 1, 0, h_of_b ? 1 : 0};
     if (hipMemsetAsync(zpage, 0, 256, s) != hipSuccess) return fail(EMAVFI_E_LAUNCH, "deform_conv2d: zero page memset failed");
-    EMAVFI_TRY(launch_pack_conv(weight, bias, wp, bp, d, dtype, s), "deform pack");
+    EMAVFI_TRY(launch_pack_conv(weight, bias, wp, bp, d, h_of_b ? (int)EMAVFI_F16 : dtype, s), "deform pack");
     EMAVFI_TRY(launch_nchw_to_cl(x, xcl, B, C, H, W, L.ck, dtype, s), "deform layout in");
     EMAVFI_TRY(launch_om_from_nchw(offset, mask, om, B, H, W, s), "deform offsets");
     EMAVFI_TRY(run_deform(P, L, workspace, xcl, L.ck, om, ycl, ops, ops, B, H, W, s, zpage), "deform_conv2d");

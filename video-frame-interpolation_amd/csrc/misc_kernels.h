@@ -8,6 +8,8 @@ struct PackDesc {
     int cout, cin_raw, cin_off, cin_take;  // raw OIHW tensor: take input channels [cin_off, cin_off + cin_take)
     int ck, nchunk, nf, npass;             // packed geometry
     int perm;                              // 0 = identity, 1 = offset_conv routing (offsets | mask)
+    int via_bf16;                          // 1 = round every weight to bf16 first, then store it in the packed type
+                                           // (f16 fragments holding the bf16 model's weights exactly: deform_pack.inl)
 };
 
 int launch_pack_conv(const float *w, const float *bias, void *wp, float *bp, const PackDesc &d, int dtype, hipStream_t s);

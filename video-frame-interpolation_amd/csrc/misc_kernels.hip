@@ -2,7 +2,23 @@
 // boundary, global-average-pool + context folding, and the backward bilinear warp.
 #include "common.h"
 #include "misc_kernels.h"
+#include <atomic>
 #include <type_traits>
+
+int device_cu_count()
+{
+    static std::atomic<int> cache[64];  // zero-initialised; a racing first call just queries twice
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return -1;
+    if (dev < 64) {
+        const int c = cache[dev].load(std::memory_order_relaxed);
+        if (c > 0) return c;
+    }
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return -1;
+    if (dev < 64) cache[dev].store(n, std::memory_order_relaxed);
+    return n;
+}
 
 // ------------------------------------------------------------------------------------------
 // Weight packing: OIHW fp32 -> [pass][chunk][tap][kg][nf][lane][16 B] in MFMA operand order.
@@ -42,6 +58,7 @@ __global__ void pack_conv_kernel(const float *__restrict__ w, const float *__res
         const int ci = chunk * d.ck + kg * CHKG + (lane >> 5) * EPV + e;
         float v = 0.0f;
         if (co < d.cout && ci < d.cin_take) v = w[((size_t)co * d.cin_raw + d.cin_off + ci) * 9 + tap];
+        if (d.via_bf16) v = (float)(bf16_t)v;
         wp[idx] = (T)v;
     }
     const int coutpad = d.npass * d.nf * 32;

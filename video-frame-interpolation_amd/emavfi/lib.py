@@ -63,6 +63,21 @@ def load() -> ctypes.CDLL:
     return _lib
 
 
+_fingerprint = None
+
+
+def fingerprint() -> str:
+    """sha256 of the loaded libemavfi.so: part of the key of the on-disk packed-weight cache (the packed layout is a
+    property of the build, not of emavfi_version())."""
+    global _fingerprint
+    if _fingerprint is None:
+        import hashlib
+        load()
+        with open(LIB_PATH, "rb") as f:
+            _fingerprint = hashlib.sha256(f.read()).hexdigest()
+    return _fingerprint
+
+
 def last_error() -> str:
     return (load().emavfi_last_error() or b"").decode("utf-8", "replace")
 
@@ -98,23 +113,46 @@ def _f32c(t):
     return t.detach().to(torch.float32).contiguous()
 
 
-_ws_cache = {}
+# Scratch memory (caller-owned, as the C-ABI requires): one grow-only buffer per (device, stream).
+#   * two streams (or two threads on different streams) never share scratch - forwards on different streams may
+#     run concurrently;
+#   * a buffer is allocated while its stream is current, so the caching allocator's stream-ordered reuse makes
+#     dropping the old buffer on growth safe: it was only ever used on that stream;
+#   * a buffer that was handed out while its stream was being captured into a hipGraph has its address baked into the
+#     graph: it is never freed on growth but parked in _ws_graph_held (until release_workspaces()), so replaying the
+#     graph after a later, larger forward still writes to memory nobody else owns.
+_ws_cache = {}        # (device index, stream handle) -> uint8 tensor
+_ws_captured = set()  # keys whose current buffer a captured graph may point at
+_ws_graph_held = []
+_ws_lock = threading.Lock()
 
 
 def workspace(nbytes: int, device):
-    """Grow-only per-device scratch buffer (caller-owned memory, as the C-ABI requires)."""
     import torch
-    key = (device.type, device.index)
-    buf = _ws_cache.get(key)
-    if buf is None or buf.numel() < nbytes:
-        _ws_cache.pop(key, None)
-        buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
-        _ws_cache[key] = buf
+    device = torch.device(device)
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (index, torch.cuda.current_stream(device).cuda_stream)
+    capturing = torch.cuda.is_current_stream_capturing()
+    with _ws_lock:
+        buf = _ws_cache.get(key)
+        if buf is None or buf.numel() < nbytes:
+            if buf is not None and key in _ws_captured:
+                _ws_graph_held.append(buf)
+                _ws_captured.discard(key)
+            with torch.cuda.device(index):
+                buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=torch.device("cuda", index))
+            _ws_cache[key] = buf
+        if capturing:
+            _ws_captured.add(key)
     return buf
 
 
 def release_workspaces():
-    _ws_cache.clear()
+    """Drop every cached workspace, including those kept alive for captured graphs (destroy the graphs first)."""
+    with _ws_lock:
+        _ws_cache.clear()
+        _ws_captured.clear()
+        del _ws_graph_held[:]
 
 
 # ---------------------------------------------------------------- operator-level wrappers

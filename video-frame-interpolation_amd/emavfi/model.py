@@ -15,8 +15,10 @@ PyTorch fallback: CPU tensors or a missing library raise ``RuntimeError``.
 """
 from __future__ import annotations
 
+import hashlib
 import math
 import os
+import tempfile
 from collections import OrderedDict
 from ctypes import POINTER, c_void_p, cast
 
@@ -115,6 +117,8 @@ class EMA_VFI(nn.Module):
             [ModulatedDeformConvPack(m + 3, m + 3, kernel_size=3, padding=1, groups=1) for _ in range(num_blocks)])
         self.reconstruction = nn.Sequential(conv_block(m + 3, m), conv_block(m, m // 2), conv(m // 2, in_channels), nn.Tanh())
         self._packed = {}      # dtype code -> (key, packed uint8 tensor)
+        self._installed = {}   # dtype code -> parameter versions when load_packed_weights() installed the blob
+        self._params_loaded = True   # False once a foreign blob is installed and no state_dict has been loaded since
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
@@ -139,7 +143,11 @@ class EMA_VFI(nn.Module):
                 raise RuntimeError(f"EMA_VFI.load_state_dict: {k} has shape {tuple(v.shape)}, "
                                    f"expected {tuple(own[k].shape)} for EMA_VFI({self.in_channels}, "
                                    f"{self.mid_channels}, {self.num_blocks})")
-        return super().load_state_dict(clean, strict=strict, assign=assign)
+        res = super().load_state_dict(clean, strict=strict, assign=assign)
+        self._installed.clear()          # the parameters are authoritative again: blobs re-pack from them
+        self._packed.clear()
+        self._params_loaded = True
+        return res
 
     def _ordered_params(self):
         """Tensors in the order emavfi_pack_weights expects = the reference's registration order."""
@@ -148,8 +156,27 @@ class EMA_VFI(nn.Module):
     def _weights_key(self, device):
         return (str(device),) + tuple((p.data_ptr(), p._version) for p in self._ordered_params())
 
+    def _versions(self):
+        return tuple(p._version for p in self._ordered_params())
+
     def packed_weights(self, dt: int, device):
         """Packed blob for this dtype, re-packed lazily after load_state_dict / .to() / in-place edits."""
+        inst = self._installed.get(dt)
+        if inst is not None:
+            # a blob installed by load_packed_weights() (another rank's weights): it stays in force across .to() /
+            # device moves; this rank's nn.Parameters are NOT its source, so an in-place edit cannot be honoured
+            if inst != self._versions():
+                raise RuntimeError("EMA_VFI: parameters were modified in place, but this model runs on packed weights "
+                                   "installed by load_packed_weights() and never loaded a state_dict - call "
+                                   "load_state_dict() (then the blob is re-packed from the parameters)")
+            blob = self._packed[dt][1]
+            if blob.device != torch.device(device):
+                blob = blob.to(device)
+                self._packed[dt] = (None, blob)
+            return blob
+        if not self._params_loaded:
+            raise RuntimeError(f"EMA_VFI: no packed weights for dtype code {dt}: this model received its weights through "
+                               "load_packed_weights() for another dtype and its nn.Parameters were never loaded")
         key = self._weights_key(device)
         hit = self._packed.get(dt)
         if hit is not None and hit[0] == key:
@@ -162,18 +189,78 @@ class EMA_VFI(nn.Module):
         n = L.emavfi_param_count(self.num_blocks)
         if len(params) != n:
             raise RuntimeError(f"EMA_VFI: expected {n} parameter tensors, module has {len(params)}")
-        blob = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        arr = (c_void_p * n)(*[p.data_ptr() for p in params])
-        with torch.cuda.device(device):
-            _lib.check(L.emavfi_pack_weights(self.in_channels, self.mid_channels, self.num_blocks,
-                                             cast(arr, POINTER(c_void_p)), n, blob.data_ptr(), nbytes, dt, _lib._stream()),
-                       "emavfi_pack_weights")
+        # on-disk cache keyed by CONTENT (the reference reloads and re-prepares its checkpoint at every
+        # process start, inference.py:69): state_dict bytes + dtype + model shape + the library build
+        path = self._cache_path(params, dt, nbytes)
+        blob = self._cache_read(path, nbytes, device)
+        if blob is None:
+            blob = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            arr = (c_void_p * n)(*[p.data_ptr() for p in params])
+            with torch.cuda.device(device):
+                _lib.check(L.emavfi_pack_weights(self.in_channels, self.mid_channels, self.num_blocks,
+                                                 cast(arr, POINTER(c_void_p)), n, blob.data_ptr(), nbytes, dt, _lib._stream()),
+                           "emavfi_pack_weights")
+            self._cache_write(path, blob)
         self._packed[dt] = (key, blob)
         return blob
 
-    def load_packed_weights(self, dt, blob):
-        """Install an already-packed blob (e.g. received by an RCCL broadcast from rank 0)."""
-        self._packed[_lib.dtype_code(dt)] = (self._weights_key(blob.device), blob)
+    # ------------------------------------------------------------------ packed-weight cache on disk
+    @staticmethod
+    def cache_dir():
+        """Directory of the packed-weight cache, or None when disabled (EMAVFI_CACHE=0)."""
+        if os.environ.get("EMAVFI_CACHE", "1") == "0":
+            return None
+        return os.environ.get("EMAVFI_CACHE_DIR") or os.path.join(
+            os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache"), "emavfi")
+
+    def _cache_path(self, params, dt, nbytes):
+        d = self.cache_dir()
+        if d is None:
+            return None
+        h = hashlib.sha256()
+        h.update(f"{_lib.fingerprint()}|{dt}|{self.in_channels}|{self.mid_channels}|{self.num_blocks}|{nbytes}".encode())
+        for name, p in zip((k for k, _ in self.named_parameters()), params):
+            h.update(name.encode())
+            h.update(p.cpu().numpy().tobytes())
+        return os.path.join(d, f"packed_{h.hexdigest()[:32]}.bin")
+
+    @staticmethod
+    def _cache_read(path, nbytes, device):
+        if path is None or not os.path.isfile(path) or os.path.getsize(path) != nbytes:
+            return None
+        try:
+            import numpy as np
+            return torch.from_numpy(np.fromfile(path, dtype=np.uint8)).to(device)
+        except OSError:
+            return None
+
+    @staticmethod
+    def _cache_write(path, blob):
+        if path is None:
+            return
+        try:  # best effort: a read-only or full cache directory must never fail a forward
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            fd, tmp = tempfile.mkstemp(dir=os.path.dirname(path), suffix=".tmp")
+            with os.fdopen(fd, "wb") as f:
+                f.write(blob.cpu().numpy().tobytes())
+            os.replace(tmp, path)  # atomic: concurrent ranks write identical bytes
+        except OSError:
+            pass
+
+    def load_packed_weights(self, dt, blob, params_are_source=False):
+        """Install an already-packed blob (e.g. received by an RCCL broadcast from rank 0).  The blob is pinned: it is
+        used as is until load_state_dict() is called.  ``params_are_source=True`` (the broadcasting rank, whose own
+        parameters produced the blob) keeps the normal re-pack-on-change behaviour."""
+        dt = _lib.dtype_code(dt)
+        nbytes = _lib.load().emavfi_packed_bytes(self.in_channels, self.mid_channels, self.num_blocks, dt)
+        if blob.dtype != torch.uint8 or blob.numel() != nbytes:
+            raise ValueError(f"load_packed_weights: a uint8 blob of {nbytes} bytes is expected for this model / dtype")
+        if params_are_source:
+            self._packed[dt] = (self._weights_key(blob.device), blob)
+            return
+        self._packed[dt] = (None, blob)
+        self._installed[dt] = self._versions()
+        self._params_loaded = False
 
     def _resolve_dtype(self) -> int:
         if self.compute_dtype is not None:
@@ -191,6 +278,11 @@ class EMA_VFI(nn.Module):
                              f"{tuple(frame1.shape)} and {tuple(frame2.shape)}")
         if frame1.device != frame2.device:
             raise ValueError("EMA_VFI.forward: frame1 and frame2 are on different devices")
+        if self.in_channels != 3:
+            # the reference's fusion width is the literal mid_channels + 3 (ema_vfi.py:97): any other in_channels
+            # fails there with a channel mismatch at the first attention block
+            raise RuntimeError(f"EMA_VFI: in_channels={self.in_channels} is not runnable (the reference's fusion width "
+                               "is mid_channels + 3, ema_vfi.py:97); only in_channels=3 is supported")
         _lib._require_cuda(frame1, frame2)
         if torch.is_grad_enabled() and (frame1.requires_grad or frame2.requires_grad
                                         or any(p.requires_grad for p in self.parameters())):
