@@ -182,3 +182,65 @@ def forward(p: Params, frame1, frame2, num_blocks: int = 3, taps: Optional[dict]
     if taps is not None:
         taps["out"] = out
     return out
+
+
+# --------------------------------------------------------------------------------------------------------------
+# The reference's forward under ``torch.cuda.amp.autocast()`` (float16), which is what ``inference.py:159`` runs on a
+# GPU.  Restated from PyTorch's published autocast op policy, NOT pinned by execution (the reference has never been
+# run on a GPU here): ``conv2d`` / ``linear`` are on the float16 list (inputs, weight AND bias are cast to fp16, the
+# products accumulate in fp32, the result is an fp16 tensor); ``grid_sampler`` is on the float32 list;
+# ``torch.cat`` and the ``grid + flow`` add promote to the widest input; element-wise ops without a list entry
+# (relu, sigmoid, tanh, ``+ 1``, ``/ 2``, adaptive_avg_pool2d) run in their input's dtype with fp32 op-math and one
+# rounding; torchvision registers ``deform_conv2d`` with an Autocast kernel that casts input, weight, offset, mask and
+# bias to fp32 and casts the result back to the INPUT's dtype.  Consequences along ema_vfi.py:110-147:
+#   feat, ctx, flow are fp16 tensors; warp runs in fp32 on the fp16-valued flow and returns fp32; cat(feat, warped) is
+#   fp32; every attention block computes its offset_conv in fp16 (input rounded), sigmoid in fp16, the DCN in fp32 on
+#   the UNROUNDED fp32 input with the fp32 master weights, and returns fp32; reconstruction is fp16 to the end, so
+#   the frame is an fp16 tensor.  tests/test_gpu_runtime.py::test_autocast_op_policy_of_this_torch checks the
+#   per-op dtypes this restatement assumes against the installed torch on the GPU box.
+def _h(t):
+    """Round to float16 (what storing a value in an autocast fp16 tensor does); values stay in fp32 containers."""
+    return t.half().float()
+
+
+def _conv16(x, w, b, stride: int = 1):
+    return _h(F.conv2d(_h(x), _h(w), _h(b), stride=stride, padding=1))
+
+
+@torch.no_grad()
+def forward_autocast16(p: Params, frame1, frame2, num_blocks: int = 3, taps: Optional[dict] = None):
+    x = torch.cat([frame1, frame2], dim=1)
+    x = F.relu(_conv16(x, p["feat_ext_conv1.0.weight"], p["feat_ext_conv1.0.bias"]))
+    for i in range(num_blocks):
+        k = f"feat_ext_blocks.conv_block_{i}.0"
+        x = F.relu(_conv16(x, p[k + ".weight"], p[k + ".bias"]))
+    feat = x
+    c = F.relu(_conv16(feat, p["context_encoding.0.0.weight"], p["context_encoding.0.0.bias"], 2))
+    c = F.relu(_conv16(c, p["context_encoding.1.0.weight"], p["context_encoding.1.0.bias"], 2))
+    c = F.relu(_conv16(c, p["context_encoding.2.0.weight"], p["context_encoding.2.0.bias"]))
+    c = _h(F.adaptive_avg_pool2d(c, 1).flatten(1))
+    ctx = _h(F.linear(c, _h(p["context_encoding.5.weight"]), _h(p["context_encoding.5.bias"])))
+    B, _, H, W = feat.shape
+    m = torch.cat([feat, ctx[:, :, None, None].expand(B, ctx.shape[1], H, W)], dim=1)
+    m = F.relu(_conv16(m, p["motion_estimation.0.0.weight"], p["motion_estimation.0.0.bias"]))
+    m = F.relu(_conv16(m, p["motion_estimation.1.0.weight"], p["motion_estimation.1.0.bias"]))
+    flow = _conv16(m, p["motion_estimation.2.weight"], p["motion_estimation.2.bias"])
+    warped = warp(frame2, flow)                       # fp32 op on the fp16-valued flow
+    fused = torch.cat([feat, warped], dim=1)          # promotes to fp32: warped keeps its fp32 bits
+    if taps is not None:
+        taps.update(feat=feat, ctx=ctx, flow=flow, warped=warped)
+    for i in range(num_blocks):
+        k = f"attention_blocks.{i}"
+        raw = _conv16(fused, p[k + ".offset_conv.weight"], p[k + ".offset_conv.bias"])
+        o1, mk, o2 = torch.chunk(raw, 3, dim=1)
+        fused = deform_conv2d(fused, torch.cat((o1, o2), dim=1), _h(torch.sigmoid(mk)),
+                              p[k + ".dcn_v2.weight"], p[k + ".dcn_v2.bias"])      # fp32, master weights
+        if taps is not None:
+            taps[f"fused_{i}"] = fused
+    r = F.relu(_conv16(fused, p["reconstruction.0.0.weight"], p["reconstruction.0.0.bias"]))
+    r = F.relu(_conv16(r, p["reconstruction.1.0.weight"], p["reconstruction.1.0.bias"]))
+    r = _h(torch.tanh(_conv16(r, p["reconstruction.2.weight"], p["reconstruction.2.bias"])))
+    out = _h(r + 1.0) / 2.0
+    if taps is not None:
+        taps["out"] = out
+    return out

@@ -111,7 +111,7 @@ def test_installed_blob_is_pinned_until_a_state_dict_is_loaded():
             other.compute_dtype = "fp32"
             other(f1, f2)
         other.compute_dtype = "bf16"
-        other.feat_ext_conv1[0].bias.data.add_(1.0)
+        other.feat_ext_conv1[0].bias.add_(1.0)    # (under no_grad; an edit through .data bypasses the version counter)
         with pytest.raises(RuntimeError, match="modified in place"):
             other(f1, f2)
         other.load_state_dict(sd2)

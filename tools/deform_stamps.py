@@ -36,4 +36,8 @@ print(f"{dtype}: {len(v)} waves sampled (median cycles per wave and tile)")
 tot = np.median(v[:, 5])
 for i, n in enumerate(names):
     print(f"  {n:42s} {np.median(v[:, i]):10.0f}  {100.0 * np.median(v[:, i]) / tot:5.1f} %   (p10 {np.percentile(v[:, i], 10):.0f}, p90 {np.percentile(v[:, i], 90):.0f})")
+d = buf[buf[:, 6] == 1][:, 7]
+parts = [((d >> np.uint64(16 * i)) & np.uint64(0xffff)).astype(np.float64) * 4 for i in range(4)]
+print("  prologue detail (median cycles): tile mapping + small loads + DMA issue %.0f, DMA landed after %.0f, convert %.0f, barrier wait %.0f"
+      % tuple(np.median(x) for x in parts))
 print(f"  per tap: geometry {np.median(v[:, 2]) / 9:.0f}, steps {np.median(v[:, 3]) / 9:.0f} cycles")

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Reduce two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into HBM bytes per launch per kernel.
 
-usage: pmc_to_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out_prefix>
+usage: pmc_to_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out_dir/> <round tag, e.g. r02_final> [--install]
+(--install also writes profiles/traffic.json, stamped with the sha of the kernel sources it was measured on: bench.py
+refuses a file whose stamp does not match the sources it runs)
 Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (section HBM): the counters are KiB;
 on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced read and is doubled;
 WRITE_SIZE is exact for 16-byte-per-lane streaming stores and taken as is.  Kernel labels match bench.py."""
@@ -17,9 +19,9 @@ def per_kernel(path, counter):
 
 
 def label(k):
-    m = re.match(r"_Z17deform_lds_kernelI(DF16b|DF16_)Li(\d+)ELi(\d+)", k)
-    if m:  # the LDS-window kernel (one launch per ModulatedDeformConvPack when its last template argument is true)
-        return f"deform<{'bf16' if m.group(1) == 'DF16b' else 'f16'},ck={m.group(2)},nf={m.group(3)}>"
+    m = re.match(r"_Z18deform_pack_kernelI(DF16b|DF16_)Li(\d+)ELi(\d+)ELb1", k)
+    if m:  # the LDS-window kernel, one launch per ModulatedDeformConvPack (csrc/deform_pack.inl)
+        return f"deform<{'bf16' if m.group(1) == 'DF16b' else 'f16'},ck=80,nf=3>"
     m = re.match(r"_Z14conv3x3_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)EEv", k)
     if m:
         return f"conv3x3<{'bf16' if m.group(1) == 'DF16b' else 'f32'},ck={m.group(2)},nf={m.group(3)},s={m.group(4)}>"
@@ -46,5 +48,23 @@ for k in sorted(f, key=lambda k: -sum(f[k])):
     out[lab] = {"hbm_bytes_per_launch": rd + wr, "fetch_bytes_corrected_x2": rd, "write_bytes": wr,
                 "launches_sampled": len(f[k]), "raw_FETCH_SIZE_KiB": fk, "raw_WRITE_SIZE_KiB": wk}
     print(f"{lab:42s} n={len(f[k]):3d} read {rd / 1e6:9.1f} MB  write {wr / 1e6:8.1f} MB  total {(rd + wr) / 1e6:9.1f} MB")
-json.dump({k: v["hbm_bytes_per_launch"] for k, v in out.items()}, open(sys.argv[3] + "traffic.json", "w"), indent=1)
-json.dump({"method": __doc__, "kernels": out}, open(sys.argv[3] + "r01_final_pmc_traffic_detail.json", "w"), indent=1)
+tag = sys.argv[4] if len(sys.argv) > 4 else "rXX"
+json.dump({"method": __doc__, "kernels": out}, open(sys.argv[3] + f"{tag}_pmc_traffic_detail.json", "w"), indent=1)
+if "--install" in sys.argv:
+    import datetime, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    # kernel_source_sha() without importing torch: replicate bench.py's definition
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(root, "video-frame-interpolation_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".inl", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    t = {k: v["hbm_bytes_per_launch"] for k, v in out.items()}
+    t["_kernel_source_sha"] = h.hexdigest()[:16]
+    t["_measured"] = f"{tag}, {datetime.date.today().isoformat()}, profiles/{tag}_pmc_traffic_detail.json"
+    json.dump(t, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)

@@ -155,6 +155,10 @@ struct ConvParams {
     int cstore;   // channels to store across all passes (multiple of 4)
     int epi, nplanes, bias_mode;
     int ck, nf, stride;  // host-side template selectors
+    int round16;         // EMAVFI_AMP16: fp32-stored results (flow, offsets / masks, the frame) hold fp16-rounded values and
+                         // sigmoid / tanh / (t+1)/2 round after every op, as fp16 tensors do under autocast
+    int in_pieces;       // 16-byte pieces of an input pixel (single-chunk layers) that exist in memory; 0 = all CK of them.
+                         // Pieces beyond read as zeros: the 72-channel fusion buffers feed CK = 80 layers this way.
 };
 
 struct DeformParams {

@@ -24,6 +24,10 @@
 #include "common.h"
 #include <mutex>
 
+#ifndef EMAVFI_CONV_PIPELINE
+#define EMAVFI_CONV_PIPELINE 1   // persistent kernel: operands one step ahead of their MFMAs (0 = the compiler's own order)
+#endif
+
 template <typename T, int CK, int NF, int S> struct ConvCfg {
     using D = DT<T>;
     static constexpr int MF = (S == 1) ? 2 : 1;
@@ -90,7 +94,10 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[MF][NF], const
                 for (int c = 0; c < 4; ++c)
                     if (c < p.nplanes) {
                         float v = acc[m][0][c];
-                        if (p.epi == EPI_PLANAR_TANH01) v = (tanhf(v) + 1.0f) / 2.0f;  // ema_vfi.py:106,146
+                        if (p.round16) {  // fp16 tensors under autocast: one rounding per op
+                            v = (float)(half_t)v;
+                            if (p.epi == EPI_PLANAR_TANH01) v = (float)(half_t)((float)(half_t)tanhf(v) + 1.0f) / 2.0f;
+                        } else if (p.epi == EPI_PLANAR_TANH01) v = (tanhf(v) + 1.0f) / 2.0f;  // ema_vfi.py:106,146
                         p.out_planar[((size_t)b * p.nplanes + c) * plane + (size_t)y * p.Wout + x] = v;
                     }
             }
@@ -99,7 +106,12 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[MF][NF], const
         if (p.epi == EPI_OM) {
             // mask = sigmoid(second chunk), ema_vfi.py:59; routed to channels 18..26 at pack time
             const auto om_act = [](float v, int c) { return (c >= 18 && c < 27) ? 1.0f / (1.0f + expf(-v)) : v; };
-            store_frag(reinterpret_cast<float *>(p.out) + pix * p.out_ps, acc[m][0], h, p.cstore, om_act);
+            const auto om_act16 = [](float v, int c) {  // offset_conv's output and sigmoid(mask) are fp16 tensors under autocast
+                v = (float)(half_t)v;
+                return (c >= 18 && c < 27) ? (float)(half_t)(1.0f / (1.0f + expf(-v))) : v;
+            };
+            if (p.round16) store_frag(reinterpret_cast<float *>(p.out) + pix * p.out_ps, acc[m][0], h, p.cstore, om_act16);
+            else store_frag(reinterpret_cast<float *>(p.out) + pix * p.out_ps, acc[m][0], h, p.cstore, om_act);
             continue;
         }
         T *ob = reinterpret_cast<T *>(p.out) + pix * p.out_ps + p.out_coff + pass * NF * 32;
@@ -139,6 +151,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvParams p)
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
     const char *zeros = (const char *)p.zeros;
+    const int npieces = p.in_pieces > 0 ? p.in_pieces : C::PIECES;
 
     for (int chunk = 0; chunk < p.nchunk; ++chunk) {
         if (chunk) {
@@ -159,7 +172,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvParams p)
                 const int pix = sl / C::SP, pc = sl - pix * C::SP;
                 const int ly = pix / IW, lx = pix - ly * IW;
                 const int gy = iy0 + ly, gx = ix0 + lx;
-                const bool ok = sl < C::NSLOT && pc < C::PIECES && gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
+                const bool ok = sl < C::NSLOT && pc < npieces && gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
                 const char *src = ok ? gchunk + ((size_t)gy * p.Win + gx) * p.in_ps * sizeof(T) + pc * 16 : zeros;
                 __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)(lds_in + j * 1024), 16, 0, 0);
             }
@@ -273,6 +286,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_persist_kernel(const ConvP
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const char *zeros = (const char *)p.zeros;
+    const int npieces = p.in_pieces > 0 ? p.in_pieces : C::PIECES;
 
     // all nine taps' packed weights, once per workgroup
 #pragma unroll 1
@@ -296,7 +310,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_persist_kernel(const ConvP
                 const int pix = sl / C::SP, pc = sl - pix * C::SP;
                 const int ly = pix / IW, lx = pix - ly * IW;
                 const int gy = iy0 + ly, gx = ix0 + lx;
-                const bool ok = sl < C::NSLOT && pc < C::PIECES && gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
+                const bool ok = sl < C::NSLOT && pc < npieces && gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
                 const char *src = ok ? gin + ((size_t)gy * p.Win + gx) * p.in_ps * sizeof(T) + pc * 16 : zeros;
                 __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)(lds_in + j * 1024), 16, 0, 0);
             }
@@ -305,6 +319,45 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_persist_kernel(const ConvP
         conv_init_acc<MF, NF>(acc, p, b, 0, ty * C::TH + wave * MF, tx * 32 + r, h);
         __syncthreads();  // hipcc drains the DMA (vmcnt(0)) ahead of the barrier: tile (and, first time, weights) landed
 
+#if EMAVFI_CONV_PIPELINE
+        // Software pipeline over (tap, k-group pair) steps: the operands of step s+1 (MF pixel pieces + NF weight fragments
+        // per k-group) are read from LDS BEFORE the MFMAs of step s issue, and sched_barrier pins that order (left alone,
+        // hipcc places each read group directly in front of its MFMAs, exposing an LDS round trip per group).
+        {
+            constexpr int KGS = (C::KG % 2 == 0) ? 2 : 1;         // k-groups per step
+            constexpr int SPT = C::KG / KGS, NSTEP = 9 * SPT;     // steps per tap, steps per tile
+            static_assert(C::KG % KGS == 0, "k-groups per step must divide KG");
+            vec xq[2][MF][KGS], wq[2][KGS][NF];
+            auto load_step = [&](int s, vec (&xd)[MF][KGS], vec (&wd)[KGS][NF]) {
+                const int tap = s / SPT, kg0 = (s - tap * SPT) * KGS;
+                const int dy = tap / 3, dx = tap - 3 * dy;
+#pragma unroll
+                for (int m = 0; m < MF; ++m) {
+                    const char *xb = lds_in + (((wave * MF + m) + dy) * IW + r + dx) * PSTR + h * 16;
+#pragma unroll
+                    for (int k = 0; k < KGS; ++k) xd[m][k] = *reinterpret_cast<const vec *>(xb + (kg0 + k) * 32);
+                }
+                const char *wb = lds_w + tap * C::WTAP + lane * 16;
+#pragma unroll
+                for (int k = 0; k < KGS; ++k)
+#pragma unroll
+                    for (int n = 0; n < NF; ++n) wd[k][n] = *reinterpret_cast<const vec *>(wb + ((kg0 + k) * NF + n) * 1024);
+            };
+            load_step(0, xq[0], wq[0]);
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+                if (s + 1 < NSTEP) load_step(s + 1, xq[(s + 1) & 1], wq[(s + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < KGS; ++k)
+#pragma unroll
+                    for (int n = 0; n < NF; ++n)
+#pragma unroll
+                        for (int m = 0; m < MF; ++m) mma_kg(acc[m][n], wq[s & 1][k][n], xq[s & 1][m][k]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#else
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap - 3 * dy;
@@ -325,6 +378,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_persist_kernel(const ConvP
                 }
             }
         }
+#endif
         conv_epilogue<T, MF, NF>(acc, p, b, 0, ty * C::TH + wave * MF, tx * 32 + r, h);
     }
 }

@@ -107,13 +107,15 @@ template <int NQ> __device__ __forceinline__ f16x8 blend_corners(const u32x4_t (
     // explicit dword arrays: subscripting v[c][q] with the loop variable made hipcc (ROCm 7.2) use element 0 for every q
     const unsigned d0[4] = {v[0][0], v[0][1], v[0][2], v[0][3]}, d1[4] = {v[1][0], v[1][1], v[1][2], v[1][3]};
     const unsigned d2[4] = {v[2][0], v[2][1], v[2][2], v[2][3]}, d3[4] = {v[3][0], v[3][1], v[3][2], v[3][3]};
+    // corner-major: the NQ chains are independent, so consecutive instructions never depend on each other
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        f16x2_t t = __builtin_bit_cast(f16x2_t, d0[q]) * bcast_half<0>(w01);
-        t = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d1[q]), bcast_half<1>(w01), t);
-        t = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d2[q]), bcast_half<0>(w23), t);
-        a[q] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d3[q]), bcast_half<1>(w23), t);
-    }
+    for (int q = 0; q < NQ; ++q) a[q] = __builtin_bit_cast(f16x2_t, d0[q]) * bcast_half<0>(w01);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) a[q] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d1[q]), bcast_half<1>(w01), a[q]);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) a[q] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d2[q]), bcast_half<0>(w23), a[q]);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) a[q] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d3[q]), bcast_half<1>(w23), a[q]);
     return f16x8{a[0][0], a[0][1], a[1][0], a[1][1], a[2][0], a[2][1], a[3][0], a[3][1]};
 }
 
@@ -213,6 +215,11 @@ __global__ __launch_bounds__(16 * TCOLS, 2) void deform_pack_kernel(const Deform
             if (lx >= C::TC) { lx -= C::TC; ly += 1; }
         }
     }
+    DEFORM_STAMP(ts_issued);
+#if EMAVFI_DEFORM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    DEFORM_STAMP(ts_landed);
     if constexpr (std::is_same<TS, bf16_t>::value) {
         // bf16 -> f16 in place: every wave converts exactly the pieces its own DMA instructions fetched, so its own
         // vmcnt(0) is the only wait needed before it reads them back
@@ -247,6 +254,7 @@ __global__ __launch_bounds__(16 * TCOLS, 2) void deform_pack_kernel(const Deform
     if (!FUSE_OFF) nxt = load_om(om_my, 0, my_in);
     const float fy_base = (float)(my_y - 1), fx_base = (float)(px_x - 1);
     const float fy_max = (float)(H + 1), fx_max = (float)(W + 1);
+    DEFORM_STAMP(ts_converted);
     __syncthreads();  // hipcc drains the DMA (vmcnt(0)) ahead of the barrier
     DEFORM_STAMP(ts_window);
 
@@ -262,15 +270,11 @@ __global__ __launch_bounds__(16 * TCOLS, 2) void deform_pack_kernel(const Deform
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int i = 0; i < 16; ++i) omr[m][i] = p.off_bias[acc_channel(i, h)];
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            if (tap < 7) {  // two taps ahead (L2 latency is ~3 taps of MFMA time for one wave)
-#pragma unroll
-                for (int kg = 0; kg < KG; ++kg) ow[(tap + 2) % 3][kg] = *reinterpret_cast<const f16x8 *>(owl + ((tap + 2) * KG + kg) * 1024);
-            }
-            // keep the prefetch where it is written: left alone, hipcc sinks each load next to its MFMA to save registers
-            // (load -> vmcnt(0) -> MFMA: one L2 round trip per MFMA)
-            __builtin_amdgcn_sched_barrier(0);
+        // B operands of a tap: 2 rows x KG pieces, read one tap AHEAD of their MFMAs (double buffered; the DCN
+        // accumulators are not live yet, so the registers are free).  Unpipelined, every MFMA waited for its own
+        // ds_read: 125 cycles per MFMA.
+        u32x4_t xq[2][2][KG];
+        auto load_x = [&](int tap, u32x4_t (&dst)[2][KG]) {
             const int i = tap / 3, j = tap - 3 * i;
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
@@ -278,10 +282,26 @@ __global__ __launch_bounds__(16 * TCOLS, 2) void deform_pack_kernel(const Deform
 #pragma unroll
                 for (int kg = 0; kg < KG; ++kg) {
                     const int slot = (2 * kg + h < C::SP) ? 2 * kg + h : C::SP - 1;
-                    const f16x8 xv = __builtin_bit_cast(f16x8, lds_read16(xp + slot * 16));
-                    mma_kg(omr[m], ow[tap % 3][kg], xv);
+                    dst[m][kg] = lds_read16(xp + slot * 16);
                 }
             }
+        };
+        load_x(0, xq[0]);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap < 7) {  // weight fragments two taps ahead (L2 latency is ~3 taps of MFMA time for one wave)
+#pragma unroll
+                for (int kg = 0; kg < KG; ++kg) ow[(tap + 2) % 3][kg] = *reinterpret_cast<const f16x8 *>(owl + ((tap + 2) * KG + kg) * 1024);
+            }
+            if (tap < 8) load_x(tap + 1, xq[(tap + 1) & 1]);
+            // keep the prefetches where they are written: left alone, hipcc sinks each load next to its MFMA to save
+            // registers (load -> wait -> MFMA: one L2 / LDS round trip per MFMA)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int kg = 0; kg < KG; ++kg) mma_kg(omr[m], ow[tap % 3][kg], __builtin_bit_cast(f16x8, xq[tap & 1][m][kg]));
+            __builtin_amdgcn_sched_barrier(0);
         }
         // mask = sigmoid(third chunk), ema_vfi.py:59 (channels 18..26 after the pack-time routing)
 #pragma unroll
@@ -479,7 +499,10 @@ __global__ __launch_bounds__(16 * TCOLS, 2) void deform_pack_kernel(const Deform
         if (row < DEFORM_STAMP_ROWS) {
             unsigned long long *o = p.stamps + (size_t)row * 8;
             o[0] = ts_window - ts_begin; o[1] = ts_offconv - ts_window; o[2] = sum_geom; o[3] = sum_steps;
-            o[4] = ts_done - ts_loop; o[5] = ts_done - ts_begin; o[6] = 1; o[7] = ts_begin;
+            o[4] = ts_done - ts_loop; o[5] = ts_done - ts_begin; o[6] = 1;
+            // prologue detail packed into o[7]: 16 bits each (units of 4 cycles): issue, landed - issued, convert, barrier wait
+            auto q16 = [](unsigned long long v) { v >>= 2; return v > 0xffffull ? 0xffffull : v; };
+            o[7] = q16(ts_issued - ts_begin) | (q16(ts_landed - ts_issued) << 16) | (q16(ts_converted - ts_landed) << 32) | (q16(ts_window - ts_converted) << 48);
         }
     }
 #endif

@@ -94,8 +94,13 @@ bool deform16_lds_shape_host(int ck, int nf, int cin_real) { return ck == 80 && 
 constexpr int kMaxBlocks = 8;
 
 struct Plan {
-    int in_ch, mid, nb, dtype, esize;
+    int in_ch, mid, nb, dtype, esize;  // dtype = the KERNEL storage type (EMAVFI_AMP16 runs the f16 kernels)
+    bool amp;                          // EMAVFI_AMP16: autocast op policy (fp32 DCN on an fp32 fusion tensor, fp16 roundings)
+    Layer dcn32[kMaxBlocks];           // amp: the deformable convolutions' fp32 master weights
     int fpad, p_mid;  // padded fusion / feature widths
+    int fps;          // pixel stride (elements) of the fusion buffers: 72 when the 16-bit LDS-window pack serves them (the
+                      // only channels any consumer reads; 144-byte pixels instead of 160: -10 % HBM traffic on every tensor
+                      // the three packs and reconstruction.0 touch), else fpad
     Layer conv1, blk[kMaxBlocks], c0, c1, c2, m0, m1, m2, off[kMaxBlocks], dcn[kMaxBlocks], r0, r1, r2;
     Layer offh[kMaxBlocks];  // bf16 model at the reference width: second copy of offset_conv for the one-launch pack
     bool has_offh;
@@ -115,7 +120,12 @@ Layer mk(int param, int cout, int cin_raw, int stride = 1, int cin_off = 0, int 
 bool build_plan(Plan &P, int in_ch, int mid, int nb, int dtype)
 {
     P.why = "";
-    if (dtype != EMAVFI_F32 && dtype != EMAVFI_BF16 && dtype != EMAVFI_F16) { P.why = "dtype must be EMAVFI_F32, EMAVFI_BF16 or EMAVFI_F16"; return false; }
+    if (dtype != EMAVFI_F32 && dtype != EMAVFI_BF16 && dtype != EMAVFI_F16 && dtype != EMAVFI_AMP16) {
+        P.why = "dtype must be EMAVFI_F32, EMAVFI_BF16, EMAVFI_F16 or EMAVFI_AMP16";
+        return false;
+    }
+    P.amp = dtype == EMAVFI_AMP16;
+    if (P.amp) dtype = EMAVFI_F16;  // every convolution runs the f16 kernels; what differs is in forward_impl / pack
     // the reference's fusion width is the literal mid_channels + 3 (ema_vfi.py:97): with any other in_channels its
     // forward raises a channel mismatch at the first attention block, so this build refuses instead of padding / dropping
     if (in_ch != 3) { P.why = "in_channels must be 3 (the reference's fusion width is mid_channels + 3, ema_vfi.py:97)"; return false; }
@@ -159,6 +169,17 @@ bool build_plan(Plan &P, int in_ch, int mid, int nb, int dtype)
     // The one-launch pack kernel (deform_pack.inl) keeps its window in f16 on chip whatever the storage type: in a bf16
     // model its two weight sets are the bf16-rounded values stored as f16.  The stand-alone offset_conv (conv3x3, used
     // when the pack is not fused) still reads the bf16 copy.
+    P.fps = P.fpad;
+    if (ok && !P.amp && dtype != EMAVFI_F32 && nb > 0 && deform16_lds_shape_host(P.dcn[0].ck, P.dcn[0].nf, P.dcn[0].cin_take)) P.fps = 72;
+    if (ok && P.amp) {
+        for (int i = 0; i < nb && ok; ++i) {
+            P.dcn32[i] = mk(P.dcn[i].param, f, f);
+            ok = deform_geometry(P.dcn32[i], 4);
+            P.dcn32[i].w_off = o; o = rup256(o + P.dcn32[i].w_bytes);
+            P.dcn32[i].b_off = o; o = rup256(o + (size_t)P.dcn32[i].coutpad * sizeof(float));
+        }
+        if (!ok) { P.why = "no fp32 deformable-conv instantiation for these channel widths"; return false; }
+    }
     P.has_offh = false;
     if (ok && dtype == EMAVFI_BF16 && nb > 0 && deform16_lds_shape_host(P.dcn[0].ck, P.dcn[0].nf, P.dcn[0].cin_take)) {
         P.has_offh = true;
@@ -184,6 +205,10 @@ int run_conv(const Plan &P, const Layer &L, const void *packed, const void *in, 
              float *planar = nullptr, int nplanes = 0, const void *zeros = nullptr)
 {
     ConvParams c{};
+    // a single-chunk layer wider than its input's pixel stride (CK = 80 fed from the 72-channel fusion buffers) reads
+    // the missing pieces as zeros
+    if (L.nchunk == 1 && in_ps < L.ck) c.in_pieces = in_ps * P.esize / 16;
+    c.round16 = P.amp ? 1 : 0;
     c.zeros = zeros ? zeros : (const char *)packed + P.zero_off;
     c.in = in; c.out = out; c.out_planar = planar;
     c.w = (const char *)packed + L.w_off;
@@ -210,8 +235,9 @@ unsigned long long *debug_stamp_buffer()
 
 int run_deform(const Plan &P, const Layer &L, const void *packed, const void *x, int x_ps, float *om, void *out,
                int out_ps, int cstore, int B, int H, int W, hipStream_t s, const void *zeros = nullptr, const Layer *off = nullptr,
-               const void *x_tail = nullptr, int tail_ps = 0)
+               const void *x_tail = nullptr, int tail_ps = 0, int force_dtype = -1)
 {
+    const int kd = force_dtype >= 0 ? force_dtype : P.dtype;
     DeformParams d{};
     d.x = x; d.om = om; d.out = out;
     d.x_tail = x_tail; d.tail_ps = tail_ps;
@@ -226,12 +252,12 @@ int run_deform(const Plan &P, const Layer &L, const void *packed, const void *x,
 #if defined(EMAVFI_DEFORM_STAMPS) && EMAVFI_DEFORM_STAMPS
     d.stamps = debug_stamp_buffer();
 #endif
-    return P.dtype == EMAVFI_F32 ? launch_deform_f32(d, s) : P.dtype == EMAVFI_F16 ? launch_deform_f16(d, s) : launch_deform_bf16(d, s);
+    return kd == EMAVFI_F32 ? launch_deform_f32(d, s) : kd == EMAVFI_F16 ? launch_deform_f16(d, s) : launch_deform_bf16(d, s);
 }
 
-int pack_layer(const Layer &L, const void *const *params, void *packed, int dtype, hipStream_t s)
+int pack_layer(const Layer &L, const void *const *params, void *packed, int dtype, hipStream_t s, bool bias_f16 = false)
 {
-    PackDesc d{L.cout, L.cin_raw, L.cin_off, L.cin_take, L.ck, L.nchunk, L.nf, L.npass, L.perm, L.f16_of_bf16 ? 1 : 0};
+    PackDesc d{L.cout, L.cin_raw, L.cin_off, L.cin_take, L.ck, L.nchunk, L.nf, L.npass, L.perm, L.f16_of_bf16 ? 1 : 0, bias_f16 ? 1 : 0};
     return launch_pack_conv((const float *)params[L.param], (const float *)params[L.param + 1], (char *)packed + L.w_off,
                             (float *)((char *)packed + L.b_off), d, L.f16_of_bf16 ? (int)EMAVFI_F16 : dtype, s);
 }
@@ -243,6 +269,7 @@ struct Workspace {
 
 struct FwdBuffers {
     void *in16, *fA, *fB, *fu0, *fu1, *c1, *c2, *c3;
+    float *fuF0, *fuF1;  // amp: fp32 copies of the fusion tensor (input / output of the fp32 DCN)
     float *part, *ctx, *table, *flow, *om;
     int nparts, H2, W2, H4, W4, p2, p4, p_half;
 };
@@ -257,8 +284,8 @@ void carve_forward(const Plan &P, Workspace &ws, FwdBuffers &f, int B, int H, in
     f.in16 = ws.take(px * 16 * e);
     f.fA = ws.take(px * P.p_mid * e);
     f.fB = ws.take(px * P.p_mid * e);
-    f.fu0 = ws.take(px * P.fpad * e);
-    f.fu1 = ws.take(px * P.fpad * e);
+    f.fu0 = ws.take(px * P.fps * e);
+    f.fu1 = ws.take(px * P.fps * e);
     f.c1 = ws.take((size_t)B * f.H2 * f.W2 * f.p2 * e);
     f.c2 = ws.take((size_t)B * npix4 * f.p4 * e);
     f.c3 = ws.take((size_t)B * npix4 * f.p4 * e);
@@ -267,6 +294,11 @@ void carve_forward(const Plan &P, Workspace &ws, FwdBuffers &f, int B, int H, in
     f.table = (float *)ws.take((size_t)B * 16 * P.m0.coutpad * sizeof(float));
     f.flow = (float *)ws.take(px * 2 * sizeof(float));
     f.om = (float *)ws.take(px * 32 * sizeof(float));
+    f.fuF0 = f.fuF1 = nullptr;
+    if (P.amp) {
+        f.fuF0 = (float *)ws.take(px * P.fpad * sizeof(float));
+        f.fuF1 = (float *)ws.take(px * P.fpad * sizeof(float));
+    }
 }
 
 // ---- launch recorder: names every kernel launch of a forward, its algorithmic work, and can
@@ -328,6 +360,7 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
 {
     Plan P;
     if (!build_plan(P, in_channels, mid_channels, num_blocks, dtype)) return fail(EMAVFI_E_UNSUPPORTED, "%s", P.why);
+    dtype = P.dtype;  // the kernel storage type from here on (EMAVFI_AMP16 -> EMAVFI_F16, with P.amp set)
     if (B < 1 || H < 1 || W < 1) return fail(EMAVFI_E_ARG, "forward: B, H, W must be >= 1 (got %d, %d, %d)", B, H, W);
     if ((size_t)B * H * W >= ((size_t)1 << 31)) return fail(EMAVFI_E_ARG, "forward: B*H*W must be < 2^31");
     if ((size_t)H * W * P.fpad * P.esize >= ((size_t)1 << 32)) return fail(EMAVFI_E_ARG, "forward: one sample's activation plane must be < 4 GiB");
@@ -358,15 +391,15 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
         void *dst = last ? f.fu0 : nxt;
         conv_work(P, P.blk[i], B, H, W, e, fl, by);
         EMAVFI_STEP(rec, conv_name(P, P.blk[i]) + " feat_ext_blocks", fl, by,
-                    run_conv(P, P.blk[i], packed, cur, P.p_mid, H, W, dst, last ? P.fpad : P.p_mid, 0, P.p_mid, EPI_RELU, B, s));
+                    run_conv(P, P.blk[i], packed, cur, P.p_mid, H, W, dst, last ? P.fps : P.p_mid, 0, P.p_mid, EPI_RELU, B, s));
         if (!last) { void *t = cur; cur = nxt; nxt = t; }
     }
-    if (!rec.dry && taps && taps[0]) EMAVFI_TRY(launch_cl_to_nchw(f.fu0, taps[0], B, mid, H, W, P.fpad, 0, dtype, s), "tap feat");
+    if (!rec.dry && taps && taps[0]) EMAVFI_TRY(launch_cl_to_nchw(f.fu0, taps[0], B, mid, H, W, P.fps, 0, dtype, s), "tap feat");
 
     // --- context encoding (ema_vfi.py:120): two stride-2 convs, one conv, global mean, linear
     conv_work(P, P.c0, B, H, W, e, fl, by);
     EMAVFI_STEP(rec, conv_name(P, P.c0) + " context_encoding.0", fl, by,
-                run_conv(P, P.c0, packed, f.fu0, P.fpad, H, W, f.c1, f.p2, 0, f.p2, EPI_RELU, B, s));
+                run_conv(P, P.c0, packed, f.fu0, P.fps, H, W, f.c1, f.p2, 0, f.p2, EPI_RELU, B, s));
     conv_work(P, P.c1, B, f.H2, f.W2, e, fl, by);
     EMAVFI_STEP(rec, conv_name(P, P.c1) + " context_encoding.1", fl, by,
                 run_conv(P, P.c1, packed, f.c1, f.p2, f.H2, f.W2, f.c2, f.p4, 0, f.p4, EPI_RELU, B, s));
@@ -377,7 +410,7 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
                 launch_pool_partial(f.c3, f.part, B, f.H4 * f.W4, f.p4, f.p4, f.nparts, dtype, s));
     EMAVFI_STEP(rec, "context_linear_fold", 0, (double)B * f.nparts * 4 * mid * 4,
                 launch_ctx_finish(f.part, (const float *)((const char *)packed + P.ctx_off), f.ctx, f.table, B, mid, f.p4,
-                                  f.nparts, f.H4 * f.W4, P.m0.coutpad, s));
+                                  f.nparts, f.H4 * f.W4, P.m0.coutpad, P.amp ? 1 : 0, s));
     if (!rec.dry && taps && taps[1])
         if (hipMemcpyAsync(taps[1], f.ctx, (size_t)B * mid * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
             return fail(EMAVFI_E_LAUNCH, "tap ctx copy failed");
@@ -385,7 +418,7 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
     // --- motion estimation (ema_vfi.py:124-126); the broadcast-context concat is a per-border-class bias
     conv_work(P, P.m0, B, H, W, e, fl, by);
     EMAVFI_STEP(rec, conv_name(P, P.m0) + " motion_estimation.0(ctx folded)", fl, by,
-                run_conv(P, P.m0, packed, f.fu0, P.fpad, H, W, f.fA, P.p_mid, 0, P.p_mid, EPI_RELU, B, s, f.table));
+                run_conv(P, P.m0, packed, f.fu0, P.fps, H, W, f.fA, P.p_mid, 0, P.p_mid, EPI_RELU, B, s, f.table));
     conv_work(P, P.m1, B, H, W, e, fl, by);
     EMAVFI_STEP(rec, conv_name(P, P.m1) + " motion_estimation.1", fl, by,
                 run_conv(P, P.m1, packed, f.fA, P.p_mid, H, W, f.fB, P.p_mid, 0, P.p_mid, EPI_RELU, B, s));
@@ -396,55 +429,81 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
         if (hipMemcpyAsync(taps[2], f.flow, npx * 2 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
             return fail(EMAVFI_E_LAUNCH, "tap flow copy failed");
 
-    // --- warp frame2 by the flow into channels [mid, fpad) of the fusion buffer (ema_vfi.py:130,134).
-    // When the first pack runs as the one-launch LDS kernel, those 16 channels go to a compact buffer of their own
-    // (8 channels = 16 bytes per pixel, in the packed-input buffer, free since conv1) and the kernel's window DMA picks
-    // them up from there: contiguous 16-byte pixels instead of 6 useful bytes scattered into every 160-byte fusion pixel.
-    auto pack_fuses = [&](int i) {
-        return dtype != EMAVFI_F32 && P.off[i].nchunk == 1 && P.off[i].npass == 1 && P.off[i].stride == 1 &&
-               deform16_can_fuse_offset_conv(P.dcn[i].ck, P.dcn[i].nf, P.dcn[i].cin_take, P.off[i].ck, P.off[i].nf);
-    };
-    const bool split_tail = P.nb > 0 && pack_fuses(0) && P.fpad - mid == 16;
-    EMAVFI_STEP(rec, std::string("warp_fused<") + dtype_name(dtype) + ">", 24.0 * px, px * (8.0 + 4.0 * C + C * e),
-                split_tail ? launch_warp_fused(frame2, f.flow, f.in16, B, C, H, W, 8, 0, dtype, s)
-                           : launch_warp_fused(frame2, f.flow, f.fu0, B, C, H, W, P.fpad, mid, dtype, s));
-    if (!rec.dry && taps && taps[3])
-        EMAVFI_TRY(split_tail ? launch_cl_to_nchw(f.in16, taps[3], B, C, H, W, 8, 0, dtype, s)
-                              : launch_cl_to_nchw(f.fu0, taps[3], B, C, H, W, P.fpad, mid, dtype, s), "tap warped");
-
-    // --- multi-attention fusion: num_blocks x ModulatedDeformConvPack, no activation (ema_vfi.py:136-138)
     void *x = f.fu0, *y = f.fu1;
-    for (int i = 0; i < P.nb; ++i) {
-        conv_work(P, P.off[i], B, H, W, 4.0, fl, by);
+    if (P.amp) {
+        // --- EMAVFI_AMP16: the autocast op policy for ema_vfi.py:130-138.  grid_sample runs in fp32 on the fp16-valued
+        // flow and cat(feat, warped) promotes to fp32, so the fusion tensor exists twice: fp32 (fuF: what the fp32
+        // deform_conv2d reads and writes, never rounded between blocks) and its fp16 rounding (fu: what the fp16
+        // offset_conv / reconstruction.0 read).
         const double cf = mid + 3;
-        const bool fused = pack_fuses(i);
-        if (fused) {
-            // one launch for the whole pack (ema_vfi.py:54-60): offset_conv on the staged window, then the DCN;
-            // the input is read once and the offsets / masks never leave the registers
-            EMAVFI_STEP(rec, deform_name(P, P.dcn[i]) + " offset_conv+dcn_v2", fl + 2.0 * 9.0 * cf * cf * px,
-                        px * (2.0 * cf * e) + 9.0 * cf * (cf + 27.0) * e,
-                        // a pack whose consumer is another one-launch pack stores 72 channels (9 sixteen-byte slots = all
-                        // its consumer's window DMA reads); the last pack feeds reconstruction.0, which reads all fpad
-                        run_deform(P, P.dcn[i], packed, x, P.fpad, f.om, y, P.fpad,
-                                   (i + 1 < P.nb && pack_fuses(i + 1) && P.fpad == 80) ? 72 : P.fpad, B, H, W, s, nullptr,
-                                   P.has_offh ? &P.offh[i] : &P.off[i],
-                                   i == 0 && split_tail ? f.in16 : nullptr, 8));
-        } else {
+        float *xF = f.fuF0, *yF = f.fuF1;
+        EMAVFI_STEP(rec, "warp_fused<f32>", 24.0 * px, px * (8.0 + 8.0 * C),
+                    launch_warp_fused(frame2, f.flow, xF, B, C, H, W, P.fpad, mid, EMAVFI_F32, s));
+        EMAVFI_STEP(rec, "fusion_widen_feat", 0, px * mid * 6.0, launch_convert_cl(f.fu0, xF, npx, P.fps, P.fpad, 0, P.p_mid, 1, s));
+        EMAVFI_STEP(rec, "fusion_round_warped", 0, px * 16 * 6.0, launch_convert_cl(xF, f.fu0, npx, P.fpad, P.fps, mid, P.fpad - mid, 0, s));
+        if (!rec.dry && taps && taps[3])
+            EMAVFI_TRY(launch_cl_to_nchw(xF, taps[3], B, C, H, W, P.fpad, mid, EMAVFI_F32, s), "tap warped");
+        for (int i = 0; i < P.nb; ++i) {
+            conv_work(P, P.off[i], B, H, W, 4.0, fl, by);
             EMAVFI_STEP(rec, conv_name(P, P.off[i]) + " offset_conv", fl, by,
-                        run_conv(P, P.off[i], packed, x, P.fpad, H, W, f.om, 32, 0, 32, EPI_OM, B, s));
-            EMAVFI_STEP(rec, deform_name(P, P.dcn[i]) + " dcn_v2", 2.0 * 9.0 * cf * cf * px,
-                        px * (2.0 * cf * e + 27.0 * 4.0) + 9.0 * cf * cf * e,
-                        run_deform(P, P.dcn[i], packed, x, P.fpad, f.om, y, P.fpad, P.fpad, B, H, W, s));
+                        run_conv(P, P.off[i], packed, x, P.fps, H, W, f.om, 32, 0, 32, EPI_OM, B, s));
+            EMAVFI_STEP(rec, "deform<f32,ck=80,nf=3> dcn_v2 (fp32 under autocast)", 2.0 * 9.0 * cf * cf * px,
+                        px * (2.0 * cf * 4.0 + 27.0 * 4.0) + 9.0 * cf * cf * 4.0,
+                        run_deform(P, P.dcn32[i], packed, xF, P.fpad, f.om, yF, P.fpad, P.fpad, B, H, W, s, nullptr, nullptr, nullptr, 0,
+                                   EMAVFI_F32));
+            EMAVFI_STEP(rec, "fusion_round", 0, px * cf * 6.0, launch_convert_cl(yF, y, npx, P.fpad, P.fps, 0, P.fpad, 0, s));
+            if (!rec.dry && taps && taps[5 + i])
+                EMAVFI_TRY(launch_cl_to_nchw(yF, taps[5 + i], B, mid + 3, H, W, P.fpad, 0, EMAVFI_F32, s), "tap fused");
+            void *t = x; x = y; y = t;
+            float *tf = xF; xF = yF; yF = tf;
         }
-        if (!rec.dry && taps && taps[5 + i])
-            EMAVFI_TRY(launch_cl_to_nchw(y, taps[5 + i], B, mid + 3, H, W, P.fpad, 0, dtype, s), "tap fused");
-        void *t = x; x = y; y = t;
+    } else {
+        // --- warp frame2 by the flow into channels [mid, fpad) of the fusion buffer (ema_vfi.py:130,134).
+        // When the first pack runs as the one-launch LDS kernel, those 16 channels go to a compact buffer of their own
+        // (8 channels = 16 bytes per pixel, in the packed-input buffer, free since conv1) and the kernel's window DMA picks
+        // them up from there: contiguous 16-byte pixels instead of 6 useful bytes scattered into every 160-byte fusion pixel.
+        auto pack_fuses = [&](int i) {
+            return dtype != EMAVFI_F32 && P.off[i].nchunk == 1 && P.off[i].npass == 1 && P.off[i].stride == 1 &&
+                   deform16_can_fuse_offset_conv(P.dcn[i].ck, P.dcn[i].nf, P.dcn[i].cin_take, P.off[i].ck, P.off[i].nf);
+        };
+        const bool split_tail = P.nb > 0 && pack_fuses(0) && P.fpad - mid == 16;
+        EMAVFI_STEP(rec, std::string("warp_fused<") + dtype_name(dtype) + ">", 24.0 * px, px * (8.0 + 4.0 * C + C * e),
+                    split_tail ? launch_warp_fused(frame2, f.flow, f.in16, B, C, H, W, 8, 0, dtype, s)
+                               : launch_warp_fused(frame2, f.flow, f.fu0, B, C, H, W, P.fps, mid, dtype, s));
+        if (!rec.dry && taps && taps[3])
+            EMAVFI_TRY(split_tail ? launch_cl_to_nchw(f.in16, taps[3], B, C, H, W, 8, 0, dtype, s)
+                                  : launch_cl_to_nchw(f.fu0, taps[3], B, C, H, W, P.fps, mid, dtype, s), "tap warped");
+
+        // --- multi-attention fusion: num_blocks x ModulatedDeformConvPack, no activation (ema_vfi.py:136-138)
+        for (int i = 0; i < P.nb; ++i) {
+            conv_work(P, P.off[i], B, H, W, 4.0, fl, by);
+            const double cf = mid + 3;
+            const bool fused = pack_fuses(i);
+            if (fused) {
+                // one launch for the whole pack (ema_vfi.py:54-60): offset_conv on the staged window, then the DCN;
+                // the input is read once and the offsets / masks never leave the registers
+                EMAVFI_STEP(rec, deform_name(P, P.dcn[i]) + " offset_conv+dcn_v2", fl + 2.0 * 9.0 * cf * cf * px,
+                            px * (2.0 * cf * e) + 9.0 * cf * (cf + 27.0) * e,
+                            run_deform(P, P.dcn[i], packed, x, P.fps, f.om, y, P.fps, P.fps, B, H, W, s, nullptr,
+                                       P.has_offh ? &P.offh[i] : &P.off[i],
+                                       i == 0 && split_tail ? f.in16 : nullptr, 8));
+            } else {
+                EMAVFI_STEP(rec, conv_name(P, P.off[i]) + " offset_conv", fl, by,
+                            run_conv(P, P.off[i], packed, x, P.fps, H, W, f.om, 32, 0, 32, EPI_OM, B, s));
+                EMAVFI_STEP(rec, deform_name(P, P.dcn[i]) + " dcn_v2", 2.0 * 9.0 * cf * cf * px,
+                            px * (2.0 * cf * e + 27.0 * 4.0) + 9.0 * cf * cf * e,
+                            run_deform(P, P.dcn[i], packed, x, P.fps, f.om, y, P.fps, P.fps, B, H, W, s));
+            }
+            if (!rec.dry && taps && taps[5 + i])
+                EMAVFI_TRY(launch_cl_to_nchw(y, taps[5 + i], B, mid + 3, H, W, P.fps, 0, dtype, s), "tap fused");
+            void *t = x; x = y; y = t;
+        }
     }
 
     // --- reconstruction (ema_vfi.py:144-146)
     conv_work(P, P.r0, B, H, W, e, fl, by);
     EMAVFI_STEP(rec, conv_name(P, P.r0) + " reconstruction.0", fl, by,
-                run_conv(P, P.r0, packed, x, P.fpad, H, W, f.fA, P.p_mid, 0, P.p_mid, EPI_RELU, B, s));
+                run_conv(P, P.r0, packed, x, P.fps, H, W, f.fA, P.p_mid, 0, P.p_mid, EPI_RELU, B, s));
     conv_work(P, P.r1, B, H, W, e, fl, by);
     EMAVFI_STEP(rec, conv_name(P, P.r1) + " reconstruction.1", fl, by,
                 run_conv(P, P.r1, packed, f.fA, P.p_mid, H, W, f.fB, f.p_half, 0, f.p_half, EPI_RELU, B, s));
@@ -502,25 +561,28 @@ int emavfi_pack_weights(int in_channels, int mid_channels, int num_blocks, const
     if (packed_bytes < P.total) return fail(EMAVFI_E_WORKSPACE, "pack_weights: need %zu bytes, got %zu", P.total, packed_bytes);
     if (!aligned16(packed)) return fail(EMAVFI_E_ARG, "pack_weights: packed buffer must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    EMAVFI_TRY(pack_layer(P.conv1, params, packed, dtype, s), "pack conv1");
-    for (int i = 0; i < P.nb; ++i) EMAVFI_TRY(pack_layer(P.blk[i], params, packed, dtype, s), "pack feat block");
-    EMAVFI_TRY(pack_layer(P.c0, params, packed, dtype, s), "pack ctx0");
-    EMAVFI_TRY(pack_layer(P.c1, params, packed, dtype, s), "pack ctx1");
-    EMAVFI_TRY(pack_layer(P.c2, params, packed, dtype, s), "pack ctx2");
-    EMAVFI_TRY(pack_layer(P.m0, params, packed, dtype, s), "pack motion0");
-    EMAVFI_TRY(pack_layer(P.m1, params, packed, dtype, s), "pack motion1");
-    EMAVFI_TRY(pack_layer(P.m2, params, packed, dtype, s), "pack motion2");
+    dtype = P.dtype;            // kernel storage type (EMAVFI_AMP16 -> EMAVFI_F16)
+    const bool b16 = P.amp;     // autocast casts a convolution's bias to fp16 as well
+    EMAVFI_TRY(pack_layer(P.conv1, params, packed, dtype, s, b16), "pack conv1");
+    for (int i = 0; i < P.nb; ++i) EMAVFI_TRY(pack_layer(P.blk[i], params, packed, dtype, s, b16), "pack feat block");
+    EMAVFI_TRY(pack_layer(P.c0, params, packed, dtype, s, b16), "pack ctx0");
+    EMAVFI_TRY(pack_layer(P.c1, params, packed, dtype, s, b16), "pack ctx1");
+    EMAVFI_TRY(pack_layer(P.c2, params, packed, dtype, s, b16), "pack ctx2");
+    EMAVFI_TRY(pack_layer(P.m0, params, packed, dtype, s, b16), "pack motion0");
+    EMAVFI_TRY(pack_layer(P.m1, params, packed, dtype, s, b16), "pack motion1");
+    EMAVFI_TRY(pack_layer(P.m2, params, packed, dtype, s, b16), "pack motion2");
     for (int i = 0; i < P.nb; ++i) {
-        EMAVFI_TRY(pack_layer(P.off[i], params, packed, dtype, s), "pack offset_conv");
+        EMAVFI_TRY(pack_layer(P.off[i], params, packed, dtype, s, b16), "pack offset_conv");
         if (P.has_offh) EMAVFI_TRY(pack_layer(P.offh[i], params, packed, dtype, s), "pack offset_conv (f16 fragments)");
         EMAVFI_TRY(pack_layer(P.dcn[i], params, packed, dtype, s), "pack dcn_v2");
+        if (P.amp) EMAVFI_TRY(pack_layer(P.dcn32[i], params, packed, EMAVFI_F32, s), "pack dcn_v2 (fp32 master weights)");
     }
-    EMAVFI_TRY(pack_layer(P.r0, params, packed, dtype, s), "pack recon0");
-    EMAVFI_TRY(pack_layer(P.r1, params, packed, dtype, s), "pack recon1");
-    EMAVFI_TRY(pack_layer(P.r2, params, packed, dtype, s), "pack recon2");
+    EMAVFI_TRY(pack_layer(P.r0, params, packed, dtype, s, b16), "pack recon0");
+    EMAVFI_TRY(pack_layer(P.r1, params, packed, dtype, s, b16), "pack recon1");
+    EMAVFI_TRY(pack_layer(P.r2, params, packed, dtype, s, b16), "pack recon2");
     EMAVFI_TRY(launch_pack_ctx((const float *)params[P.lin_param], (const float *)params[P.lin_param + 1],
                                (const float *)params[P.m0.param], (const float *)params[P.m0.param + 1],
-                               (float *)((char *)packed + P.ctx_off), P.mid, s),
+                               (float *)((char *)packed + P.ctx_off), P.mid, P.amp ? 1 : 0, s),
                "pack context");
     if (hipMemsetAsync((char *)packed + P.zero_off, 0, 256, s) != hipSuccess) return fail(EMAVFI_E_LAUNCH, "pack: zero page memset failed");
     return EMAVFI_OK;

@@ -10,17 +10,21 @@ struct PackDesc {
     int perm;                              // 0 = identity, 1 = offset_conv routing (offsets | mask)
     int via_bf16;                          // 1 = round every weight to bf16 first, then store it in the packed type
                                            // (f16 fragments holding the bf16 model's weights exactly: deform_pack.inl)
+    int bias_f16;                          // 1 = the fp32 bias table holds fp16-rounded values (autocast casts the bias too)
 };
 
 int launch_pack_conv(const float *w, const float *bias, void *wp, float *bp, const PackDesc &d, int dtype, hipStream_t s);
-int launch_pack_ctx(const float *lin_w, const float *lin_b, const float *w9, const float *b9, float *dst, int m, hipStream_t s);
+int launch_pack_ctx(const float *lin_w, const float *lin_b, const float *w9, const float *b9, float *dst, int m, int round16,
+                    hipStream_t s);
+// channels-last conversion of channels [c0, c0 + nc) of every pixel (nc % 4 == 0): fp16 -> fp32 (widen) or fp32 -> fp16
+int launch_convert_cl(const void *src, void *dst, size_t npx, int ps_src, int ps_dst, int c0, int nc, int widen, hipStream_t s);
 int launch_pack_input(const float *f1, const float *f2, void *dst, int B, int C, int H, int W, int cpad, int dtype, hipStream_t s);
 int launch_nchw_to_cl(const float *src, void *dst, int B, int C, int H, int W, int ps, int dtype, hipStream_t s);
 int launch_cl_to_nchw(const void *src, float *dst, int B, int C, int H, int W, int ps, int coff, int dtype, hipStream_t s);
 int launch_om_from_nchw(const float *off, const float *msk, float *om, int B, int H, int W, hipStream_t s);
 int launch_pool_partial(const void *src, float *part, int B, int npix, int cp, int ps, int nparts, int dtype, hipStream_t s);
 int launch_ctx_finish(const float *part, const float *ctxw, float *ctx_out, float *table, int B, int m, int cp, int nparts,
-                      int npix, int coutpad, hipStream_t s);
+                      int npix, int coutpad, int round16, hipStream_t s);
 int launch_warp_nchw(const float *frame2, const float *flow, float *out, int B, int C, int H, int W, hipStream_t s);
 int launch_warp_fused(const float *frame2, const float *flow, void *dst, int B, int C, int H, int W, int ps, int coff, int dtype,
                       hipStream_t s);

@@ -64,7 +64,9 @@ __global__ void pack_conv_kernel(const float *__restrict__ w, const float *__res
     const int coutpad = d.npass * d.nf * 32;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < coutpad; i += gridDim.x * blockDim.x) {
         const int co = route_cout(i, d.perm);
-        bp[i] = (co < d.cout && bias) ? bias[co] : 0.0f;
+        float bv = (co < d.cout && bias) ? bias[co] : 0.0f;
+        if (d.bias_f16) bv = (float)(half_t)bv;
+        bp[i] = bv;
     }
 }
 
@@ -82,22 +84,25 @@ int launch_pack_conv(const float *w, const float *bias, void *wp, float *bp, con
 // raw fp32 copies the context kernels need: Linear weight/bias, the context half of
 // motion_estimation.0.0.weight as [o][c][tap], its bias.
 __global__ void pack_ctx_kernel(const float *__restrict__ lin_w, const float *__restrict__ lin_b,
-                                const float *__restrict__ w9, const float *__restrict__ b9, float *__restrict__ dst, int m)
+                                const float *__restrict__ w9, const float *__restrict__ b9, float *__restrict__ dst, int m, int round16)
 {
+    // round16: autocast casts Linear's and the convolution's weight and bias to fp16 (EMAVFI_AMP16)
+    const auto rq = [round16](float v) { return round16 ? (float)(half_t)v : v; };
     float *o_lw = dst, *o_lb = o_lw + (size_t)m * 4 * m, *o_w9 = o_lb + m, *o_b9 = o_w9 + (size_t)m * m * 9;
     const int n_lw = m * 4 * m, n_w9 = m * m * 9;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_lw + n_w9 + 2 * m; i += gridDim.x * blockDim.x) {
-        if (i < n_lw) o_lw[i] = lin_w[i];
-        else if (i < n_lw + m) o_lb[i - n_lw] = lin_b[i - n_lw];
+        if (i < n_lw) o_lw[i] = rq(lin_w[i]);
+        else if (i < n_lw + m) o_lb[i - n_lw] = rq(lin_b[i - n_lw]);
         else if (i < n_lw + m + n_w9) {
             const int k = i - n_lw - m, o = k / (m * 9), rem = k - o * m * 9, c = rem / 9, tap = rem - c * 9;
-            o_w9[k] = w9[((size_t)o * 2 * m + m + c) * 9 + tap];
-        } else o_b9[i - n_lw - m - n_w9] = b9[i - n_lw - m - n_w9];
+            o_w9[k] = rq(w9[((size_t)o * 2 * m + m + c) * 9 + tap]);
+        } else o_b9[i - n_lw - m - n_w9] = rq(b9[i - n_lw - m - n_w9]);
     }
 }
-int launch_pack_ctx(const float *lin_w, const float *lin_b, const float *w9, const float *b9, float *dst, int m, hipStream_t s)
+int launch_pack_ctx(const float *lin_w, const float *lin_b, const float *w9, const float *b9, float *dst, int m, int round16,
+                    hipStream_t s)
 {
-    pack_ctx_kernel<<<64, 256, 0, s>>>(lin_w, lin_b, w9, b9, dst, m);
+    pack_ctx_kernel<<<64, 256, 0, s>>>(lin_w, lin_b, w9, b9, dst, m, round16);
     return (int)hipGetLastError();
 }
 
@@ -179,6 +184,33 @@ int launch_cl_to_nchw(const void *src, float *dst, int B, int C, int H, int W, i
     return (int)hipGetLastError();
 }
 
+// EMAVFI_AMP16 keeps the fusion tensor twice: fp32 (what the fp32 DCN reads and writes) and fp16 (what the fp16
+// convolutions read).  One thread = 4 channels of one pixel.
+template <bool WIDEN>
+__global__ void convert_cl_kernel(const void *__restrict__ src, void *__restrict__ dst, size_t npx, int ps_src, int ps_dst, int c0, int nc)
+{
+    const int groups = nc / 4;
+    const size_t total = npx * groups;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t px = i / groups;
+        const int c = c0 + 4 * (int)(i - px * groups);
+        if (WIDEN) {
+            const f16x4 v = *reinterpret_cast<const f16x4 *>((const half_t *)src + px * ps_src + c);
+            *reinterpret_cast<f32x4 *>((float *)dst + px * ps_dst + c) = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+        } else {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>((const float *)src + px * ps_src + c);
+            *reinterpret_cast<f16x4 *>((half_t *)dst + px * ps_dst + c) = f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        }
+    }
+}
+int launch_convert_cl(const void *src, void *dst, size_t npx, int ps_src, int ps_dst, int c0, int nc, int widen, hipStream_t s)
+{
+    const int grid = (int)std::min<size_t>((npx * (nc / 4) + 255) / 256, 65535 * 4);
+    if (widen) convert_cl_kernel<true><<<grid, 256, 0, s>>>(src, dst, npx, ps_src, ps_dst, c0, nc);
+    else convert_cl_kernel<false><<<grid, 256, 0, s>>>(src, dst, npx, ps_src, ps_dst, c0, nc);
+    return (int)hipGetLastError();
+}
+
 // offset [B,18,H,W] + mask [B,9,H,W] (torchvision argument layout) -> om [px][32]
 __global__ void om_from_nchw_kernel(const float *__restrict__ off, const float *__restrict__ msk, float *__restrict__ om,
                                     int B, int H, int W)
@@ -240,8 +272,10 @@ int launch_pool_partial(const void *src, float *part, int B, int npix, int cp, i
 // cls = ym*4 + xm; bit0 of ym: row y-1 exists, bit1: row y+1 exists (same for xm / columns).
 __global__ __launch_bounds__(256) void ctx_finish_kernel(const float *__restrict__ part, const float *__restrict__ ctxw,
                                                          float *__restrict__ ctx_out, float *__restrict__ table,
-                                                         int m, int cp, int nparts, int npix, int coutpad)
+                                                         int m, int cp, int nparts, int npix, int coutpad, int round16)
 {
+    // round16 (EMAVFI_AMP16): the pooled mean and the Linear output are fp16 tensors under autocast
+    const auto rq = [round16](float v) { return round16 ? (float)(half_t)v : v; };
     extern __shared__ float sm[];
     float *mean = sm, *ctx = sm + 4 * m, *tsum = ctx + m;  // tsum [m][9]
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -249,12 +283,13 @@ __global__ __launch_bounds__(256) void ctx_finish_kernel(const float *__restrict
     for (int c = tid; c < 4 * m; c += 256) {
         float s = 0.0f;
         for (int q = 0; q < nparts; ++q) s += part[((size_t)b * nparts + q) * cp + c];
-        mean[c] = s / (float)npix;
+        mean[c] = rq(s / (float)npix);
     }
     __syncthreads();
     for (int o = tid; o < m; o += 256) {
         float s = lb[o];
         for (int c = 0; c < 4 * m; ++c) s = fmaf(lw[(size_t)o * 4 * m + c], mean[c], s);
+        s = rq(s);
         ctx[o] = s;
         ctx_out[(size_t)b * m + o] = s;
     }
@@ -284,10 +319,10 @@ __global__ __launch_bounds__(256) void ctx_finish_kernel(const float *__restrict
     }
 }
 int launch_ctx_finish(const float *part, const float *ctxw, float *ctx_out, float *table, int B, int m, int cp, int nparts,
-                      int npix, int coutpad, hipStream_t s)
+                      int npix, int coutpad, int round16, hipStream_t s)
 {
     const size_t sh = (size_t)(4 * m + m + 9 * m) * sizeof(float);
-    ctx_finish_kernel<<<B, 256, sh, s>>>(part, ctxw, ctx_out, table, m, cp, nparts, npix, coutpad);
+    ctx_finish_kernel<<<B, 256, sh, s>>>(part, ctxw, ctx_out, table, m, cp, nparts, npix, coutpad, round16);
     return (int)hipGetLastError();
 }
 

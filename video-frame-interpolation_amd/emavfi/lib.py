@@ -10,10 +10,12 @@ import os
 import threading
 from ctypes import c_int, c_size_t, c_void_p, c_char_p, POINTER
 
-F32, BF16, F16 = 0, 1, 2
+F32, BF16, F16, AMP16 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_TANH01 = 0, 1, 2
 DTYPES = {"fp32": F32, "f32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16,
-          "fp16": F16, "f16": F16, "float16": F16, "half": F16}
+          "fp16": F16, "f16": F16, "float16": F16, "half": F16,
+          # the reference's forward under torch.cuda.amp.autocast(), op policy restated (include/emavfi.h, EMAVFI_AMP16)
+          "amp16": AMP16, "autocast": AMP16, "autocast16": AMP16}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EMAVFI_LIB", os.path.join(_HERE, "lib", "libemavfi.so"))

@@ -91,12 +91,17 @@ class ModulatedDeformConvPack(nn.Module):
 
 
 class EMA_VFI(nn.Module):
-    """MI355X-native EMA-VFI.  ``compute_dtype``: ``"fp32"`` (parity mode: exact-fp32 MFMA,
-    <= 1e-3 max-abs vs the reference CPU forward), ``"bf16"`` (bf16 convs, fp32 warp / offsets /
-    accumulation; BASELINE.json configs[2]), ``"fp16"`` (the same data flow in IEEE half) or ``None`` =
-    fp32 unless autocast is active, then the autocast dtype: under the reference's own
-    ``torch.cuda.amp.autocast()`` (inference.py:159, float16 by default) the convolutions run in fp16 as
-    they would there, under ``torch.autocast("cuda", dtype=torch.bfloat16)`` in bf16."""
+    """MI355X-native EMA-VFI.  ``compute_dtype``:
+
+    * ``"fp32"``  parity mode: exact-fp32 MFMA, <= 1e-3 max-abs vs the reference CPU forward;
+    * ``"bf16"``  bf16 convolutions and tensors, fp32 warp / offsets / accumulation (BASELINE.json configs[2]);
+    * ``"fp16"``  the same data flow in IEEE half, deformable convolution included - the FAST half mode;
+    * ``"amp16"`` the reference's forward under ``torch.cuda.amp.autocast()`` (inference.py:159) with the autocast op
+      policy restated: fp16 Conv2d / Linear (weight and bias cast too), but ``grid_sample`` and torchvision's
+      ``deform_conv2d`` in fp32 on an fp32 fusion tensor with the fp32 master weights, fp16 roundings after
+      sigmoid / tanh / ``(t + 1) / 2``; returns an fp16 tensor as the reference does there;
+    * ``None``    fp32, unless autocast is active: ``torch.autocast("cuda", torch.float16)`` (the reference's own
+      ``torch.cuda.amp.autocast()``) selects ``"amp16"``, ``torch.autocast("cuda", torch.bfloat16)`` selects ``"bf16"``."""
 
     def __init__(self, in_channels=3, mid_channels=64, num_blocks=3, compute_dtype=None):
         super().__init__()
@@ -269,7 +274,7 @@ class EMA_VFI(nn.Module):
             return _lib.F32
         get = getattr(torch, "get_autocast_dtype", None)
         auto = get("cuda") if get is not None else torch.get_autocast_gpu_dtype()
-        return _lib.BF16 if auto == torch.bfloat16 else _lib.F16
+        return _lib.BF16 if auto == torch.bfloat16 else _lib.AMP16
 
     # ------------------------------------------------------------------ forward
     def forward(self, frame1, frame2, return_taps=False, _events=None):
@@ -318,7 +323,9 @@ class EMA_VFI(nn.Module):
                 _lib.check(L.emavfi_forward(C, self.mid_channels, self.num_blocks, packed.data_ptr(), f1.data_ptr(),
                                             f2.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, dt, taps_arg,
                                             _lib._stream()), "emavfi_forward")
-        out = out.to(frame1.dtype)
+        # under autocast the reference's reconstruction tail is fp16, so its frame is an fp16 tensor (the values computed
+        # here are fp16-representable: the conversion is exact)
+        out = out.half() if dt == _lib.AMP16 else out.to(frame1.dtype)
         if return_taps:
             taps["out"] = out
             return out, taps
