@@ -54,7 +54,8 @@ extern "C" {
 #define EMAVFI_F16 2
 /* The reference's forward under torch.cuda.amp.autocast() (inference.py:159), op policy restated: fp16 nn.Conv2d /
  * nn.Linear (input, weight AND bias cast to fp16, fp32 accumulation, fp16 result), fp16 tensors between those layers,
- * but grid_sample (ema_vfi.py:169) in fp32 on the fp16-valued flow and torchvision's deform_conv2d (ema_vfi.py:60)
+ * but grid_sample (ema_vfi.py:169; promotes to its widest argument, and frame2 and the grid are fp32) in fp32 on the
+ * fp16-valued flow and torchvision's deform_conv2d (ema_vfi.py:60)
  * in fp32 on the UNROUNDED fp32 fusion tensor with the fp32 master weights (its Autocast kernel casts every argument
  * to float and the result back to the input's dtype, which is fp32 because cat(feat, warped) promotes), offsets /
  * sigmoid(mask) as fp16 values, tanh and (t+1)/2 in fp16.  The frame holds fp16-representable values.

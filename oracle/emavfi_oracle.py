@@ -188,8 +188,9 @@ def forward(p: Params, frame1, frame2, num_blocks: int = 3, taps: Optional[dict]
 # The reference's forward under ``torch.cuda.amp.autocast()`` (float16), which is what ``inference.py:159`` runs on a
 # GPU.  Restated from PyTorch's published autocast op policy, NOT pinned by execution (the reference has never been
 # run on a GPU here): ``conv2d`` / ``linear`` are on the float16 list (inputs, weight AND bias are cast to fp16, the
-# products accumulate in fp32, the result is an fp16 tensor); ``grid_sampler`` is on the float32 list;
-# ``torch.cat`` and the ``grid + flow`` add promote to the widest input; element-wise ops without a list entry
+# products accumulate in fp32, the result is an fp16 tensor); ``grid_sampler``, ``torch.cat`` and the ``grid + flow``
+# add promote to the widest input - fp32 for all three here, because frame2, the pixel grid and ``warped`` are fp32
+# (ema_vfi.py:157-169, :134); element-wise ops without a list entry
 # (relu, sigmoid, tanh, ``+ 1``, ``/ 2``, adaptive_avg_pool2d) run in their input's dtype with fp32 op-math and one
 # rounding; torchvision registers ``deform_conv2d`` with an Autocast kernel that casts input, weight, offset, mask and
 # bias to fp32 and casts the result back to the INPUT's dtype.  Consequences along ema_vfi.py:110-147:

@@ -323,7 +323,7 @@ def test_forward_fp16_fast_mode_and_dtype_resolution():
 
 def test_autocast_op_policy_of_this_torch():
     """The per-op dtypes oracle.forward_autocast16 assumes, checked against the installed torch ON THE GPU (torch's own
-    autocast dispatch, not the reference): conv2d / linear -> fp16, grid_sample -> fp32, cat and fp32 + fp16 promote,
+    autocast dispatch, not the reference): conv2d / linear -> fp16, grid_sample / cat / fp32 + fp16 promote (fp32 here),
     sigmoid / tanh / pooling / scalar arithmetic keep fp16.  (torchvision is not installed: its deform_conv2d Autocast
     kernel - cast every argument to float, result back to the input's dtype - is restated, not checked.)"""
     x32 = torch.randn(1, 4, 8, 8, device=DEV)
@@ -339,7 +339,9 @@ def test_autocast_op_policy_of_this_torch():
         grid = torch.zeros(1, 8, 8, 2, device=DEV)
         assert F.grid_sample(x32, grid + y[:, :2].permute(0, 2, 3, 1), align_corners=True).dtype == torch.float32
         assert (grid + y[:, :2].permute(0, 2, 3, 1)).dtype == torch.float32
-        assert F.grid_sample(y, grid.half(), align_corners=True).dtype == torch.float32   # fp32-list op even on fp16 inputs
+        # grid_sampler is on autocast's PROMOTE list (widest input type): fp32 in the reference, whose frame2 and grid
+        # are both fp32 (ema_vfi.py:162-169); all-fp16 arguments would stay fp16
+        assert F.grid_sample(y, grid.half(), align_corners=True).dtype == torch.float16
         assert torch.cat([y, x32], dim=1).dtype == torch.float32
     # the cast of conv2d covers the bias: the result equals the fp16-rounded-operand convolution
     ref = F.conv2d(x32.half().float(), w.half().float(), bias.half().float(), padding=1).half()

@@ -32,6 +32,9 @@
 #ifndef EMAVFI_DEFORM_XCD_ORDER
 #define EMAVFI_DEFORM_XCD_ORDER 1   // 0: plain row-major tile order (A/B switch)
 #endif
+#ifndef EMAVFI_DEFORM_ABL_NO_WLOADS
+#define EMAVFI_DEFORM_ABL_NO_WLOADS 0  // timing-only ablation (wrong results): no weight-fragment loads after the first
+#endif
 
 // Diagnostic build only (-DEMAVFI_DEFORM_STAMPS=1; cdna_hip_programming.md section 7, in-kernel stamps): s_memtime at
 // the seams of the kernel, per-wave segment sums written to DeformParams::stamps (a buffer the diagnostic build of
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(16 * TCOLS, 2) void deform_pack_kernel(const Deform
         load_x(0, xq[0]);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            if (tap < 7) {  // weight fragments two taps ahead (L2 latency is ~3 taps of MFMA time for one wave)
+            if (tap < 7 && !EMAVFI_DEFORM_ABL_NO_WLOADS) {  // weight fragments two taps ahead (L2 latency is ~3 taps of MFMA time for one wave)
 #pragma unroll
                 for (int kg = 0; kg < KG; ++kg) ow[(tap + 2) % 3][kg] = *reinterpret_cast<const f16x8 *>(owl + ((tap + 2) * KG + kg) * 1024);
             }
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(16 * TCOLS, 2) void deform_pack_kernel(const Deform
         for (int sidx = 0; sidx < 2 * KG; ++sidx) {
             if (sidx + 1 < 2 * KG) gather(sidx + 1, vb[(sidx + 1) & 1]);
             const int kg = sidx >> 1, m = sidx & 1;
-            if (m == 0) {  // fetch the next k-group's fragments (or the next tap's first) while this one is used
+            if (m == 0 && !EMAVFI_DEFORM_ABL_NO_WLOADS) {  // fetch the next k-group's fragments (or the next tap's first) while this one is used
                 if (kg + 1 < KG) {
 #pragma unroll
                     for (int n = 0; n < NF; ++n) wq[(kg + 1) & 1][n] = *reinterpret_cast<const f16x8 *>(wtap + ((kg + 1) * NF + n) * 1024);
@@ -524,8 +527,10 @@ template <typename TS, int TCOLS, int R, bool FUSE_OFF, int TQ> static int launc
     return (int)hipGetLastError();
 }
 
+// tile width: 16 = two 4-wave workgroups per CU (one's prologue / epilogue beside the other's main loop): measured 3 %
+// faster than 32 (one 8-wave workgroup per CU) at B=8 x 720p in both 16-bit types, at equal HBM traffic
 #ifndef EMAVFI_DEFORM_TCOLS
-#define EMAVFI_DEFORM_TCOLS 32
+#define EMAVFI_DEFORM_TCOLS 16
 #endif
 // the reference width (mid_channels 64 -> 67 channels, k-groups to 80): LDS-staged window of 72 channels
 static inline bool deform16_lds_shape(int ck, int nf, int cin_real) { return ck == 80 && nf == 3 && cin_real <= 72; }

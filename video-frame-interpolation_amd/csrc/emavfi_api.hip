@@ -6,6 +6,7 @@
 #include "misc_kernels.h"
 
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -31,12 +32,17 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 // ---- which (CK, NF, stride) / (CK, NF) instantiations exist (keep in sync with the .inl lists) ----
 const int kConvInst[][3] = {{16, 1, 1}, {16, 2, 1}, {32, 1, 1}, {48, 1, 1}, {64, 1, 1}, {64, 2, 1},
                             {64, 4, 1}, {80, 1, 1}, {80, 2, 1}, {16, 1, 2}, {32, 2, 2}, {32, 4, 2}};
+// 16-bit types only (the fp32 tiles would not fit the LDS): stride-2 layers with 64-channel chunks
+const int kConvInst16[][3] = {{64, 4, 2}, {64, 8, 2}};
 const int kDeformInst[][2] = {{16, 1}, {32, 1}, {48, 2}, {80, 3}};
 
-bool conv_inst_exists(int ck, int nf, int st)
+bool conv_inst_exists(int ck, int nf, int st, int esize)
 {
     for (auto &i : kConvInst)
         if (i[0] == ck && i[1] == nf && i[2] == st) return true;
+    if (esize == 2)
+        for (auto &i : kConvInst16)
+            if (i[0] == ck && i[1] == nf && i[2] == st) return true;
     return false;
 }
 
@@ -53,20 +59,38 @@ struct Layer {
 bool conv_geometry(Layer &L, int esize)
 {
     L.cin_pad = rup(L.cin_take, 16);
-    if (L.stride == 2) L.ck = (L.cin_pad % 32 == 0) ? 32 : 16;
+    // Stride-2 layers: 32-channel chunks, two workgroups per CU.  PMC shows 2.6 GB of HBM reads per launch for 0.7 GB of
+    // input: a pixel's record is fetched in 64-byte quarters several microseconds apart (chunk loop) and once per output
+    // pass, each time a whole 128-byte line.  The plan that reads every record once - 64-channel chunks, all output
+    // channels in one pass (EMAVFI_CONV_S2_CK64=1, 16-bit types) - needs a 85 KiB tile + 32-64 KiB of weights, i.e. one
+    // 4-wave workgroup per CU, and measured SLOWER (64->128: 757 vs 513 us, 128->256: 534 vs 513 us at B=8 x 720p):
+    // these layers are not bound by the over-fetch but by how little of a tile's DMA / MFMA / store phases one
+    // workgroup per CU can overlap.  Kept as an experiment switch, not the default.
+    static const bool s2_ck64 = getenv("EMAVFI_CONV_S2_CK64") != nullptr;
+    const bool s2_wide = L.stride == 2 && esize == 2 && L.cin_pad % 64 == 0 && s2_ck64;
+    if (s2_wide) L.ck = 64;
+    else if (L.stride == 2) L.ck = (L.cin_pad % 32 == 0) ? 32 : 16;
     else if (L.cin_pad <= 80) L.ck = L.cin_pad;
     else if (L.cin_pad % 64 == 0) L.ck = 64;
     else return false;
     L.nchunk = L.cin_pad / L.ck;
     const int frags = (L.cout + 31) / 32;
     L.nf = (frags % 4 == 0) ? 4 : (frags % 2 == 0) ? 2 : 1;
+    if (s2_wide && frags % 8 == 0) L.nf = 8;
     if (L.stride == 2 && L.ck == 16) L.nf = 1;
     if (L.stride == 2 && L.ck == 32 && L.nf == 1) { L.ck = 16; L.nchunk = L.cin_pad / 16; }
     L.npass = frags / L.nf;
     L.coutpad = frags * 32;
     // fall back to narrower fragments if the preferred width has no instantiation
-    while (!conv_inst_exists(L.ck, L.nf, L.stride) && L.nf > 1) { L.nf /= 2; L.npass = frags / L.nf; }
-    if (!conv_inst_exists(L.ck, L.nf, L.stride)) return false;
+    while (!conv_inst_exists(L.ck, L.nf, L.stride, esize) && L.nf > 1) { L.nf /= 2; L.npass = frags / L.nf; }
+    if (!conv_inst_exists(L.ck, L.nf, L.stride, esize) && s2_wide) {  // e.g. 64 -> 32 stride 2: back to the 32-channel plan
+        L.ck = 32; L.nchunk = L.cin_pad / 32;
+        L.nf = (frags % 4 == 0) ? 4 : (frags % 2 == 0) ? 2 : 1;
+        if (L.nf == 1) { L.ck = 16; L.nchunk = L.cin_pad / 16; }
+        L.npass = frags / L.nf;
+        while (!conv_inst_exists(L.ck, L.nf, L.stride, esize) && L.nf > 1) { L.nf /= 2; L.npass = frags / L.nf; }
+    }
+    if (!conv_inst_exists(L.ck, L.nf, L.stride, esize)) return false;
     L.w_bytes = (size_t)L.npass * L.nchunk * 9 * (L.ck * esize / 32) * L.nf * 1024;
     return true;
 }
@@ -439,7 +463,7 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
         float *xF = f.fuF0, *yF = f.fuF1;
         EMAVFI_STEP(rec, "warp_fused<f32>", 24.0 * px, px * (8.0 + 8.0 * C),
                     launch_warp_fused(frame2, f.flow, xF, B, C, H, W, P.fpad, mid, EMAVFI_F32, s));
-        EMAVFI_STEP(rec, "fusion_widen_feat", 0, px * mid * 6.0, launch_convert_cl(f.fu0, xF, npx, P.fps, P.fpad, 0, P.p_mid, 1, s));
+        EMAVFI_STEP(rec, "fusion_widen_feat", 0, px * mid * 6.0, launch_convert_cl(f.fu0, xF, npx, P.fps, P.fpad, 0, mid, 1, s));
         EMAVFI_STEP(rec, "fusion_round_warped", 0, px * 16 * 6.0, launch_convert_cl(xF, f.fu0, npx, P.fpad, P.fps, mid, P.fpad - mid, 0, s));
         if (!rec.dry && taps && taps[3])
             EMAVFI_TRY(launch_cl_to_nchw(xF, taps[3], B, C, H, W, P.fpad, mid, EMAVFI_F32, s), "tap warped");

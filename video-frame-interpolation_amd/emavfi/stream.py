@@ -10,7 +10,8 @@ Reproduces the call pattern and OUTPUT ORDER of the reference's hot loop
             write denormalize(model(frame1, frame2))   # identical arguments for every i (alpha unused, :174)
         write denormalize(normalize(frame1))           # :187-188  (predictions come BEFORE the earlier frame)
         frame1 = frame2
-    write the last frame as read                       # :166 (raw uint8, not round-tripped)
+    write the last frame: as read (raw uint8) when the loop ends in the pair branch (:164-167),
+                          denormalize(normalize(frame1)) when it ends in the skip branch (:198-201, frame_interval > 1)
 
 What changes is how the work is scheduled, not what is computed:
   * pairs are processed in batches (the reference runs batch 1 with a blocking D2H per frame, :53);
@@ -66,21 +67,23 @@ class FrameInterpolator:
     # ---- the reference's frame selection (inference.py:158-201), as (pairs, tail) over frame indices
     @staticmethod
     def schedule(n_frames: int, frame_interval: int):
-        """Returns (pairs, last): pairs = [(i1, i2)] in processing order, last = index of the frame written raw
-        at the end (or None for an empty input)."""
+        """Returns (pairs, last, last_roundtrip): pairs = [(i1, i2)] in processing order, last = index of the frame
+        written at the end (None for an empty input), last_roundtrip = the loop ended in the skip branch
+        (inference.py:198-201), where the reference writes denormalize_frame(frame1_tensor) - the float32 normalise ->
+        float64 de-normalise -> truncate round trip, which changes some pixels by one count - instead of the raw frame."""
         if n_frames <= 0:
-            return [], None
+            return [], None, False
         pairs, cur, frame_num, nxt = [], 0, 0, 1
         while True:
             frame_num += 1
             if nxt >= n_frames:          # cap.read() fails: both branches write frame1 and stop
-                return pairs, cur
+                return pairs, cur, frame_num % frame_interval != 0
             if frame_num % frame_interval == 0:
                 pairs.append((cur, nxt))
             cur, nxt = nxt, nxt + 1      # in the skip branch the reference also advances frame1
 
     def count_outputs(self, n_frames: int) -> int:
-        pairs, last = self.schedule(n_frames, self.interval)
+        pairs, last, _ = self.schedule(n_frames, self.interval)
         return 0 if last is None else len(pairs) * (self.factor + 1) + 1
 
     # ---- buffers: two slots of pinned host memory the kernels read / write in place
@@ -155,7 +158,7 @@ class FrameInterpolator:
         for f in frames:
             if f.dtype != np.uint8 or f.ndim != 3 or f.shape != frames[0].shape:
                 raise ValueError("FrameInterpolator.run: same-shape uint8 HWC frames expected")
-        pairs, last = self.schedule(len(frames), self.interval)
+        pairs, last, last_roundtrip = self.schedule(len(frames), self.interval)
         if last is None:
             return
         self._alloc(frames[0].shape)
@@ -197,4 +200,8 @@ class FrameInterpolator:
             prev = (slot, chunk)
         if prev is not None:
             yield from drain(*prev)
-        yield frames[last]
+        if last_roundtrip and self.quirks:   # skip-branch ending: the reference writes the round-tripped frame
+            src = torch.from_numpy(frames[last]).unsqueeze(0).to(self.device)
+            yield _lib.postprocess_u8(_lib.preprocess_u8(src), denormalize=True).cpu().numpy()[0]
+        else:
+            yield frames[last]
