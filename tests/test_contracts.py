@@ -45,7 +45,7 @@ def test_size_limits_are_argument_errors_not_crashes():
 def test_bench_json_contract():
     """`python bench.py` prints ONE JSON line with the fields the driver and the judge read."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "2",
-                          "--height", "96", "--width", "128", "--cpu-rows", "24"], capture_output=True, text=True, timeout=600)
+                          "--height", "96", "--width", "128", "--cpu-reps", "2"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
@@ -60,11 +60,19 @@ def test_bench_json_contract():
     rf = r["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and "traffic" in rf
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["traffic"] is None or rf["traffic"] > 0
+    assert "traffic_source" in rf     # PMC bytes are refused when profiles/traffic.json was measured on other kernel sources
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb and cb["unit"] == "frames/s"
+    assert cb["cpu_model"] and cb["also_256x256"]["value"] > 0 and "1 warm-up" in cb["sample"]
     assert r["accuracy_vs_cpu_oracle"]["fp32"]["max_abs"] <= 1e-3
     assert r["accuracy_vs_cpu_oracle"]["fp16"]["psnr_db"] >= r["accuracy_vs_cpu_oracle"]["bf16"]["psnr_db"]
-    assert r["also_fp16_autocast_arithmetic"]["value"] > 0     # reported beside `value`, never instead of it
+    # reported beside `value`, never instead of it: the other arithmetic modes at the same size, BASELINE configs[1]
+    # (batch 16 of 256x256) in fp32 and bf16, and the warp kernel the forward itself runs
+    for k in ("also_fp16_fast", "also_amp16_autocast_policy", "also_fp32_exact"):
+        assert r[k]["value"] > 0 and r[k]["height"] == 96, k
+    assert r["config1_256"]["fp32"]["value"] > 0 and r["config1_256"]["bf16"]["pairs_per_step"] == 16
+    assert r["roofline_warp_in_forward"]["bound"] == "hbm" and r["roofline_warp_in_forward"]["kernel"].startswith("warp_fused")
 
 
 @pytest.mark.gpu
@@ -88,4 +96,4 @@ def test_config5_1080p_runs_deterministically():
         assert torch.equal(a, b) and torch.isfinite(a).all() and a.min() >= 0 and a.max() <= 1
         outs[mode] = a
     mse = (outs["fp32"].double() - outs["bf16"].double()).pow(2).mean().item()
-    assert mse < 10 ** (-3.5)  # PSNR of bf16 against fp32 > 35 dB
+    assert mse < 10 ** (-5.0)  # PSNR of bf16 against the exact-fp32 frame > 50 dB (measured ~59 dB)

@@ -125,8 +125,16 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[MF][NF], const
     }
 }
 
+// waves per SIMD the register allocation must leave room for = workgroups per CU the LDS footprint allows (each
+// workgroup is 4 waves, one per SIMD), capped at 2: without it hipcc spends up to 512 registers on the 8-fragment
+// instances and a second workgroup cannot become resident
+template <typename T, int CK, int NF, int S> constexpr int conv_wg_per_cu()
+{
+    return (160 * 1024 / ConvCfg<T, CK, NF, S>::LDS_BYTES) >= 2 ? 2 : 1;
+}
+
 template <typename T, int CK, int NF, int S>
-__global__ __launch_bounds__(256) void conv3x3_kernel(const ConvParams p)
+__global__ __launch_bounds__(256, (conv_wg_per_cu<T, CK, NF, S>())) void conv3x3_kernel(const ConvParams p)
 {
     using C = ConvCfg<T, CK, NF, S>;
     using vec = typename DT<T>::vec;
@@ -420,7 +428,7 @@ template <typename T> static int launch_conv_any(const ConvParams &p, hipStream_
     if (p.ck == CK_ && p.nf == NF_ && p.stride == ST_) return launch_conv_inst<T, CK_, NF_, ST_>(p, s);
     EMAVFI_CONV_INSTANCES(X)
     if constexpr (sizeof(T) == 2) {  // 16-bit types only: stride-2 layers with 64-channel chunks (the fp32 tiles exceed the LDS)
-        X(64, 4, 2) X(64, 8, 2)
+        X(32, 8, 2) X(64, 4, 2) X(64, 8, 2)
     }
 #undef X
     return -2;  // no instantiation

@@ -33,7 +33,7 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 const int kConvInst[][3] = {{16, 1, 1}, {16, 2, 1}, {32, 1, 1}, {48, 1, 1}, {64, 1, 1}, {64, 2, 1},
                             {64, 4, 1}, {80, 1, 1}, {80, 2, 1}, {16, 1, 2}, {32, 2, 2}, {32, 4, 2}};
 // 16-bit types only (the fp32 tiles would not fit the LDS): stride-2 layers with 64-channel chunks
-const int kConvInst16[][3] = {{64, 4, 2}, {64, 8, 2}};
+const int kConvInst16[][3] = {{32, 8, 2}, {64, 4, 2}, {64, 8, 2}};
 const int kDeformInst[][2] = {{16, 1}, {32, 1}, {48, 2}, {80, 3}};
 
 bool conv_inst_exists(int ck, int nf, int st, int esize)
@@ -76,7 +76,10 @@ bool conv_geometry(Layer &L, int esize)
     L.nchunk = L.cin_pad / L.ck;
     const int frags = (L.cout + 31) / 32;
     L.nf = (frags % 4 == 0) ? 4 : (frags % 2 == 0) ? 2 : 1;
-    if (s2_wide && frags % 8 == 0) L.nf = 8;
+    // 16-bit stride-2 layers with >= 256 output channels take all of them in ONE pass (8 fragments, 128 accumulator
+    // registers per lane): every extra pass re-reads the whole input from HBM (FETCH_SIZE calibration,
+    // tools/microbench/fetch_calib.hip: reading 64 bytes of every record fetches every 128-byte line)
+    if (L.stride == 2 && esize == 2 && frags % 8 == 0 && (L.ck == 32 || s2_wide)) L.nf = 8;
     if (L.stride == 2 && L.ck == 16) L.nf = 1;
     if (L.stride == 2 && L.ck == 32 && L.nf == 1) { L.ck = 16; L.nchunk = L.cin_pad / 16; }
     L.npass = frags / L.nf;
