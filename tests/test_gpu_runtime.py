@@ -83,10 +83,51 @@ def test_two_streams_run_forwards_concurrently():
                 outs_b.append(m(*xb))
         torch.cuda.synchronize()
     assert len({k for k in lib._ws_cache if k[1] in (s1.cuda_stream, s2.cuda_stream)}) == 2
-    for o in outs_a:
-        assert torch.equal(o, ref_a)
-    for o in outs_b:
-        assert torch.equal(o, ref_b)
+    def same(outs, ref, tag):
+        for i, o in enumerate(outs):
+            d = (o - ref).abs()
+            assert torch.equal(o, ref), (f"{tag}[{i}]: {int((d > 0).sum())} of {d.numel()} elements differ, max {d.max().item():.3e}, "
+                                         f"first at {(d > 0).nonzero()[:4].tolist()}")
+
+    same(outs_a, ref_a, "a")
+    same(outs_b, ref_b, "b")
+    lib.release_workspaces()
+
+
+def test_forward_is_exact_beside_a_foreign_gemm_stream():
+    """Round 2's two-stream corruption: the warp kernel lost one bilinear term in lanes 48-63 whenever an
+    MFMA-bound kernel of another stream shared the CUs - a torch bf16 GEMM reproduced it in every forward (the diagnostic
+    build EMAVFI_WARP_DIVERGENT=1 still does).  Every tap of every forward must equal the serial result bit for bit, for
+    the standalone C-ABI warp as well."""
+    lib.release_workspaces()
+    sd = synth.synthetic_state_dict(seed=0)
+    m = make_model(sd, dtype="bf16")
+    xb = [t.to(DEV) for t in synth.synthetic_frames(52, 1, 360, 640, "stress")]     # flows that leave the warp's LDS window
+    A = torch.randn(2048, 2048, device=DEV, dtype=torch.bfloat16)
+    with torch.no_grad():
+        ref, taps = m(*xb, return_taps=True)
+        ref, taps = ref.clone(), {k: v.clone() for k, v in taps.items()}
+        flow, f2 = taps["flow"].float().contiguous(), xb[1].contiguous()
+        ref_warp = lib.warp(f2, flow).clone()
+        A @ A
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        for _ in range(4):
+            runs, warps = [], []
+            for _ in range(10):
+                with torch.cuda.stream(s1):
+                    for _ in range(40):
+                        A @ A
+                with torch.cuda.stream(s2):
+                    runs.append(m(*xb, return_taps=True))
+                    warps += [lib.warp(f2, flow) for _ in range(10)]
+            torch.cuda.synchronize()
+            for o, tp in runs:
+                for k in taps:
+                    assert torch.equal(tp[k], taps[k]), f"stage {k}: {int((tp[k] != taps[k]).sum())} elements differ beside the GEMM stream"
+                assert torch.equal(o, ref)
+            for w in warps:
+                assert torch.equal(w, ref_warp), f"emavfi_warp: {int((w != ref_warp).sum())} elements differ beside the GEMM stream"
     lib.release_workspaces()
 
 
