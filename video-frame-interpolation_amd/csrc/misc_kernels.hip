@@ -414,16 +414,6 @@ __global__ __launch_bounds__(256) void warp_nchw_kernel(const float *__restrict_
 // pixel; the four taps are then read from LDS.  A pixel whose taps leave the window (|flow| > R)
 // gathers from global memory as the simple kernel does - same arithmetic, same result.
 __device__ const float g_zero_page[64] = {0};
-// Round 2: with a PER-LANE choice between the two paths, compiler-scheduled counted waits and the
-// SLP vectoriser's packed f32 multiplies, this kernel returned wrong pixels (one bilinear term of one channel missing, always
-// in lanes 48-63) whenever an MFMA-bound kernel of ANOTHER stream shared the CUs - about 2 % of launches beside a bf16 GEMM,
-// never alone.  Each of these alone removed it (0 of 4000-6000 launches): a wave-uniform choice of path, one vmcnt(0) behind
-// the gather burst, no packed f32 operations.  The product build does all three (the Makefile compiles this file with
-// -fno-slp-vectorize); EMAVFI_WARP_DIVERGENT=1 (with MISC_SLP= on the make line) rebuilds the failing form for
-// tools/debug_warp_terms.py.
-#ifndef EMAVFI_WARP_DIVERGENT
-#define EMAVFI_WARP_DIVERGENT 0
-#endif
 
 // T = void: NCHW fp32 planes (emavfi_warp).  T = float / bf16_t: the forward's fused variant, which
 // writes channels [coff, ps) of the channels-last fusion buffer (warped RGB, then zero padding).
@@ -485,12 +475,7 @@ __global__ __launch_bounds__(256) void warp_tiled_kernel(const float *__restrict
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const WarpTap t = warp_tap(ix[k] + q, iy[k], fx[k][q], fy[k][q], H, W, wden, hden);
-            const bool lane_inside = t.ya >= wy0 && t.yb <= wy0 + WR - 1 && t.xa >= wx0 && t.xb <= wx0 + WC - 1;
-#if EMAVFI_WARP_DIVERGENT
-            const bool inside = lane_inside;
-#else
-            const bool inside = __all(lane_inside);   // wave-uniform: one pixel column of the wave takes one path
-#endif
+            const bool inside = t.ya >= wy0 && t.yb <= wy0 + WR - 1 && t.xa >= wx0 && t.xb <= wx0 + WC - 1;
             if (inside) {
                 const int l00 = (t.ya - wy0) * WC + (t.xa - wx0), l01 = (t.ya - wy0) * WC + (t.xb - wx0);
                 const int l10 = (t.yb - wy0) * WC + (t.xa - wx0), l11 = (t.yb - wy0) * WC + (t.xb - wx0);
@@ -504,26 +489,8 @@ __global__ __launch_bounds__(256) void warp_tiled_kernel(const float *__restrict
                     v[c][q] = a;
                 }
             } else {
-#if EMAVFI_WARP_DIVERGENT
 #pragma unroll
                 for (int c = 0; c < C; ++c) v[c][q] = warp_sample(src_b + (size_t)c * plane, t);
-#else
-                float gv[C][4];
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    const float *p = src_b + (size_t)c * plane;
-                    gv[c][0] = p[t.o00]; gv[c][1] = p[t.o01]; gv[c][2] = p[t.o10]; gv[c][3] = p[t.o11];
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the whole burst has landed before the first use
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    float a = gv[c][0] * t.nw;   // accumulation order nw, ne, sw, se as warp_sample
-                    a += gv[c][1] * t.ne;
-                    a += gv[c][2] * t.sw;
-                    a += gv[c][3] * t.se;
-                    v[c][q] = a;
-                }
-#endif
             }
         }
         const size_t pix = (size_t)iy[k] * W + ix[k];
