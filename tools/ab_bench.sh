@@ -19,7 +19,7 @@ for tag in sys.argv[2:]:
         d = json.load(open(f))
         k = {x["kernel"]: x["avg_us"] for x in d["kernels"]}
         dk = [v for n, v in k.items() if n.startswith("deform")][0]
-        dh = json.load(open(f.replace("/ab_", "/abh_")))
+        dh = json.load(open(f"{out}/abh_" + f.rsplit("/ab_", 1)[1]))
         kh = [x["avg_us"] for x in dh["kernels"] if x["kernel"].startswith("deform")][0]
         rows.append((d["value"], dk, k.get("conv3x3<bf16,ck=64,nf=2,s=1>", 0), sum(v for n, v in k.items() if n.endswith("s=2>")), dh["value"], kh))
     print(f"{name:8s}", " | ".join(f"bf16 {v:6.1f} fps pack {u:7.1f} conv64x64 {c:6.1f} stride2 {c1:6.1f} us; fp16 {h:6.1f} fps pack {kk:7.1f} us" for v, u, c, c1, h, kk in rows))

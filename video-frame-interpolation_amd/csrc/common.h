@@ -62,16 +62,6 @@ __device__ __forceinline__ void mma_kg(f32x16 &acc, const f32x4 &w, const f32x4 
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[3], x[3], acc, 0, 0, 0);
 }
 
-// Retire the MFMA chain that produces `acc` before the code that follows.  Reading one element
-// makes hipcc emit v_accvgpr_read behind the required wait states, so the wave's matrix-pipe work
-// has finished when the next instruction issues.  Why it exists: the first bf16 deformable-conv
-// kernel intermittently computed a wrong predicate for lanes 48-63 (~1e-5 of the pixels per launch,
-// only with two workgroups per CU) in predicate-heavy code that ran directly behind a burst of
-// MFMAs; retiring the chains first removed it.  The mechanism is NOT established (two candidate
-// hazards tested clean in isolation, tools/microbench/) - this is an empirical
-// guard, it costs nothing measurable, and the determinism tests watch for a recurrence.
-__device__ __forceinline__ void mfma_retire(const f32x16 &acc) { asm volatile("" ::"v"(acc[0])); }
-
 // Accumulator register i of lane (r, h) is output channel (i&3) + 8*(i>>2) + 4*h of the
 // 32-channel fragment, pixel r (C/D map of the 32x32 MFMA, cdna_hip_programming.md section 3).
 __device__ __forceinline__ int acc_channel(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }

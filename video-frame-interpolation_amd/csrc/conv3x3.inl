@@ -163,11 +163,6 @@ __global__ __launch_bounds__(256, (conv_wg_per_cu<T, CK, NF, S>())) void conv3x3
 
     for (int chunk = 0; chunk < p.nchunk; ++chunk) {
         if (chunk) {
-            // the staging code below is predicate-heavy: retire the previous chunk's MFMAs first
-#pragma unroll
-            for (int m = 0; m < MF; ++m)
-#pragma unroll
-                for (int n = 0; n < NF; ++n) mfma_retire(acc[m][n]);
             __syncthreads();
         }
         // ---- DMA the input tile (+halo) for this channel chunk, and tap 0's weights ----

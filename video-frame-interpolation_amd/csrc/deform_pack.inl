@@ -484,11 +484,6 @@ __global__ __launch_bounds__(16 * TCOLS, 2) void deform_pack_kernel(const Deform
 #pragma unroll
             for (int n = 0; n < NF; ++n) mma_kg(acc[m][n], wq[kg & 1][n], xf);
         }
-        // retire the tap's accumulator chains before the next tap's geometry code (common.h)
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int n = 0; n < NF; ++n) mfma_retire(acc[m][n]);
 #if EMAVFI_DEFORM_STAMPS
         DEFORM_STAMP(ts_end);
         sum_geom += ts_geom - ts_tap;
