@@ -28,6 +28,13 @@
 #define EMAVFI_CONV_PIPELINE 1   // persistent kernel: operands one step ahead of their MFMAs (0 = the compiler's own order)
 #endif
 
+// Persistent kernel: touch the next tile's input lines (L2 prefetch) in front of the MFMA loop.  OFF: the convolution itself
+// gains 0-3.5 %, but the board answers with a lower clock (2034 vs 2157 MHz under load, tools/power_trace.py) and the whole
+// step loses 1.6-4 % - kept as a switch because it shows the step is power-managed, not latency-bound.
+#ifndef EMAVFI_CONV_PREFETCH
+#define EMAVFI_CONV_PREFETCH 0
+#endif
+
 template <typename T, int CK, int NF, int S> struct ConvCfg {
     using D = DT<T>;
     static constexpr int MF = (S == 1) ? 2 : 1;
@@ -322,6 +329,40 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_persist_kernel(const ConvP
         conv_init_acc<MF, NF>(acc, p, b, 0, ty * C::TH + wave * MF, tx * 32 + r, h);
         __syncthreads();  // hipcc drains the DMA (vmcnt(0)) ahead of the barrier: tile (and, first time, weights) landed
 
+#if EMAVFI_CONV_PREFETCH
+        // Every CU walks its tile list in step with the others, so the tiles' input DMAs hit HBM as chip-wide bursts and are
+        // waited for with the matrix pipe idle.  Touch the NEXT tile's input lines now (one byte per 128-byte line, result
+        // unused): HBM delivers them into this XCD's L2 under the MFMAs below, and the next DMA is an L2 hit.
+        constexpr int LPR = (IW * C::PIECES * 16 + 127) / 128 + 1;   // lines a tile row can touch
+        constexpr int NPF = (C::IH * LPR + 64 * WAVES - 1) / (64 * WAVES);
+        unsigned pfr[NPF] = {};
+        {
+            const int nt = tile + (int)gridDim.x;
+            if (nt < ntiles) {
+                const int nb = nt / (ntx * nty), nrem = nt - nb * (ntx * nty);
+                const int nty_ = nrem / ntx, ntx_ = nrem - nty_ * ntx;
+                const int ny0 = nty_ * C::TH - 1, nx0 = ntx_ * 32 - 1;
+                const size_t pixb = (size_t)p.in_ps * sizeof(T);
+                const char *gn = (const char *)p.in + (size_t)nb * p.Hin * p.Win * pixb;
+                const int xa = nx0 < 0 ? 0 : nx0, xb = nx0 + IW > p.Win ? p.Win : nx0 + IW;
+#pragma unroll
+                for (int sl = 0; sl < NPF; ++sl) {
+                    const int s_ = sl * 64 * WAVES + tid, row = s_ / LPR, l = s_ - row * LPR;
+                    const int gy = ny0 + row;
+                    const char *a0 = gn + ((size_t)gy * p.Win + xa) * pixb, *a1 = gn + ((size_t)gy * p.Win + xb) * pixb;
+                    const char *ln = (const char *)((size_t)a0 & ~(size_t)127) + (size_t)l * 128;
+                    if (row < C::IH && gy >= 0 && gy < p.Hin && ln < a1) {
+                        const char *t_ = ln < a0 ? a0 : ln;
+                        // the destination register stays reserved (it is an operand of the s_waitcnt statement behind the
+                        // epilogue), so the in-flight load cannot land in a register the compiler has given to something else
+                        asm volatile("global_load_ubyte %0, %1, off" : "=v"(pfr[sl]) : "v"(t_) : "memory");
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the touches in front of the MFMA loop
+#endif
+
 #if EMAVFI_CONV_PIPELINE
         // Software pipeline over (tap, k-group pair) steps: the operands of step s+1 (MF pixel pieces + NF weight fragments
         // per k-group) are read from LDS BEFORE the MFMAs of step s issue, and sched_barrier pins that order (left alone,
@@ -383,6 +424,12 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_persist_kernel(const ConvP
         }
 #endif
         conv_epilogue<T, MF, NF>(acc, p, b, 0, ty * C::TH + wave * MF, tx * 32 + r, h);
+#if EMAVFI_CONV_PREFETCH
+        if constexpr (NPF == 1) asm volatile("s_waitcnt vmcnt(0)" ::"v"(pfr[0]) : "memory");
+        else if constexpr (NPF == 2) asm volatile("s_waitcnt vmcnt(0)" ::"v"(pfr[0]), "v"(pfr[1]) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::"v"(pfr[0]), "v"(pfr[1]), "v"(pfr[NPF - 1]) : "memory");
+        static_assert(NPF <= 3, "prefetch touches per thread");
+#endif
     }
 }
 
