@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define EMAVFI_VERSION 100 /* 0.1.0 */
+#define EMAVFI_VERSION 200 /* 0.2.0: EMAVFI_AMP16, 72-channel fusion pixels in the packed layout (round 2) */
 
 #define EMAVFI_F32 0
 #define EMAVFI_BF16 1
