@@ -445,6 +445,27 @@ for dt in ("bf16", "fp16", "fp32"):
 """
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(2, 75, 131), (1, 8, 32), (1, 9, 33), (3, 40, 64), (1, 360, 640)])
+def test_fused_tail_equals_two_launches(dtype, shape, monkeypatch):
+    """reconstruction.1 + .2 as one launch (conv3x3_tail_kernel, opt-in with EMAVFI_FUSED_TAIL=1 because it measured slower:
+    the 32-channel intermediate stays in the LDS, halo recomputed, out-of-image positions zeroed) must equal the two
+    stand-alone launches bit for bit: same tap / k-group order, same rounding of the intermediate.  Ragged sizes exercise
+    tiles that hang over the image on every side."""
+    B, H, W = shape
+    sd = synth.synthetic_state_dict(seed=2)
+    m = EMA_VFI(compute_dtype=dtype).to(DEV).eval()
+    m.load_state_dict(sd)
+    f1, f2 = (t.to(DEV) for t in synth.synthetic_frames(31, B, H, W, "natural"))
+    with torch.no_grad():
+        monkeypatch.setenv("EMAVFI_FUSED_TAIL", "0")
+        two = m(f1, f2).clone()
+        monkeypatch.setenv("EMAVFI_FUSED_TAIL", "1")
+        one = m(f1, f2).clone()
+    assert torch.isfinite(one).all()
+    assert torch.equal(one, two), f"{int((one != two).sum())} of {one.numel()} elements differ, max {(one - two).abs().max().item():.3e}"
+
+
 def test_fused_pack_equals_the_two_launch_path(tmp_path):
     """bf16 / fp16 at the reference width run offset_conv inside the deform kernel (one launch per
     ModulatedDeformConvPack, csrc/deform_pack.inl); EMAVFI_NO_FUSED_OFFSET=1 runs conv3x3(EPI_OM) + the deform kernel

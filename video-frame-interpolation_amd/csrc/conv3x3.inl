@@ -459,6 +459,157 @@ template <typename T, int CK, int NF, int WAVES> static int launch_conv_persist(
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// reconstruction.1 + reconstruction.2 (ema_vfi.py:103-107: conv_block(64, 32), conv(32, 3), then tanh and (t + 1) / 2 at
+// :146) as ONE persistent launch for the 16-bit types at mid_channels = 64.  Per 8 x 32 output tile:
+//   stage 1  the 64-channel input tile with a 2-pixel halo (12 x 36 pixels) is DMA-staged; conv 64 -> 32 + bias + ReLU is
+//            evaluated on the 10 x 34 positions stage 2 needs (halo recompute: 340 instead of 256 pixels, 11 fragments of 32
+//            spread over the 8 waves), rounded to T exactly as the stand-alone layer stores it, positions outside the image
+//            forced to zero (they are stage 2's zero padding), and written to an LDS tile - it never reaches HBM;
+//   stage 2  conv 32 -> nplanes on that tile, one output row per wave, with the stand-alone layer's epilogue.
+// Same tap / k-group order as the stand-alone kernels, so the result is bit-identical to the two-launch path
+// (tests/test_gpu_parity.py::test_fused_tail_equals_two_launches).  LDS: 36 + 18 KiB of weights (resident), 61 KiB input
+// tile, 27 KiB intermediate = 142 KiB, one 8-wave workgroup per CU.
+// ------------------------------------------------------------------------------------------
+template <typename T> struct TailCfg {
+    using D = DT<T>;
+    static constexpr int WAVES = 8, TH = 8, TW = 32;
+    static constexpr int CK1 = 64, KG1 = CK1 / D::CHKG, PSTR1 = LdsPix<T, CK1>::BYTES, SP1 = PSTR1 / 16, PIECES1 = CK1 * (int)sizeof(T) / 16;
+    static constexpr int CK2 = 32, KG2 = CK2 / D::CHKG, PSTR2 = LdsPix<T, CK2>::BYTES;
+    static constexpr int IH = TH + 4, IW = TW + 4, MH = TH + 2, MW = TW + 2, NMID = MH * MW, NFRAG1 = (NMID + 31) / 32;
+    static constexpr int W1TAP = KG1 * 1024, W2TAP = KG2 * 1024, LDS_W1 = 9 * W1TAP, LDS_W2 = 9 * W2TAP;
+    static constexpr int NSLOT = IH * IW * SP1, NINST = (NSLOT + 63) / 64, LDS_IN = NINST * 1024;
+    static constexpr int LDS_MID = (NMID * PSTR2 + 15) / 16 * 16;
+    static constexpr int LDS_BYTES = LDS_W1 + LDS_W2 + LDS_IN + LDS_MID;
+    static_assert(sizeof(T) == 2, "16-bit storage types only");
+    static_assert(LDS_BYTES <= 160 * 1024, "fused tail does not fit the 160 KiB LDS");
+};
+
+template <typename T>
+__global__ __launch_bounds__(512) void conv3x3_tail_kernel(const TailParams p)
+{
+    using C = TailCfg<T>;
+    using vec = typename DT<T>::vec;
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *lds_w1 = smem, *lds_w2 = smem + C::LDS_W1, *lds_in = lds_w2 + C::LDS_W2, *lds_mid = lds_in + C::LDS_IN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const char *zeros = (const char *)p.zeros;
+    const int npieces = p.in_ps * (int)sizeof(T) / 16 < C::PIECES1 ? p.in_ps * (int)sizeof(T) / 16 : C::PIECES1;
+
+    // both layers' packed weights, once per workgroup
+#pragma unroll 1
+    for (int j = wave; j < 9 * C::KG1; j += C::WAVES)
+        __builtin_amdgcn_global_load_lds((gptr_t *)((const char *)p.w1 + j * 1024 + lane * 16), (lptr_t *)(lds_w1 + j * 1024), 16, 0, 0);
+#pragma unroll 1
+    for (int j = wave; j < 9 * C::KG2; j += C::WAVES)
+        __builtin_amdgcn_global_load_lds((gptr_t *)((const char *)p.w2 + j * 1024 + lane * 16), (lptr_t *)(lds_w2 + j * 1024), 16, 0, 0);
+
+    // the second layer's parameters in the shape the shared epilogue takes
+    ConvParams p2{};
+    p2.out_planar = p.out_planar; p2.bias = p.bias2; p2.Hout = p.H; p2.Wout = p.W; p2.B = p.B; p2.npass = 1;
+    p2.epi = p.epi2; p2.nplanes = p.nplanes; p2.round16 = p.round16;
+
+    const int ntx = (p.W + C::TW - 1) / C::TW, nty = (p.H + C::TH - 1) / C::TH;
+    const int ntiles = ntx * nty * p.B;
+    // input tile of `t` -> LDS (the caller has made sure nobody still reads the previous one)
+    auto stage_input = [&](int t) {
+        const int b = t / (ntx * nty), trem = t - b * (ntx * nty);
+        const int ty = trem / ntx, tx = trem - ty * ntx;
+        const int iy0 = ty * C::TH - 2, ix0 = tx * C::TW - 2;
+        const char *gin = (const char *)p.in + (size_t)b * p.H * p.W * p.in_ps * sizeof(T);
+#pragma unroll
+        for (int i = 0; i < (C::NINST + C::WAVES - 1) / C::WAVES; ++i) {
+            const int j = i * C::WAVES + wave;
+            if (j < C::NINST) {
+                const int sl = j * 64 + lane;
+                const int pix = sl / C::SP1, pc = sl - pix * C::SP1;
+                const int ly = pix / C::IW, lx = pix - ly * C::IW;
+                const int gy = iy0 + ly, gx = ix0 + lx;
+                const bool ok = sl < C::NSLOT && pc < npieces && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+                const char *src = ok ? gin + ((size_t)gy * p.W + gx) * p.in_ps * sizeof(T) + pc * 16 : zeros;
+                __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)(lds_in + j * 1024), 16, 0, 0);
+            }
+        }
+    };
+    if ((int)blockIdx.x < ntiles) stage_input(blockIdx.x);
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / (ntx * nty), trem = tile - b * (ntx * nty);
+        const int ty = trem / ntx, tx = trem - ty * ntx;
+        // the tile's DMA (issued behind the previous tile's stage 1) has landed; the previous stage 2 has finished with the
+        // intermediate image (hipcc drains vmcnt(0) ahead of the barrier)
+        __syncthreads();
+
+        // ---- stage 1: conv 64 -> 32 + ReLU on the 10 x 34 intermediate positions, 32 of them per fragment
+#pragma unroll 1
+        for (int f = wave; f < C::NFRAG1; f += C::WAVES) {
+            const int q = f * 32 + r, qq = q < C::NMID ? q : C::NMID - 1;   // lanes past the end recompute the last position
+            const int my = qq / C::MW, mx = qq - my * C::MW;
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = p.bias1[acc_channel(i, h)];
+            const char *xb = lds_in + (my * C::IW + mx) * C::PSTR1 + h * 16;
+            const char *wb = lds_w1 + lane * 16;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3, dx = tap - 3 * dy;
+#pragma unroll
+                for (int kg = 0; kg < C::KG1; ++kg) {
+                    const vec xv = *reinterpret_cast<const vec *>(xb + (dy * C::IW + dx) * C::PSTR1 + kg * 32);
+                    const vec wv = *reinterpret_cast<const vec *>(wb + (tap * C::KG1 + kg) * 1024);
+                    mma_kg(acc, wv, xv);
+                }
+            }
+            // the stand-alone layer's rounding (store_frag, EPI_RELU); zero outside the image = stage 2's padding
+            const int gy = ty * C::TH - 1 + my, gx = tx * C::TW - 1 + mx;
+            const float keep = (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? 1.0f : 0.0f;
+            // (lanes past the last position store nothing but still take part in store_frag's lane swaps)
+            store_frag(reinterpret_cast<T *>(lds_mid + qq * C::PSTR2), acc, h, q < C::NMID ? 32 : 0, [keep](float v, int) { return fmaxf(v, 0.0f) * keep; });
+        }
+        __syncthreads();
+        // every wave is done with the input tile: fetch the next one under stage 2
+        if (tile + (int)gridDim.x < ntiles) stage_input(tile + gridDim.x);
+
+        // ---- stage 2: conv 32 -> nplanes, output row `wave` of the tile
+        {
+            f32x16 acc2[1][1];
+            conv_init_acc<1, 1>(acc2, p2, b, 0, ty * C::TH + wave, tx * C::TW + r, h);
+            const char *xb = lds_mid + (wave * C::MW + r) * C::PSTR2 + h * 16;
+            const char *wb = lds_w2 + lane * 16;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3, dx = tap - 3 * dy;
+#pragma unroll
+                for (int kg = 0; kg < C::KG2; ++kg) {
+                    const vec xv = *reinterpret_cast<const vec *>(xb + (dy * C::MW + dx) * C::PSTR2 + kg * 32);
+                    const vec wv = *reinterpret_cast<const vec *>(wb + (tap * C::KG2 + kg) * 1024);
+                    mma_kg(acc2[0][0], wv, xv);
+                }
+            }
+            conv_epilogue<T, 1, 1>(acc2, p2, b, 0, ty * C::TH + wave, tx * C::TW + r, h);
+        }
+    }
+}
+
+template <typename T> static int launch_conv_tail(const TailParams &p, hipStream_t s)
+{
+    using C = TailCfg<T>;
+    static std::once_flag once;
+    static hipError_t init_err = hipSuccess;
+    std::call_once(once, [] {
+        init_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_tail_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    });
+    if (init_err != hipSuccess) return (int)init_err;
+    const int ncu = device_cu_count();
+    if (ncu <= 0) return (int)hipErrorInvalidDevice;
+    const int ntiles = ((p.W + C::TW - 1) / C::TW) * ((p.H + C::TH - 1) / C::TH) * p.B;
+    conv3x3_tail_kernel<T><<<ntiles < ncu ? ntiles : ncu, 512, C::LDS_BYTES, s>>>(p);
+    return (int)hipGetLastError();
+}
+
 // (CK, NF, stride) instantiations: what mid_channels in {8, 16, 32, 64} need (see plan.cpp).
 #define EMAVFI_CONV_INSTANCES(X) \
     X(16, 1, 1) X(16, 2, 1) X(32, 1, 1) X(48, 1, 1) X(64, 1, 1) X(64, 2, 1) X(64, 4, 1) X(80, 1, 1) X(80, 2, 1) \

@@ -531,12 +531,33 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
     conv_work(P, P.r0, B, H, W, e, fl, by);
     EMAVFI_STEP(rec, conv_name(P, P.r0) + " reconstruction.0", fl, by,
                 run_conv(P, P.r0, packed, x, P.fps, H, W, f.fA, P.p_mid, 0, P.p_mid, EPI_RELU, B, s));
-    conv_work(P, P.r1, B, H, W, e, fl, by);
-    EMAVFI_STEP(rec, conv_name(P, P.r1) + " reconstruction.1", fl, by,
-                run_conv(P, P.r1, packed, f.fA, P.p_mid, H, W, f.fB, f.p_half, 0, f.p_half, EPI_RELU, B, s));
-    conv_work(P, P.r2, B, H, W, 4.0, fl, by);
-    EMAVFI_STEP(rec, conv_name(P, P.r2) + " reconstruction.2(tanh)", fl, by,
-                run_conv(P, P.r2, packed, f.fB, f.p_half, H, W, nullptr, 0, 0, 0, EPI_PLANAR_TANH01, B, s, nullptr, out, C));
+    // 16-bit types at mid_channels = 64: reconstruction.1 and .2 can run as one launch whose 32-channel intermediate stays in
+    // the LDS (conv3x3.inl, conv3x3_tail_kernel; bit-identical to the two launches).  Built for VERDICT r1 item 4 and measured
+    // SLOWER (677 vs 362 + 232 us at B=8 x 720p: +33 % recomputed positions, one fragment per wave = no operand reuse, one
+    // workgroup per CU), so it is opt-in: EMAVFI_FUSED_TAIL=1.  Read per call: the parity test flips it inside one process.
+    const char *ft_ = getenv("EMAVFI_FUSED_TAIL");
+    const bool fused_tail_off = !(ft_ != nullptr && ft_[0] == '1');
+    if (P.esize == 2 && !fused_tail_off && P.r1.ck == 64 && P.r1.nf == 1 && P.r1.nchunk == 1 && P.r2.ck == 32 && P.r2.nf == 1 && P.r2.nchunk == 1) {
+        double fl2 = 0.0, by2 = 0.0;
+        conv_work(P, P.r1, B, H, W, e, fl, by);
+        conv_work(P, P.r2, B, H, W, 4.0, fl2, by2);
+        fl += fl2;
+        by += by2 - 2.0 * (double)B * H * W * f.p_half * e;   // the intermediate is neither written nor read
+        TailParams t{};
+        t.in = f.fA; t.in_ps = P.p_mid; t.H = H; t.W = W; t.B = B; t.nplanes = C; t.epi2 = EPI_PLANAR_TANH01; t.round16 = P.amp ? 1 : 0;
+        t.w1 = (const char *)packed + P.r1.w_off; t.bias1 = (const float *)((const char *)packed + P.r1.b_off);
+        t.w2 = (const char *)packed + P.r2.w_off; t.bias2 = (const float *)((const char *)packed + P.r2.b_off);
+        t.out_planar = out; t.zeros = (const char *)packed + P.zero_off;
+        EMAVFI_STEP(rec, std::string(P.dtype == EMAVFI_F16 ? "tail<f16" : "tail<bf16") + ",64-32-planes> reconstruction.1+.2(tanh)", fl, by,
+                    P.dtype == EMAVFI_F16 ? launch_conv_tail_f16(t, s) : launch_conv_tail_bf16(t, s));
+    } else {
+        conv_work(P, P.r1, B, H, W, e, fl, by);
+        EMAVFI_STEP(rec, conv_name(P, P.r1) + " reconstruction.1", fl, by,
+                    run_conv(P, P.r1, packed, f.fA, P.p_mid, H, W, f.fB, f.p_half, 0, f.p_half, EPI_RELU, B, s));
+        conv_work(P, P.r2, B, H, W, 4.0, fl, by);
+        EMAVFI_STEP(rec, conv_name(P, P.r2) + " reconstruction.2(tanh)", fl, by,
+                    run_conv(P, P.r2, packed, f.fB, f.p_half, H, W, nullptr, 0, 0, 0, EPI_PLANAR_TANH01, B, s, nullptr, out, C));
+    }
     return EMAVFI_OK;
 }
 
