@@ -172,6 +172,64 @@ def warp_roofline(hip, B, H, W, steps=20):
             "algorithmic_bytes_per_px": 32, "pixels": B * H * W}
 
 
+def board_under_load(model, a1, a2, seconds=2.0):
+    """Package power and clocks (rocm-smi, polled from a thread) while the measured forward runs back to back for about two
+    seconds AFTER the timed region: the roofline fractions are taken against a 2.4 GHz peak the board does not sustain on this
+    workload.  Never part of `value`; {} when rocm-smi is unavailable."""
+    import subprocess
+    import threading
+
+    def smi():
+        try:
+            out = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--showmaxpower", "--json"], capture_output=True, text=True, timeout=10).stdout
+            c = json.loads(out)
+            c = c[sorted(c)[0]]
+
+            def num(*keys):
+                for k, v in c.items():
+                    if all(x in k.lower() for x in keys):
+                        try:
+                            return float(str(v).replace("Mhz", "").strip("() "))
+                        except ValueError:
+                            pass
+                return None
+            return {"power_w": num("socket", "power") or num("average", "power"), "cap_w": num("max", "power"), "sclk_mhz": num("sclk", "speed"),
+                    "mclk_mhz": num("mclk", "speed")}
+        except Exception:  # noqa: BLE001 - a side measurement must never fail the bench
+            return None
+
+    samples, stop = [], []
+
+    def poll():
+        while not stop:
+            r = smi()
+            if r:
+                samples.append((time.perf_counter(), r))
+            time.sleep(0.05)
+
+    th = threading.Thread(target=poll, daemon=True)
+    t0 = time.perf_counter()
+    th.start()
+    with torch.no_grad():
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(10):
+                model(a1, a2)
+            torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    stop.append(1)
+    th.join(timeout=15)
+    load = [r for (t, r) in samples if t0 + 0.7 < t < t1]
+    out = {}
+    for key in ("power_w", "sclk_mhz", "mclk_mhz", "cap_w"):
+        v = sorted(r[key] for r in load if r.get(key) is not None)
+        if v:
+            out[key] = v[len(v) // 2]
+    if out:
+        out["samples"] = len(load)
+        out["note"] = "medians of rocm-smi readings while the forward runs back to back (after the timed region); peak sclk 2400 MHz"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -331,6 +389,7 @@ def main():
                         "pairs_per_step": b, "height": h, "width": w, "dtype": dtype}
 
             res["roofline_warp"] = warp_roofline(hip, B, H, W)
+            res["board_under_load"] = board_under_load(model, f1, f2)
             # reported beside, never part of `value`
             if args.dtype != "fp16":  # the fast half-precision mode (every contraction in fp16)
                 res["also_fp16_fast"] = timed_alt("fp16", B, H, W, args.steps)

@@ -73,6 +73,9 @@ def test_bench_json_contract():
         assert r[k]["value"] > 0 and r[k]["height"] == 96, k
     assert r["config1_256"]["fp32"]["value"] > 0 and r["config1_256"]["bf16"]["pairs_per_step"] == 16
     assert r["roofline_warp_in_forward"]["bound"] == "hbm" and r["roofline_warp_in_forward"]["kernel"].startswith("warp_fused")
+    # package power / clocks while the forward runs back to back ({} if rocm-smi is not usable on the box)
+    bl = r["board_under_load"]
+    assert isinstance(bl, dict) and (not bl or (bl["samples"] >= 1 and bl.get("sclk_mhz", 1) > 0))
 
 
 @pytest.mark.gpu
