@@ -446,6 +446,26 @@ for dt in ("bf16", "fp16", "fp32"):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("cout", [64, 32, 2])
+@pytest.mark.parametrize("shape", [(2, 75, 131), (1, 8, 32), (1, 17, 33), (2, 40, 64), (1, 360, 640)])
+def test_pingpong_conv_equals_the_persistent_kernel(dtype, cout, shape, monkeypatch):
+    """conv3x3_pingpong_kernel (opt-in, EMAVFI_CONV_PINGPONG=1: two four-wave groups half a tile out of phase; 64 -> 64 on
+    unpadded XOR-swizzled tiles) against the product's persistent kernel: same tap / k-group order, so bit-identical.  Sizes
+    with one tile, odd tile counts per group and tiles hanging over every edge."""
+    B, H, W = shape
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, 64, H, W, generator=g).to(DEV)
+    w = (torch.randn(cout, 64, 3, 3, generator=g) * 0.05).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV)
+    monkeypatch.setenv("EMAVFI_CONV_PINGPONG", "0")
+    ref = lib.conv3x3(x, w, b, dtype=dtype).clone()
+    monkeypatch.setenv("EMAVFI_CONV_PINGPONG", "1")
+    got = lib.conv3x3(x, w, b, dtype=dtype).clone()
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, ref), f"{int((got != ref).sum())} of {got.numel()} elements differ, max {(got - ref).abs().max().item():.3e}"
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("shape", [(2, 75, 131), (1, 8, 32), (1, 9, 33), (3, 40, 64), (1, 360, 640)])
 def test_fused_tail_equals_two_launches(dtype, shape, monkeypatch):
     """reconstruction.1 + .2 as one launch (conv3x3_tail_kernel, opt-in with EMAVFI_FUSED_TAIL=1 because it measured slower:

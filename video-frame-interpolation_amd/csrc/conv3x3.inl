@@ -22,6 +22,7 @@
 // LDS pixel stride is an odd number of 16-byte slots (LdsPix), so the ds_read_b128 operand
 // fetches of 32 consecutive pixels are bank-conflict free for stride 1.
 #include "common.h"
+#include <cstdlib>
 #include <mutex>
 
 #ifndef EMAVFI_CONV_PIPELINE
@@ -433,6 +434,169 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_persist_kernel(const ConvP
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Ping-pong variant of the persistent kernel (16-bit, stride 1, one chunk, one pass).  In the kernel above all eight waves
+// of the workgroup walk through a tile's phases together - DMA in, contract, store out - so the matrix pipe idles during two
+// of the three (3.8 us of MFMA time in an 11.4 us tile).  Here the workgroup is two groups of four
+// waves (one per SIMD each) with their OWN 8-row tile buffers and tile sequences, half a tile out of phase: in every slot one
+// group contracts while the other stores its previous tile and DMAs its next one, and a workgroup barrier ends the slot
+//     slot A:  group 0  MFMA(k)                       | group 1  store(k-1), DMA(k), wait
+//     slot B:  group 0  store(k), DMA(k+1), wait      | group 1  MFMA(k)
+// Same tap / k-group order per pixel as the other kernels: bit-identical results.  The weights stay resident and shared.
+// Measured: 64 -> 64 gets 7.6 % faster, 64 -> 32 / 64 -> 2 do not change, and the board lowers the clock so
+// that the whole step gains 0.2 % - opt-in (EMAVFI_CONV_PINGPONG=1), the product keeps the kernel above.
+// ------------------------------------------------------------------------------------------
+// SWZ (chosen when the padded tiles do not fit beside the weights: 64 -> 64): pixels are stored UNPADDED (128 bytes) and the
+// 16-byte piece c of tile pixel q sits in slot c ^ ((q >> 1) & 7) of that pixel - the DMA permutes via its per-lane source
+// address, the reader XORs; the 16 lanes of a ds_read_b128 group (16 consecutive-modulo-16 pixels, one piece index) then hit 16
+// different slots of the 256-byte bank row, as with the odd padded stride.
+template <typename T, int CK, int NF> struct ConvPingCfg {
+    using D = DT<T>;
+    static constexpr int GW = 4, MF = 2, TH = GW * MF, TW = 32, IH = TH + 2, IW = TW + 2;
+    static constexpr int PIECES = CK * (int)sizeof(T) / 16;
+    static constexpr int PAD_BYTES = 9 * (CK / D::CHKG) * NF * 1024 + 2 * (((IH * IW * (LdsPix<T, CK>::BYTES / 16)) + 63) / 64) * 1024;
+    static constexpr bool SWZ = PAD_BYTES > 160 * 1024 && PIECES == 8;
+    static constexpr int PSTR = SWZ ? PIECES * 16 : LdsPix<T, CK>::BYTES;
+    static constexpr int KG = CK / D::CHKG;
+    static constexpr int WTAP = KG * NF * 1024, WINST = 9 * KG * NF;
+    static constexpr int SP = PSTR / 16, NSLOT = IH * IW * SP, NINST = (NSLOT + 63) / 64;
+    static constexpr int LDS_W = 9 * WTAP, LDS_IN = NINST * 1024, LDS_BYTES = LDS_W + 2 * LDS_IN;
+    static constexpr bool FITS = LDS_BYTES <= 160 * 1024;
+};
+
+template <typename T, int CK, int NF>
+__global__ __launch_bounds__(512) void conv3x3_pingpong_kernel(const ConvParams p)
+{
+    using C = ConvPingCfg<T, CK, NF>;
+    using vec = typename DT<T>::vec;
+    constexpr int MF = C::MF, IW = C::IW, PSTR = C::PSTR;
+    static_assert(C::FITS, "resident weights + two tile buffers do not fit the 160 KiB LDS");
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *lds_w = smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = wave >> 2, wq = wave & 3;   // group, wave inside the group
+    char *lds_in = smem + C::LDS_W + g * C::LDS_IN;
+    const int r = lane & 31, h = lane >> 5;
+    const char *zeros = (const char *)p.zeros;
+    const int npieces = p.in_pieces > 0 ? p.in_pieces : C::PIECES;
+
+#pragma unroll 1
+    for (int j = wave; j < C::WINST; j += 8)
+        __builtin_amdgcn_global_load_lds((gptr_t *)((const char *)p.w + j * 1024 + lane * 16), (lptr_t *)(lds_w + j * 1024), 16, 0, 0);
+
+    const int ntx = (p.Wout + 31) / 32, nty = (p.Hout + C::TH - 1) / C::TH;
+    const int ntiles = ntx * nty * p.B;
+    const int first = (int)blockIdx.x * 2 + g, stride = (int)gridDim.x * 2;
+    // rounds: group 0 never has fewer tiles than group 1
+    const int rounds = ((int)blockIdx.x * 2 < ntiles) ? (ntiles - (int)blockIdx.x * 2 + stride - 1) / stride : 0;
+
+    auto stage = [&](int tile) {   // DMA `tile`'s input (+halo) into this group's buffer
+        const int b = tile / (ntx * nty), trem = tile - b * (ntx * nty);
+        const int ty = trem / ntx, tx = trem - ty * ntx;
+        const int iy0 = ty * C::TH - 1, ix0 = tx * 32 - 1;
+        const char *gin = (const char *)p.in + (size_t)b * p.Hin * p.Win * p.in_ps * sizeof(T);
+#pragma unroll
+        for (int i = 0; i < (C::NINST + C::GW - 1) / C::GW; ++i) {
+            const int j = i * C::GW + wq;
+            if (j < C::NINST) {
+                const int sl = j * 64 + lane;
+                const int pix = sl / C::SP, ps_ = sl - pix * C::SP;
+                const int pc = C::SWZ ? (ps_ ^ ((pix >> 1) & 7)) : ps_;
+                const int ly = pix / IW, lx = pix - ly * IW;
+                const int gy = iy0 + ly, gx = ix0 + lx;
+                const bool ok = sl < C::NSLOT && pc < npieces && gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
+                const char *src = ok ? gin + ((size_t)gy * p.Win + gx) * p.in_ps * sizeof(T) + pc * 16 : zeros;
+                __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)(lds_in + j * 1024), 16, 0, 0);
+            }
+        }
+    };
+    f32x16 acc[MF][NF];
+    auto contract = [&](int tile) {
+        const int b = tile / (ntx * nty), trem = tile - b * (ntx * nty);
+        const int ty = trem / ntx, tx = trem - ty * ntx;
+        conv_init_acc<MF, NF>(acc, p, b, 0, ty * C::TH + wq * MF, tx * 32 + r, h);
+        constexpr int KGS = (C::KG % 2 == 0) ? 2 : 1;
+        constexpr int SPT = C::KG / KGS, NSTEP = 9 * SPT;
+        vec xq[2][MF][KGS], wv[2][KGS][NF];
+        auto load_step = [&](int s, vec (&xd)[MF][KGS], vec (&wd)[KGS][NF]) {
+            const int tap = s / SPT, kg0 = (s - tap * SPT) * KGS;
+            const int dy = tap / 3, dx = tap - 3 * dy;
+#pragma unroll
+            for (int m = 0; m < MF; ++m) {
+                const int q = ((wq * MF + m) + dy) * IW + r + dx;
+                if constexpr (C::SWZ) {
+                    const int fq = (q >> 1) & 7;
+#pragma unroll
+                    for (int k = 0; k < KGS; ++k) xd[m][k] = *reinterpret_cast<const vec *>(lds_in + q * PSTR + (((2 * (kg0 + k) + h) ^ fq) << 4));
+                } else {
+                    const char *xb = lds_in + q * PSTR + h * 16;
+#pragma unroll
+                    for (int k = 0; k < KGS; ++k) xd[m][k] = *reinterpret_cast<const vec *>(xb + (kg0 + k) * 32);
+                }
+            }
+            const char *wb = lds_w + tap * C::WTAP + lane * 16;
+#pragma unroll
+            for (int k = 0; k < KGS; ++k)
+#pragma unroll
+                for (int n = 0; n < NF; ++n) wd[k][n] = *reinterpret_cast<const vec *>(wb + ((kg0 + k) * NF + n) * 1024);
+        };
+        load_step(0, xq[0], wv[0]);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            if (s + 1 < NSTEP) load_step(s + 1, xq[(s + 1) & 1], wv[(s + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < KGS; ++k)
+#pragma unroll
+                for (int n = 0; n < NF; ++n)
+#pragma unroll
+                    for (int m = 0; m < MF; ++m) mma_kg(acc[m][n], wv[s & 1][k][n], xq[s & 1][m][k]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto store = [&](int tile) {
+        const int b = tile / (ntx * nty), trem = tile - b * (ntx * nty);
+        const int ty = trem / ntx, tx = trem - ty * ntx;
+        conv_epilogue<T, MF, NF>(acc, p, b, 0, ty * C::TH + wq * MF, tx * 32 + r, h);
+    };
+
+    if (g == 0 && first < ntiles) stage(first);
+    __syncthreads();   // weights and group 0's first tile have landed (hipcc drains vmcnt(0) ahead of the barrier)
+    // slot s: the group with (s + g) even contracts its tile number (s - g) / 2; the other one stores the tile it contracted in
+    // the previous slot and stages the one it will contract in the next.  2 * rounds + 1 slots: the last one only stores.
+#pragma unroll 1
+    for (int sl = 0; sl <= 2 * rounds; ++sl) {
+        if (((sl + g) & 1) == 0) {
+            const int t = first + ((sl - g) >> 1) * stride;
+            if (sl < 2 * rounds && t < ntiles) contract(t);
+        } else {
+            const int tp = first + ((sl - 1 - g) >> 1) * stride, tn = first + ((sl + 1 - g) >> 1) * stride;
+            if (sl - 1 - g >= 0 && tp < ntiles) store(tp);
+            if (sl + 1 < 2 * rounds + 1 && tn < ntiles) stage(tn);
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T, int CK, int NF> static int launch_conv_pingpong(const ConvParams &p, hipStream_t s)
+{
+    using C = ConvPingCfg<T, CK, NF>;
+    static std::once_flag once;
+    static hipError_t init_err = hipSuccess;
+    std::call_once(once, [] {
+        init_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_pingpong_kernel<T, CK, NF>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    });
+    if (init_err != hipSuccess) return (int)init_err;
+    const int ncu = device_cu_count();
+    if (ncu <= 0) return (int)hipErrorInvalidDevice;
+    const int ntiles = ((p.Wout + 31) / 32) * ((p.Hout + C::TH - 1) / C::TH) * p.B;
+    const int wgs = (ntiles + 1) / 2;
+    conv3x3_pingpong_kernel<T, CK, NF><<<wgs < ncu ? wgs : ncu, 512, C::LDS_BYTES, s>>>(p);
+    return (int)hipGetLastError();
+}
+
 template <typename T, int CK, int NF, int WAVES> static int launch_conv_persist(const ConvParams &p, hipStream_t s)
 {
     using C = ConvPersistCfg<T, CK, NF, WAVES>;
@@ -635,6 +799,10 @@ template <typename T> static int launch_conv16(const ConvParams &p, hipStream_t 
         // measured at B=8 x 720p in bf16 (us per launch, tile-per-workgroup -> persistent): 64->64 670 -> 644,
         // 64->32 / 64->2 414 -> 370, 67->27 685 -> 557.  NOT used where it loses: 67->64 with 4 waves
         // (771 -> 915: one 4-wave workgroup per CU cannot overlap its own phases), 6->64, 32->3 (no gain).
+        const char *pp_ = getenv("EMAVFI_CONV_PINGPONG");   // read per call: the parity test flips it inside one process
+        const bool pingpong = pp_ != nullptr && pp_[0] == '1';
+        if (pingpong && p.ck == 64 && p.nf == 1) return launch_conv_pingpong<T, 64, 1>(p, s);
+        if (pingpong && p.ck == 64 && p.nf == 2) return launch_conv_pingpong<T, 64, 2>(p, s);
         if (p.ck == 64 && p.nf == 2) return launch_conv_persist<T, 64, 2, 8>(p, s);
         if (p.ck == 64 && p.nf == 1) return launch_conv_persist<T, 64, 1, 8>(p, s);
         if (p.ck == 80 && p.nf == 1) return launch_conv_persist<T, 80, 1, 8>(p, s);
