@@ -446,6 +446,31 @@ for dt in ("bf16", "fp16", "fp32"):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("cout,act", [(64, "relu"), (64, "none"), (48, "none"), (40, "relu")])
+@pytest.mark.parametrize("shape", [(2, 75, 131), (1, 16, 32), (1, 17, 33), (1, 360, 640)])
+def test_mfma16_conv_agrees_with_the_32x32_kernels(dtype, cout, act, shape, monkeypatch):
+    """conv3x3_persist16_kernel (v_mfma_f32_16x16x32, the product path for 16-bit 64 -> 33..64 layers) against the 32x32x16
+    kernels it replaces (EMAVFI_CONV_MFMA16=0): the fp32 accumulation groups 32 instead of 16 channels per MFMA, so the two
+    agree to fp32 rounding - after rounding to the storage type at most one unit in the last place, and almost everywhere
+    exactly.  (Accuracy against ATen is gated by test_conv3x3_matches_aten for both.)"""
+    B, H, W = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, 64, H, W, generator=g).to(DEV)
+    w = (torch.randn(cout, 64, 3, 3, generator=g) * 0.05).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV)
+    kw = dict(dtype=dtype, act=lib.ACT_RELU if act == "relu" else lib.ACT_NONE)
+    monkeypatch.setenv("EMAVFI_CONV_MFMA16", "0")
+    ref = lib.conv3x3(x, w, b, **kw).clone()
+    monkeypatch.setenv("EMAVFI_CONV_MFMA16", "1")
+    got = lib.conv3x3(x, w, b, **kw).clone()
+    assert torch.isfinite(got).all() and got.shape == ref.shape
+    ulp = 2.0 ** (-7 if dtype == "bf16" else -10)
+    err = (got - ref).abs()
+    assert (err <= ulp * ref.abs().clamp_min(2.0 ** -6)).all(), f"max {err.max().item():.3e}"
+    assert (err > 0).float().mean().item() < 0.02, "the two kernels should differ in rare last-place roundings only"
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("cout", [64, 32, 2])
 @pytest.mark.parametrize("shape", [(2, 75, 131), (1, 8, 32), (1, 17, 33), (2, 40, 64), (1, 360, 640)])
 def test_pingpong_conv_equals_the_persistent_kernel(dtype, cout, shape, monkeypatch):
@@ -457,6 +482,7 @@ def test_pingpong_conv_equals_the_persistent_kernel(dtype, cout, shape, monkeypa
     x = torch.randn(B, 64, H, W, generator=g).to(DEV)
     w = (torch.randn(cout, 64, 3, 3, generator=g) * 0.05).to(DEV)
     b = torch.randn(cout, generator=g).to(DEV)
+    monkeypatch.setenv("EMAVFI_CONV_MFMA16", "0")      # compare against the 32x32x16 persistent kernel, not the 16x16x32 one
     monkeypatch.setenv("EMAVFI_CONV_PINGPONG", "0")
     ref = lib.conv3x3(x, w, b, dtype=dtype).clone()
     monkeypatch.setenv("EMAVFI_CONV_PINGPONG", "1")

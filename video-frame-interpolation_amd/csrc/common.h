@@ -54,6 +54,17 @@ __device__ __forceinline__ void mma_kg(f32x16 &acc, const f16x8 &w, const f16x8 
 {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, acc, 0, 0, 0);
 }
+// the 16x16x32 shape: D[16 cout][16 pixel] += W[16][32] * X[32][16].  Lane (i = lane & 15, kb = lane >> 4) holds row / column i,
+// K elements kb*8 .. kb*8+7; the result lane (j = lane & 15, ib = lane >> 4) holds rows ib*4 .. ib*4+3 of column j.
+// tools/microbench/mfma_shape_power.hip: on this power-managed board it delivers 11 % more FLOP/s than 32x32x16, bare and LDS-fed.
+__device__ __forceinline__ void mma_k32(f32x4 &acc, const bf16x8 &w, const bf16x8 &x)
+{
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma_k32(f32x4 &acc, const f16x8 &w, const f16x8 &x)
+{
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, x, acc, 0, 0, 0);
+}
 __device__ __forceinline__ void mma_kg(f32x16 &acc, const f32x4 &w, const f32x4 &x)
 {
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], x[0], acc, 0, 0, 0);
@@ -147,6 +158,7 @@ struct ConvParams {
     int ck, nf, stride;  // host-side template selectors
     int round16;         // EMAVFI_AMP16: fp32-stored results (flow, offsets / masks, the frame) hold fp16-rounded values and
                          // sigmoid / tanh / (t+1)/2 round after every op, as fp16 tensors do under autocast
+    int mfma16;          // weights packed for v_mfma_f32_16x16x32 (conv3x3_persist16_kernel): [tap][k32][cout16 block][lane][16 B]
     int in_pieces;       // 16-byte pieces of an input pixel (single-chunk layers) that exist in memory; 0 = all CK of them.
                          // Pieces beyond read as zeros: the 72-channel fusion buffers feed CK = 80 layers this way.
 };

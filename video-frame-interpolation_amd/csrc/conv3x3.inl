@@ -435,6 +435,164 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_persist_kernel(const ConvP
 }
 
 // ------------------------------------------------------------------------------------------
+// The persistent kernel on v_mfma_f32_16x16x32 (16-bit types, CK = 64, two 32-channel fragments = 64 -> 64: five launches and a
+// quarter of the step).  The board is power-managed and this MFMA shape does the same MACs with half
+// the fp32 accumulator traffic: tools/microbench/mfma_shape_power.hip measures 11 % more FLOP/s at lower package power,
+// bare and LDS-fed.  Per wave and tile still 2 rows x 32 pixels x 64 channels: 4 pixel blocks x 4 channel blocks of 16 x 16,
+// 16 MFMAs per 32-channel step against 4 weight + 4 pixel fragments (the same 1 KiB of LDS per 16 K MACs as before).
+// The tile is stored unpadded with the XOR slot swizzle of the ping-pong kernel (a 16-lane ds_read_b128 group here mixes two
+// adjacent pieces of 8 + 8 consecutive pixels, which no padded stride serves without conflicts; the swizzle does for the
+// taps with dx = 0 and leaves a two-way conflict on a few lanes otherwise).  Weights come packed for this shape
+// (PackDesc::mfma16).  fp32 accumulation order inside a tap differs from the 32x32x16 kernels (32 channels per MFMA instead
+// of 16), so results agree with them to fp32 rounding, not bit for bit.
+// ------------------------------------------------------------------------------------------
+template <typename T, int CK, int NF> struct ConvP16Cfg {
+    static constexpr int WAVES = 8, MF = 2, TH = WAVES * MF, TW = 32, IH = TH + 2, IW = TW + 2;
+    static constexpr int PIECES = CK * (int)sizeof(T) / 16, PSTR = PIECES * 16, SP = PIECES;
+    static constexpr int K32 = CK / 32, NB = NF * 2, PB = MF * 2;
+    static constexpr int WTAP = K32 * NB * 1024, WINST = 9 * K32 * NB;
+    static constexpr int NSLOT = IH * IW * SP, NINST = (NSLOT + 63) / 64;
+    static constexpr int LDS_W = 9 * WTAP, LDS_IN = NINST * 1024, LDS_BYTES = LDS_W + LDS_IN;
+    static_assert(sizeof(T) == 2 && PIECES == 8, "16-bit storage, 64 input channels (8 pieces: the XOR swizzle's domain)");
+    static_assert(LDS_BYTES <= 160 * 1024, "resident weights + tile do not fit the 160 KiB LDS");
+};
+
+template <typename T, int CK, int NF>
+__global__ __launch_bounds__(512) void conv3x3_persist16_kernel(const ConvParams p)
+{
+    using C = ConvP16Cfg<T, CK, NF>;
+    using vec = typename DT<T>::vec;
+    constexpr int MF = C::MF, IW = C::IW, PSTR = C::PSTR, NB = C::NB, PB = C::PB;
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *lds_w = smem;
+    char *lds_in = smem + C::LDS_W;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kb = lane >> 4;
+    const char *zeros = (const char *)p.zeros;
+    const int npieces = p.in_pieces > 0 ? p.in_pieces : C::PIECES;
+
+#pragma unroll 1
+    for (int i = wave; i < C::WINST; i += C::WAVES)
+        __builtin_amdgcn_global_load_lds((gptr_t *)((const char *)p.w + i * 1024 + lane * 16), (lptr_t *)(lds_w + i * 1024), 16, 0, 0);
+
+    const int ntx = (p.Wout + 31) / 32, nty = (p.Hout + C::TH - 1) / C::TH;
+    const int ntiles = ntx * nty * p.B;
+    const int coutpad = NF * 32;
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / (ntx * nty), trem = tile - b * (ntx * nty);
+        const int ty = trem / ntx, tx = trem - ty * ntx;
+        const int iy0 = ty * C::TH - 1, ix0 = tx * 32 - 1;
+        const char *gin = (const char *)p.in + (size_t)b * p.Hin * p.Win * p.in_ps * sizeof(T);
+        if (tile != (int)blockIdx.x) __syncthreads();  // every wave has finished reading the previous tile
+#pragma unroll
+        for (int i = 0; i < (C::NINST + C::WAVES - 1) / C::WAVES; ++i) {
+            const int jn = i * C::WAVES + wave;
+            if (jn < C::NINST) {
+                const int sl = jn * 64 + lane;
+                const int pix = sl >> 3, pc = (sl & 7) ^ ((pix >> 1) & 7);   // slot -> the piece stored there
+                const int ly = pix / IW, lx = pix - ly * IW;
+                const int gy = iy0 + ly, gx = ix0 + lx;
+                const bool ok = sl < C::NSLOT && pc < npieces && gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
+                const char *src = ok ? gin + ((size_t)gy * p.Win + gx) * p.in_ps * sizeof(T) + pc * 16 : zeros;
+                __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)(lds_in + jn * 1024), 16, 0, 0);
+            }
+        }
+        // accumulators: block pb = 2 * m + c is row m of the wave, columns 16 c .. 16 c + 15; the lane's pixel is column j of it
+        f32x4 acc[PB][NB];
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            const float *bp = p.bias;
+            if (p.bias_mode == 1) {   // border-class bias table (motion_estimation.0, see conv_init_acc)
+                const int y = ty * C::TH + wave * MF + (pb >> 1), x = tx * 32 + (pb & 1) * 16 + j;
+                const int ym = (y >= 1 ? 1 : 0) | (y <= p.Hout - 2 ? 2 : 0);
+                const int xm = (x >= 1 ? 1 : 0) | (x <= p.Wout - 2 ? 2 : 0);
+                bp += ((size_t)b * 16 + ym * 4 + xm) * coutpad;
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[pb][nb][e] = bp[nb * 16 + kb * 4 + e];
+        }
+        __syncthreads();  // hipcc drains the DMA (vmcnt(0)) ahead of the barrier: tile (and, first time, weights) landed
+
+        {
+            constexpr int NSTEP = 9 * C::K32;
+            vec xq[2][PB], wq[2][NB];
+            auto load_step = [&](int s, vec (&xd)[PB], vec (&wd)[NB]) {
+                const int tap = s / C::K32, k32 = s - tap * C::K32;
+                const int dy = tap / 3, dx = tap - 3 * dy;
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) {
+                    const int q = ((wave * MF + (pb >> 1)) + dy) * IW + (pb & 1) * 16 + j + dx;
+                    xd[pb] = *reinterpret_cast<const vec *>(lds_in + q * PSTR + (((k32 * 4 + kb) ^ ((q >> 1) & 7)) << 4));
+                }
+                const char *wb = lds_w + tap * C::WTAP + k32 * NB * 1024 + lane * 16;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) wd[nb] = *reinterpret_cast<const vec *>(wb + nb * 1024);
+            };
+            load_step(0, xq[0], wq[0]);
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+                if (s + 1 < NSTEP) load_step(s + 1, xq[(s + 1) & 1], wq[(s + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb) mma_k32(acc[pb][nb], wq[s & 1][nb], xq[s & 1][pb]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+
+        // epilogue (channels-last T, bias already in, optional ReLU): channel blocks nb = 2 t and 2 t + 1 are exchanged between the
+        // lane rows with v_permlane16_swap so that every lane holds 8 consecutive channels of its pixel = one 16-byte store:
+        // row kb stores channels (2 t + (kb & 1)) * 16 + (kb >> 1) * 8 .. + 7
+        typedef __attribute__((ext_vector_type(2))) T pair_t;
+        const bool relu = p.epi == EPI_RELU;
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            const int y = ty * C::TH + wave * MF + (pb >> 1), x = tx * 32 + (pb & 1) * 16 + j;
+            const bool inside = y < p.Hout && x < p.Wout;
+            T *ob = reinterpret_cast<T *>(p.out) + (((size_t)b * p.Hout + (inside ? y : 0)) * p.Wout + (inside ? x : 0)) * p.out_ps + p.out_coff;
+#pragma unroll
+            for (int t = 0; t < NB / 2; ++t) {
+                unsigned a[2], c2[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    float v0 = acc[pb][2 * t][2 * i], v1 = acc[pb][2 * t][2 * i + 1], u0 = acc[pb][2 * t + 1][2 * i], u1 = acc[pb][2 * t + 1][2 * i + 1];
+                    if (relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); u0 = fmaxf(u0, 0.0f); u1 = fmaxf(u1, 0.0f); }
+                    const pair_t pa = {(T)v0, (T)v1}, pc2 = {(T)u0, (T)u1};
+                    const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, pa), __builtin_bit_cast(unsigned, pc2), false, false);
+                    a[i] = sw[0];
+                    c2[i] = sw[1];
+                }
+                const int c0 = (2 * t + (kb & 1)) * 16 + (kb >> 1) * 8;
+                if (inside && c0 < p.cstore) *reinterpret_cast<uint4 *>(ob + c0) = make_uint4(a[0], a[1], c2[0], c2[1]);
+            }
+        }
+    }
+}
+
+template <typename T, int CK, int NF> static int launch_conv_persist16(const ConvParams &p, hipStream_t s)
+{
+    using C = ConvP16Cfg<T, CK, NF>;
+    if (p.epi != EPI_NONE && p.epi != EPI_RELU) return -2;
+    static std::once_flag once;
+    static hipError_t init_err = hipSuccess;
+    std::call_once(once, [] {
+        init_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_persist16_kernel<T, CK, NF>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    });
+    if (init_err != hipSuccess) return (int)init_err;
+    const int ncu = device_cu_count();
+    if (ncu <= 0) return (int)hipErrorInvalidDevice;
+    const int ntiles = ((p.Wout + 31) / 32) * ((p.Hout + C::TH - 1) / C::TH) * p.B;
+    conv3x3_persist16_kernel<T, CK, NF><<<ntiles < ncu ? ntiles : ncu, 512, C::LDS_BYTES, s>>>(p);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // Ping-pong variant of the persistent kernel (16-bit, stride 1, one chunk, one pass).  In the kernel above all eight waves
 // of the workgroup walk through a tile's phases together - DMA in, contract, store out - so the matrix pipe idles during two
 // of the three (3.8 us of MFMA time in an 11.4 us tile).  Here the workgroup is two groups of four
@@ -795,6 +953,7 @@ template <typename T> static int launch_conv_any(const ConvParams &p, hipStream_
 // (CK, NF, waves): 64->64, 64->32 / 64->2, 67->27 of the mid_channels = 64 model.
 template <typename T> static int launch_conv16(const ConvParams &p, hipStream_t s, bool no_persistent)
 {
+    if (p.mfma16) return (p.ck == 64 && p.nf == 2 && p.stride == 1 && p.nchunk == 1 && p.npass == 1) ? launch_conv_persist16<T, 64, 2>(p, s) : -2;
     if (!no_persistent && p.stride == 1 && p.nchunk == 1 && p.npass == 1) {
         // measured at B=8 x 720p in bf16 (us per launch, tile-per-workgroup -> persistent): 64->64 670 -> 644,
         // 64->32 / 64->2 414 -> 370, 67->27 685 -> 557.  NOT used where it loses: 67->64 with 4 waves

@@ -54,6 +54,7 @@ struct Layer {
     size_t w_off = 0, b_off = 0, w_bytes = 0;
     bool deform = false;
     bool f16_of_bf16 = false;  // bf16 model, layer consumed by deform_pack_kernel: bf16-rounded weights stored as f16
+    bool mfma16 = false;       // packed for and run by conv3x3_persist16_kernel (v_mfma_f32_16x16x32): 16-bit 64 -> (33..64) layers
 };
 
 bool conv_geometry(Layer &L, int esize)
@@ -95,6 +96,10 @@ bool conv_geometry(Layer &L, int esize)
     }
     if (!conv_inst_exists(L.ck, L.nf, L.stride, esize)) return false;
     L.w_bytes = (size_t)L.npass * L.nchunk * 9 * (L.ck * esize / 32) * L.nf * 1024;
+    // full-resolution 64-channel layers with two output fragments: the 16x16x32 MFMA shape (conv3x3.inl, conv3x3_persist16_kernel).
+    // EMAVFI_CONV_MFMA16=0 keeps the 32x32x16 kernels (read per call: tests compare the two inside one process).
+    const char *m16 = getenv("EMAVFI_CONV_MFMA16");
+    L.mfma16 = esize == 2 && L.stride == 1 && L.ck == 64 && L.nf == 2 && L.nchunk == 1 && L.npass == 1 && !(m16 && m16[0] == '0');
     return true;
 }
 
@@ -245,7 +250,7 @@ int run_conv(const Plan &P, const Layer &L, const void *packed, const void *in, 
     c.Hout = (Hin + L.stride - 1) / L.stride; c.Wout = (Win + L.stride - 1) / L.stride;
     c.B = B; c.nchunk = L.nchunk; c.npass = L.npass; c.cstore = cstore;
     c.epi = epi; c.nplanes = nplanes; c.bias_mode = bias_table ? 1 : 0;
-    c.ck = L.ck; c.nf = L.nf; c.stride = L.stride;
+    c.ck = L.ck; c.nf = L.nf; c.stride = L.stride; c.mfma16 = L.mfma16 ? 1 : 0;
     return P.dtype == EMAVFI_F32 ? launch_conv3x3_f32(c, s) : P.dtype == EMAVFI_F16 ? launch_conv3x3_f16(c, s) : launch_conv3x3_bf16(c, s);
 }
 
@@ -285,6 +290,7 @@ int run_deform(const Plan &P, const Layer &L, const void *packed, const void *x,
 int pack_layer(const Layer &L, const void *const *params, void *packed, int dtype, hipStream_t s, bool bias_f16 = false)
 {
     PackDesc d{L.cout, L.cin_raw, L.cin_off, L.cin_take, L.ck, L.nchunk, L.nf, L.npass, L.perm, L.f16_of_bf16 ? 1 : 0, bias_f16 ? 1 : 0};
+    d.mfma16 = L.mfma16 ? 1 : 0;
     return launch_pack_conv((const float *)params[L.param], (const float *)params[L.param + 1], (char *)packed + L.w_off,
                             (float *)((char *)packed + L.b_off), d, L.f16_of_bf16 ? (int)EMAVFI_F16 : dtype, s);
 }
@@ -775,6 +781,7 @@ int emavfi_conv3x3(const float *x, const float *weight, const float *bias, float
     L.w_off = (char *)wp - (char *)workspace;
     L.b_off = (char *)bp - (char *)workspace;
     PackDesc d{L.cout, L.cin_raw, 0, L.cin_take, L.ck, L.nchunk, L.nf, L.npass, 0, 0};
+    d.mfma16 = L.mfma16 ? 1 : 0;
     if (hipMemsetAsync(zpage, 0, 256, s) != hipSuccess) return fail(EMAVFI_E_LAUNCH, "conv3x3: zero page memset failed");
     EMAVFI_TRY(launch_pack_conv(weight, bias, wp, bp, d, dtype, s), "conv3x3 pack");
     EMAVFI_TRY(launch_nchw_to_cl(x, xcl, B, Cin, H, W, L.cin_pad, dtype, s), "conv3x3 layout in");

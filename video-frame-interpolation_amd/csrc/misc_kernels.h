@@ -11,6 +11,7 @@ struct PackDesc {
     int via_bf16;                          // 1 = round every weight to bf16 first, then store it in the packed type
                                            // (f16 fragments holding the bf16 model's weights exactly: deform_pack.inl)
     int bias_f16;                          // 1 = the fp32 bias table holds fp16-rounded values (autocast casts the bias too)
+    int mfma16;                            // 1 = fragments for v_mfma_f32_16x16x32: [tap][k32][cout16 block][lane (i, kb)][8 elements]
 };
 
 int launch_pack_conv(const float *w, const float *bias, void *wp, float *bp, const PackDesc &d, int dtype, hipStream_t s);

@@ -54,8 +54,13 @@ __global__ void pack_conv_kernel(const float *__restrict__ w, const float *__res
         const int tap = t % 9; t /= 9;
         const int chunk = t % d.nchunk; t /= d.nchunk;
         const int pass = (int)t;
-        const int co = route_cout(pass * d.nf * 32 + n * 32 + (lane & 31), d.perm);
-        const int ci = chunk * d.ck + kg * CHKG + (lane >> 5) * EPV + e;
+        int co = route_cout(pass * d.nf * 32 + n * 32 + (lane & 31), d.perm);
+        int ci = chunk * d.ck + kg * CHKG + (lane >> 5) * EPV + e;
+        if (d.mfma16) {   // same number of elements, regrouped: (kg, n) enumerates (k32, cout16 block) = KG * nf = (KG / 2) * (2 nf)
+            const int flat = kg * d.nf + n, nb16 = 2 * d.nf, k32 = flat / nb16, blk = flat - k32 * nb16;
+            co = route_cout(pass * d.nf * 32 + blk * 16 + (lane & 15), d.perm);
+            ci = chunk * d.ck + k32 * 32 + (lane >> 4) * 8 + e;
+        }
         float v = 0.0f;
         if (co < d.cout && ci < d.cin_take) v = w[((size_t)co * d.cin_raw + d.cin_off + ci) * 9 + tap];
         if (d.via_bf16) v = (float)(bf16_t)v;
