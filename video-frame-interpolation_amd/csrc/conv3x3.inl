@@ -446,23 +446,26 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_persist_kernel(const ConvP
 // (PackDesc::mfma16).  fp32 accumulation order inside a tap differs from the 32x32x16 kernels (32 channels per MFMA instead
 // of 16), so results agree with them to fp32 rounding, not bit for bit.
 // ------------------------------------------------------------------------------------------
-template <typename T, int CK, int NF> struct ConvP16Cfg {
+// NF = 32-channel fragments the layer is packed for (2 NF blocks of 16 in the packed weights); NB = blocks of 16 output channels
+// the kernel computes: 2 NF, or 1 for the planar heads (flow: 2 channels), which then do half the MFMAs of a 32-wide fragment.
+template <typename T, int CK, int NF, int NB> struct ConvP16Cfg {
     static constexpr int WAVES = 8, MF = 2, TH = WAVES * MF, TW = 32, IH = TH + 2, IW = TW + 2;
     static constexpr int PIECES = CK * (int)sizeof(T) / 16, PSTR = PIECES * 16, SP = PIECES;
-    static constexpr int K32 = CK / 32, NB = NF * 2, PB = MF * 2;
-    static constexpr int WTAP = K32 * NB * 1024, WINST = 9 * K32 * NB;
+    static constexpr int K32 = CK / 32, NBP = NF * 2, PB = MF * 2;
+    static constexpr int WTAP = K32 * NBP * 1024, WINST = 9 * K32 * NBP;
     static constexpr int NSLOT = IH * IW * SP, NINST = (NSLOT + 63) / 64;
     static constexpr int LDS_W = 9 * WTAP, LDS_IN = NINST * 1024, LDS_BYTES = LDS_W + LDS_IN;
     static_assert(sizeof(T) == 2 && PIECES == 8, "16-bit storage, 64 input channels (8 pieces: the XOR swizzle's domain)");
+    static_assert(NB == NBP || NB == 1, "all packed blocks, or the first one only");
     static_assert(LDS_BYTES <= 160 * 1024, "resident weights + tile do not fit the 160 KiB LDS");
 };
 
-template <typename T, int CK, int NF>
+template <typename T, int CK, int NF, int NB>
 __global__ __launch_bounds__(512) void conv3x3_persist16_kernel(const ConvParams p)
 {
-    using C = ConvP16Cfg<T, CK, NF>;
+    using C = ConvP16Cfg<T, CK, NF, NB>;
     using vec = typename DT<T>::vec;
-    constexpr int MF = C::MF, IW = C::IW, PSTR = C::PSTR, NB = C::NB, PB = C::PB;
+    constexpr int MF = C::MF, IW = C::IW, PSTR = C::PSTR, PB = C::PB, NBP = C::NBP;
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -529,7 +532,7 @@ __global__ __launch_bounds__(512) void conv3x3_persist16_kernel(const ConvParams
                     const int q = ((wave * MF + (pb >> 1)) + dy) * IW + (pb & 1) * 16 + j + dx;
                     xd[pb] = *reinterpret_cast<const vec *>(lds_in + q * PSTR + (((k32 * 4 + kb) ^ ((q >> 1) & 7)) << 4));
                 }
-                const char *wb = lds_w + tap * C::WTAP + k32 * NB * 1024 + lane * 16;
+                const char *wb = lds_w + tap * C::WTAP + k32 * NBP * 1024 + lane * 16;
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) wd[nb] = *reinterpret_cast<const vec *>(wb + nb * 1024);
             };
@@ -546,50 +549,82 @@ __global__ __launch_bounds__(512) void conv3x3_persist16_kernel(const ConvParams
             }
         }
 
-        // epilogue (channels-last T, bias already in, optional ReLU): channel blocks nb = 2 t and 2 t + 1 are exchanged between the
-        // lane rows with v_permlane16_swap so that every lane holds 8 consecutive channels of its pixel = one 16-byte store:
-        // row kb stores channels (2 t + (kb & 1)) * 16 + (kb >> 1) * 8 .. + 7
-        typedef __attribute__((ext_vector_type(2))) T pair_t;
-        const bool relu = p.epi == EPI_RELU;
+        if constexpr (NB == 1) {
+            // planar heads (flow / frame): <= 4 real channels = the four accumulator registers of the lanes with kb == 0, written
+            // as NCHW fp32 planes exactly as conv_epilogue does
 #pragma unroll
-        for (int pb = 0; pb < PB; ++pb) {
-            const int y = ty * C::TH + wave * MF + (pb >> 1), x = tx * 32 + (pb & 1) * 16 + j;
-            const bool inside = y < p.Hout && x < p.Wout;
-            T *ob = reinterpret_cast<T *>(p.out) + (((size_t)b * p.Hout + (inside ? y : 0)) * p.Wout + (inside ? x : 0)) * p.out_ps + p.out_coff;
+            for (int pb = 0; pb < PB; ++pb) {
+                const int y = ty * C::TH + wave * MF + (pb >> 1), x = tx * 32 + (pb & 1) * 16 + j;
+                if (kb != 0 || y >= p.Hout || x >= p.Wout) continue;
+                const size_t plane = (size_t)p.Hout * p.Wout;
 #pragma unroll
-            for (int t = 0; t < NB / 2; ++t) {
-                unsigned a[2], c2[2];
+                for (int c = 0; c < 4; ++c)
+                    if (c < p.nplanes) {
+                        float v = acc[pb][0][c];
+                        if (p.round16) {
+                            v = (float)(half_t)v;
+                            if (p.epi == EPI_PLANAR_TANH01) v = (float)(half_t)((float)(half_t)tanhf(v) + 1.0f) / 2.0f;
+                        } else if (p.epi == EPI_PLANAR_TANH01) v = (tanhf(v) + 1.0f) / 2.0f;
+                        p.out_planar[((size_t)b * p.nplanes + c) * plane + (size_t)y * p.Wout + x] = v;
+                    }
+            }
+        } else {
+            // channels-last T, bias already in, optional ReLU: channel blocks nb = 2 t and 2 t + 1 are exchanged between the lane
+            // rows with v_permlane16_swap so that every lane holds 8 consecutive channels of its pixel = one 16-byte store:
+            // row kb stores channels (2 t + (kb & 1)) * 16 + (kb >> 1) * 8 .. + 7
+            typedef __attribute__((ext_vector_type(2))) T pair_t;
+            const bool relu = p.epi == EPI_RELU;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    float v0 = acc[pb][2 * t][2 * i], v1 = acc[pb][2 * t][2 * i + 1], u0 = acc[pb][2 * t + 1][2 * i], u1 = acc[pb][2 * t + 1][2 * i + 1];
-                    if (relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); u0 = fmaxf(u0, 0.0f); u1 = fmaxf(u1, 0.0f); }
-                    const pair_t pa = {(T)v0, (T)v1}, pc2 = {(T)u0, (T)u1};
-                    const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, pa), __builtin_bit_cast(unsigned, pc2), false, false);
-                    a[i] = sw[0];
-                    c2[i] = sw[1];
+            for (int pb = 0; pb < PB; ++pb) {
+                const int y = ty * C::TH + wave * MF + (pb >> 1), x = tx * 32 + (pb & 1) * 16 + j;
+                const bool inside = y < p.Hout && x < p.Wout;
+                T *ob = reinterpret_cast<T *>(p.out) + (((size_t)b * p.Hout + (inside ? y : 0)) * p.Wout + (inside ? x : 0)) * p.out_ps + p.out_coff;
+#pragma unroll
+                for (int t = 0; t < NB / 2; ++t) {
+                    unsigned a[2], c2[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        float v0 = acc[pb][2 * t][2 * i], v1 = acc[pb][2 * t][2 * i + 1], u0 = acc[pb][2 * t + 1][2 * i], u1 = acc[pb][2 * t + 1][2 * i + 1];
+                        if (relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); u0 = fmaxf(u0, 0.0f); u1 = fmaxf(u1, 0.0f); }
+                        const pair_t pa = {(T)v0, (T)v1}, pc2 = {(T)u0, (T)u1};
+                        const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, pa), __builtin_bit_cast(unsigned, pc2), false, false);
+                        a[i] = sw[0];
+                        c2[i] = sw[1];
+                    }
+                    const int c0 = (2 * t + (kb & 1)) * 16 + (kb >> 1) * 8;
+                    if (inside && c0 < p.cstore) *reinterpret_cast<uint4 *>(ob + c0) = make_uint4(a[0], a[1], c2[0], c2[1]);
                 }
-                const int c0 = (2 * t + (kb & 1)) * 16 + (kb >> 1) * 8;
-                if (inside && c0 < p.cstore) *reinterpret_cast<uint4 *>(ob + c0) = make_uint4(a[0], a[1], c2[0], c2[1]);
             }
         }
     }
 }
 
-template <typename T, int CK, int NF> static int launch_conv_persist16(const ConvParams &p, hipStream_t s)
+template <typename T, int CK, int NF, int NB> static int launch_conv_persist16(const ConvParams &p, hipStream_t s)
 {
-    using C = ConvP16Cfg<T, CK, NF>;
-    if (p.epi != EPI_NONE && p.epi != EPI_RELU) return -2;
+    using C = ConvP16Cfg<T, CK, NF, NB>;
     static std::once_flag once;
     static hipError_t init_err = hipSuccess;
     std::call_once(once, [] {
-        init_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_persist16_kernel<T, CK, NF>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        init_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_persist16_kernel<T, CK, NF, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     });
     if (init_err != hipSuccess) return (int)init_err;
     const int ncu = device_cu_count();
     if (ncu <= 0) return (int)hipErrorInvalidDevice;
     const int ntiles = ((p.Wout + 31) / 32) * ((p.Hout + C::TH - 1) / C::TH) * p.B;
-    conv3x3_persist16_kernel<T, CK, NF><<<ntiles < ncu ? ntiles : ncu, 512, C::LDS_BYTES, s>>>(p);
+    conv3x3_persist16_kernel<T, CK, NF, NB><<<ntiles < ncu ? ntiles : ncu, 512, C::LDS_BYTES, s>>>(p);
     return (int)hipGetLastError();
+}
+
+// weights packed for the 16x16x32 shape (ConvParams::mfma16): 64 -> 64 (four blocks), 64 -> 32 (two), 64 -> planes (one)
+template <typename T> static int launch_conv_mfma16(const ConvParams &p, hipStream_t s)
+{
+    if (p.ck != 64 || p.stride != 1 || p.nchunk != 1 || p.npass != 1) return -2;
+    const bool planar = p.epi == EPI_PLANAR || p.epi == EPI_PLANAR_TANH01;
+    if (!planar && p.epi != EPI_NONE && p.epi != EPI_RELU) return -2;
+    if (p.nf == 2 && !planar) return launch_conv_persist16<T, 64, 2, 4>(p, s);
+    if (p.nf == 1 && !planar) return launch_conv_persist16<T, 64, 1, 2>(p, s);
+    if (p.nf == 1 && planar && p.nplanes <= 4) return launch_conv_persist16<T, 64, 1, 1>(p, s);
+    return -2;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -953,7 +988,7 @@ template <typename T> static int launch_conv_any(const ConvParams &p, hipStream_
 // (CK, NF, waves): 64->64, 64->32 / 64->2, 67->27 of the mid_channels = 64 model.
 template <typename T> static int launch_conv16(const ConvParams &p, hipStream_t s, bool no_persistent)
 {
-    if (p.mfma16) return (p.ck == 64 && p.nf == 2 && p.stride == 1 && p.nchunk == 1 && p.npass == 1) ? launch_conv_persist16<T, 64, 2>(p, s) : -2;
+    if (p.mfma16) return launch_conv_mfma16<T>(p, s);
     if (!no_persistent && p.stride == 1 && p.nchunk == 1 && p.npass == 1) {
         // measured at B=8 x 720p in bf16 (us per launch, tile-per-workgroup -> persistent): 64->64 670 -> 644,
         // 64->32 / 64->2 414 -> 370, 67->27 685 -> 557.  NOT used where it loses: 67->64 with 4 waves

@@ -54,7 +54,7 @@ struct Layer {
     size_t w_off = 0, b_off = 0, w_bytes = 0;
     bool deform = false;
     bool f16_of_bf16 = false;  // bf16 model, layer consumed by deform_pack_kernel: bf16-rounded weights stored as f16
-    bool mfma16 = false;       // packed for and run by conv3x3_persist16_kernel (v_mfma_f32_16x16x32): 16-bit 64 -> (33..64) layers
+    bool mfma16 = false;       // packed for and run by conv3x3_persist16_kernel (v_mfma_f32_16x16x32): 16-bit full-resolution 64 -> (1..64) layers
 };
 
 bool conv_geometry(Layer &L, int esize)
@@ -99,7 +99,7 @@ bool conv_geometry(Layer &L, int esize)
     // full-resolution 64-channel layers with two output fragments: the 16x16x32 MFMA shape (conv3x3.inl, conv3x3_persist16_kernel).
     // EMAVFI_CONV_MFMA16=0 keeps the 32x32x16 kernels (read per call: tests compare the two inside one process).
     const char *m16 = getenv("EMAVFI_CONV_MFMA16");
-    L.mfma16 = esize == 2 && L.stride == 1 && L.ck == 64 && L.nf == 2 && L.nchunk == 1 && L.npass == 1 && !(m16 && m16[0] == '0');
+    L.mfma16 = esize == 2 && L.stride == 1 && L.ck == 64 && (L.nf == 2 || L.nf == 1) && L.nchunk == 1 && L.npass == 1 && !(m16 && m16[0] == '0');
     return true;
 }
 
@@ -540,10 +540,11 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
     // 16-bit types at mid_channels = 64: reconstruction.1 and .2 can run as one launch whose 32-channel intermediate stays in
     // the LDS (conv3x3.inl, conv3x3_tail_kernel; bit-identical to the two launches).  Built for VERDICT r1 item 4 and measured
     // SLOWER (677 vs 362 + 232 us at B=8 x 720p: +33 % recomputed positions, one fragment per wave = no operand reuse, one
-    // workgroup per CU), so it is opt-in: EMAVFI_FUSED_TAIL=1.  Read per call: the parity test flips it inside one process.
+    // workgroup per CU), so it is opt-in: EMAVFI_FUSED_TAIL=1 together with EMAVFI_CONV_MFMA16=0 (the tail kernel reads
+    // reconstruction.1's weights in the 32x32x16 packing).  Read per call: the parity test flips it inside one process.
     const char *ft_ = getenv("EMAVFI_FUSED_TAIL");
     const bool fused_tail_off = !(ft_ != nullptr && ft_[0] == '1');
-    if (P.esize == 2 && !fused_tail_off && P.r1.ck == 64 && P.r1.nf == 1 && P.r1.nchunk == 1 && P.r2.ck == 32 && P.r2.nf == 1 && P.r2.nchunk == 1) {
+    if (P.esize == 2 && !fused_tail_off && !P.r1.mfma16 && P.r1.ck == 64 && P.r1.nf == 1 && P.r1.nchunk == 1 && P.r2.ck == 32 && P.r2.nf == 1 && P.r2.nchunk == 1) {
         double fl2 = 0.0, by2 = 0.0;
         conv_work(P, P.r1, B, H, W, e, fl, by);
         conv_work(P, P.r2, B, H, W, 4.0, fl2, by2);

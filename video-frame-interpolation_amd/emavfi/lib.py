@@ -80,6 +80,12 @@ def fingerprint() -> str:
     return _fingerprint
 
 
+def layout_switches() -> str:
+    """Diagnostic environment switches the PACKED LAYOUT depends on (csrc/emavfi_api.hip, conv_geometry): a blob packed under one
+    setting must not be run under another, so the setting is part of the in-memory and on-disk cache keys of the packed weights."""
+    return "|".join(f"{k}={os.environ.get(k, '')}" for k in ("EMAVFI_CONV_MFMA16", "EMAVFI_CONV_S2_CK64"))
+
+
 def last_error() -> str:
     return (load().emavfi_last_error() or b"").decode("utf-8", "replace")
 

@@ -159,7 +159,7 @@ class EMA_VFI(nn.Module):
         return [p for _, p in self.named_parameters()]
 
     def _weights_key(self, device):
-        return (str(device),) + tuple((p.data_ptr(), p._version) for p in self._ordered_params())
+        return (str(device), _lib.layout_switches()) + tuple((p.data_ptr(), p._version) for p in self._ordered_params())
 
     def _versions(self):
         return tuple(p._version for p in self._ordered_params())
@@ -223,7 +223,7 @@ class EMA_VFI(nn.Module):
         if d is None:
             return None
         h = hashlib.sha256()
-        h.update(f"{_lib.fingerprint()}|{dt}|{self.in_channels}|{self.mid_channels}|{self.num_blocks}|{nbytes}".encode())
+        h.update(f"{_lib.fingerprint()}|{_lib.layout_switches()}|{dt}|{self.in_channels}|{self.mid_channels}|{self.num_blocks}|{nbytes}".encode())
         for name, p in zip((k for k, _ in self.named_parameters()), params):
             h.update(name.encode())
             h.update(p.cpu().numpy().tobytes())
