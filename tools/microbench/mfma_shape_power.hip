@@ -90,7 +90,7 @@ template <int SHAPE, bool READS> static int run(const char *name, float *sink)
         CHECK(hipDeviceSynchronize());
     }
     const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    printf("%-44s %8.1f TFLOP/s   mid-run [power W, sclk]: %s\n", name, flop_per_launch * launches / el / 1e12, mid.c_str());
+    printf("%-44s %8.1f TFLOP/s   mid-run [sclk, package power W]: %s\n", name, flop_per_launch * launches / el / 1e12, mid.c_str());
     return 0;
 }
 
