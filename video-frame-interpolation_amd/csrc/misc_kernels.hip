@@ -96,10 +96,12 @@ __global__ void pack_ctx_kernel(const float *__restrict__ lin_w, const float *__
     float *o_lw = dst, *o_lb = o_lw + (size_t)m * 4 * m, *o_w9 = o_lb + m, *o_b9 = o_w9 + (size_t)m * m * 9;
     const int n_lw = m * 4 * m, n_w9 = m * m * 9;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_lw + n_w9 + 2 * m; i += gridDim.x * blockDim.x) {
-        if (i < n_lw) o_lw[i] = rq(lin_w[i]);
-        else if (i < n_lw + m) o_lb[i - n_lw] = rq(lin_b[i - n_lw]);
-        else if (i < n_lw + m + n_w9) {
-            const int k = i - n_lw - m, o = k / (m * 9), rem = k - o * m * 9, c = rem / 9, tap = rem - c * 9;
+        if (i < n_lw) {   // Linear weight transposed to [c][o]: the threads of ctx_finish_kernel (one per o) read consecutive addresses
+            const int c = i / m, o = i - c * m;
+            o_lw[i] = rq(lin_w[(size_t)o * 4 * m + c]);
+        } else if (i < n_lw + m) o_lb[i - n_lw] = rq(lin_b[i - n_lw]);
+        else if (i < n_lw + m + n_w9) {   // context half of motion_estimation.0's weight as [c][o * 9 + tap]
+            const int k = i - n_lw - m, c = k / (m * 9), rem = k - c * m * 9, o = rem / 9, tap = rem - o * 9;
             o_w9[k] = rq(w9[((size_t)o * 2 * m + m + c) * 9 + tap]);
         } else o_b9[i - n_lw - m - n_w9] = rq(b9[i - n_lw - m - n_w9]);
     }
@@ -270,7 +272,8 @@ int launch_pool_partial(const void *src, float *part, int B, int npix, int cp, i
     return (int)hipGetLastError();
 }
 
-// One block per sample.  ctxw = [lin_w m x 4m][lin_b m][w9c m x m x 9][b9 m] (pack_ctx_kernel).
+// One block per sample (m <= 64: 4m divides 256).  ctxw = [lin_w TRANSPOSED 4m x m][lin_b m][w9c as [c][o * 9 + tap]][b9 m]
+// (pack_ctx_kernel): every loop below reads consecutive addresses from consecutive threads.
 // Writes ctx[b][m] and the border-class bias table R[b][16][coutpad]:
 //   R[cls][o] = b9[o] + sum over taps (ky,kx) inside the image for that class of
 //               sum_c W9[o, m + c, ky, kx] * ctx[c]
@@ -286,24 +289,54 @@ __global__ __launch_bounds__(256) void ctx_finish_kernel(const float *__restrict
     const int b = blockIdx.x, tid = threadIdx.x;
     const float *lw = ctxw, *lb = lw + (size_t)m * 4 * m, *w9 = lb + m, *b9 = w9 + (size_t)m * m * 9;
     for (int c = tid; c < 4 * m; c += 256) {
-        float s = 0.0f;
-        for (int q = 0; q < nparts; ++q) s += part[((size_t)b * nparts + q) * cp + c];
+        // up to 256 partial sums per channel: eight independent chains keep eight loads in flight (one chain = one L2 round
+        // trip per partial sum, which was most of this kernel's 90 us); fixed combination order, so still deterministic
+        float a[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        const float *pp = part + (size_t)b * nparts * cp + c;
+        int q = 0;
+        for (; q + 8 <= nparts; q += 8)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += pp[(size_t)(q + u) * cp];
+        for (; q < nparts; ++q) a[0] += pp[(size_t)q * cp];
+        const float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
         mean[c] = rq(s / (float)npix);
     }
     __syncthreads();
-    for (int o = tid; o < m; o += 256) {
-        float s = lb[o];
-        for (int c = 0; c < 4 * m; ++c) s = fmaf(lw[(size_t)o * 4 * m + c], mean[c], s);
-        s = rq(s);
-        ctx[o] = s;
-        ctx_out[(size_t)b * m + o] = s;
+    // Linear (ema_vfi.py:91, 121): all 256 threads, thread (o, quarter) sums a quarter of the 4m inputs from the [c][o] copy
+    // (coalesced), the four partial sums of an output are added in a fixed order
+    {
+        const int nq = 256 / m > 0 ? (256 / m < 4 ? 256 / m : 4) : 1;   // m = 64: 4 quarters
+        const int o = tid % m, qd = tid / m, per = (4 * m + nq - 1) / nq;
+        float s = 0.0f;
+        if (qd < nq) {   // four independent chains: four weight loads in flight
+            float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            const int c1 = (qd + 1) * per < 4 * m ? (qd + 1) * per : 4 * m;
+            int c = qd * per;
+            for (; c + 4 <= c1; c += 4)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[u] = fmaf(lw[(size_t)(c + u) * m + o], mean[c + u], a[u]);
+            for (; c < c1; ++c) a[0] = fmaf(lw[(size_t)c * m + o], mean[c], a[0]);
+            s = (a[0] + a[1]) + (a[2] + a[3]);
+            tsum[qd * m + o] = s;   // tsum is free until the next phase (m * 9 >= 4 * m floats)
+        }
+        __syncthreads();
+        if (tid < m) {
+            float t = lb[tid];
+            for (int q = 0; q < nq; ++q) t += tsum[q * m + tid];
+            t = rq(t);
+            ctx[tid] = t;
+            ctx_out[(size_t)b * m + tid] = t;
+        }
     }
     __syncthreads();
-    for (int k = tid; k < m * 9; k += 256) {
-        const int o = k / 9, tap = k - o * 9;
-        float s = 0.0f;
-        for (int c = 0; c < m; ++c) s = fmaf(w9[((size_t)o * m + c) * 9 + tap], ctx[c], s);
-        tsum[k] = s;
+    for (int k = tid; k < m * 9; k += 256) {   // [c][o * 9 + tap]: consecutive threads, consecutive addresses
+        float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        int c = 0;
+        for (; c + 4 <= m; c += 4)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = fmaf(w9[(size_t)(c + u) * m * 9 + k], ctx[c + u], a[u]);
+        for (; c < m; ++c) a[0] = fmaf(w9[(size_t)c * m * 9 + k], ctx[c], a[0]);
+        tsum[k] = (a[0] + a[1]) + (a[2] + a[3]);
     }
     __syncthreads();
     for (int k = tid; k < 16 * coutpad; k += 256) {
