@@ -446,6 +446,27 @@ for dt in ("bf16", "fp16", "fp32"):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("cout,act", [(64, "relu"), (48, "none")])
+@pytest.mark.parametrize("shape", [(2, 75, 131), (1, 8, 32), (1, 17, 33), (2, 40, 64), (1, 360, 640)])
+def test_pingpong16_equals_the_lockstep_16x16x32_kernel(dtype, cout, act, shape, monkeypatch):
+    """The product kernel of the 64 -> 64 layers (conv3x3_pingpong16_kernel) against conv3x3_persist16_kernel
+    (EMAVFI_CONV_PINGPONG=0): same MFMA shape, same accumulation order - bit-identical; one tile, odd tile counts per group,
+    tiles hanging over every edge."""
+    B, H, W = shape
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(B, 64, H, W, generator=g).to(DEV)
+    w = (torch.randn(cout, 64, 3, 3, generator=g) * 0.05).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV)
+    kw = dict(dtype=dtype, act=lib.ACT_RELU if act == "relu" else lib.ACT_NONE)
+    monkeypatch.setenv("EMAVFI_CONV_PINGPONG", "0")
+    ref = lib.conv3x3(x, w, b, **kw).clone()
+    monkeypatch.delenv("EMAVFI_CONV_PINGPONG")
+    got = lib.conv3x3(x, w, b, **kw).clone()
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, ref), f"{int((got != ref).sum())} of {got.numel()} elements differ, max {(got - ref).abs().max().item():.3e}"
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("cout,act", [(64, "relu"), (64, "none"), (48, "none"), (40, "relu"), (32, "relu"), (24, "none"), (2, "none"), (3, "tanh01")])
 @pytest.mark.parametrize("shape", [(2, 75, 131), (1, 16, 32), (1, 17, 33), (1, 360, 640)])
 def test_mfma16_conv_agrees_with_the_32x32_kernels(dtype, cout, act, shape, monkeypatch):

@@ -615,12 +615,170 @@ template <typename T, int CK, int NF, int NB> static int launch_conv_persist16(c
     return (int)hipGetLastError();
 }
 
+// The 16x16x32 kernel with the ping-pong schedule (see conv3x3_pingpong_kernel below): two groups of four waves, each with
+// its own 8-row tile buffer (unpadded + XOR swizzle: 72 KiB of weights + 2 x 44 KiB fit), one group in its MFMA loop while the
+// other stores its previous tile and DMAs its next.  Channels-last epilogue only (64 -> 64).  The product's kernel for these
+// layers; bit-identical to conv3x3_persist16_kernel (EMAVFI_CONV_PINGPONG=0).
+template <typename T, int CK, int NF>
+__global__ __launch_bounds__(512) void conv3x3_pingpong16_kernel(const ConvParams p)
+{
+    constexpr int GW = 4, MF = 2, TH = GW * MF, IH = TH + 2, IW = 34, PSTR = 128, K32 = CK / 32, NB = NF * 2, PB = MF * 2;
+    constexpr int WTAP = K32 * NB * 1024, WINST = 9 * K32 * NB, NSLOT = IH * IW * 8, NINST = (NSLOT + 63) / 64;
+    constexpr int LDS_W = 9 * WTAP, LDS_IN = NINST * 1024;
+    static_assert(sizeof(T) == 2 && CK * 2 / 16 == 8 && LDS_W + 2 * LDS_IN <= 160 * 1024, "64 input channels, 16-bit, two tiles beside the weights");
+    using vec = typename DT<T>::vec;
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *lds_w = smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = wave >> 2, wq = wave & 3;
+    char *lds_in = smem + LDS_W + g * LDS_IN;
+    const int j = lane & 15, kb = lane >> 4;
+    const char *zeros = (const char *)p.zeros;
+    const int npieces = p.in_pieces > 0 ? p.in_pieces : 8;
+#pragma unroll 1
+    for (int i = wave; i < WINST; i += 8)
+        __builtin_amdgcn_global_load_lds((gptr_t *)((const char *)p.w + i * 1024 + lane * 16), (lptr_t *)(lds_w + i * 1024), 16, 0, 0);
+    const int ntx = (p.Wout + 31) / 32, nty = (p.Hout + TH - 1) / TH;
+    const int ntiles = ntx * nty * p.B;
+    const int first = (int)blockIdx.x * 2 + g, stride = (int)gridDim.x * 2;
+    const int rounds = ((int)blockIdx.x * 2 < ntiles) ? (ntiles - (int)blockIdx.x * 2 + stride - 1) / stride : 0;
+    const int coutpad = NF * 32;
+
+    auto stage = [&](int tile) {
+        const int b = tile / (ntx * nty), trem = tile - b * (ntx * nty);
+        const int ty = trem / ntx, tx = trem - ty * ntx;
+        const int iy0 = ty * TH - 1, ix0 = tx * 32 - 1;
+        const char *gin = (const char *)p.in + (size_t)b * p.Hin * p.Win * p.in_ps * sizeof(T);
+#pragma unroll
+        for (int i = 0; i < (NINST + GW - 1) / GW; ++i) {
+            const int jn = i * GW + wq;
+            if (jn < NINST) {
+                const int sl = jn * 64 + lane;
+                const int pix = sl >> 3, pc = (sl & 7) ^ ((pix >> 1) & 7);
+                const int ly = pix / IW, lx = pix - ly * IW;
+                const int gy = iy0 + ly, gx = ix0 + lx;
+                const bool ok = sl < NSLOT && pc < npieces && gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
+                const char *src = ok ? gin + ((size_t)gy * p.Win + gx) * p.in_ps * sizeof(T) + pc * 16 : zeros;
+                __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)(lds_in + jn * 1024), 16, 0, 0);
+            }
+        }
+    };
+    f32x4 acc[PB][NB];
+    auto contract = [&](int tile) {
+        const int b = tile / (ntx * nty), trem = tile - b * (ntx * nty);
+        const int ty = trem / ntx, tx = trem - ty * ntx;
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            const float *bp = p.bias;
+            if (p.bias_mode == 1) {
+                const int y = ty * TH + wq * MF + (pb >> 1), x = tx * 32 + (pb & 1) * 16 + j;
+                const int ym = (y >= 1 ? 1 : 0) | (y <= p.Hout - 2 ? 2 : 0);
+                const int xm = (x >= 1 ? 1 : 0) | (x <= p.Wout - 2 ? 2 : 0);
+                bp += ((size_t)b * 16 + ym * 4 + xm) * coutpad;
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[pb][nb][e] = bp[nb * 16 + kb * 4 + e];
+        }
+        constexpr int NSTEP = 9 * K32;
+        vec xq[2][PB], wv[2][NB];
+        auto load_step = [&](int s, vec (&xd)[PB], vec (&wd)[NB]) {
+            const int tap = s / K32, k32 = s - tap * K32;
+            const int dy = tap / 3, dx = tap - 3 * dy;
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) {
+                const int q = ((wq * MF + (pb >> 1)) + dy) * IW + (pb & 1) * 16 + j + dx;
+                xd[pb] = *reinterpret_cast<const vec *>(lds_in + q * PSTR + (((k32 * 4 + kb) ^ ((q >> 1) & 7)) << 4));
+            }
+            const char *wb = lds_w + tap * WTAP + k32 * NB * 1024 + lane * 16;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) wd[nb] = *reinterpret_cast<const vec *>(wb + nb * 1024);
+        };
+        load_step(0, xq[0], wv[0]);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            if (s + 1 < NSTEP) load_step(s + 1, xq[(s + 1) & 1], wv[(s + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) mma_k32(acc[pb][nb], wv[s & 1][nb], xq[s & 1][pb]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto store = [&](int tile) {
+        const int b = tile / (ntx * nty), trem = tile - b * (ntx * nty);
+        const int ty = trem / ntx, tx = trem - ty * ntx;
+        typedef __attribute__((ext_vector_type(2))) T pair_t;
+        const bool relu = p.epi == EPI_RELU;
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            const int y = ty * TH + wq * MF + (pb >> 1), x = tx * 32 + (pb & 1) * 16 + j;
+            const bool inside = y < p.Hout && x < p.Wout;
+            T *ob = reinterpret_cast<T *>(p.out) + (((size_t)b * p.Hout + (inside ? y : 0)) * p.Wout + (inside ? x : 0)) * p.out_ps + p.out_coff;
+#pragma unroll
+            for (int t = 0; t < NB / 2; ++t) {
+                unsigned a[2], c2[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    float v0 = acc[pb][2 * t][2 * i], v1 = acc[pb][2 * t][2 * i + 1], u0 = acc[pb][2 * t + 1][2 * i], u1 = acc[pb][2 * t + 1][2 * i + 1];
+                    if (relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); u0 = fmaxf(u0, 0.0f); u1 = fmaxf(u1, 0.0f); }
+                    const pair_t pa = {(T)v0, (T)v1}, pc2 = {(T)u0, (T)u1};
+                    const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, pa), __builtin_bit_cast(unsigned, pc2), false, false);
+                    a[i] = sw[0];
+                    c2[i] = sw[1];
+                }
+                const int c0 = (2 * t + (kb & 1)) * 16 + (kb >> 1) * 8;
+                if (inside && c0 < p.cstore) *reinterpret_cast<uint4 *>(ob + c0) = make_uint4(a[0], a[1], c2[0], c2[1]);
+            }
+        }
+    };
+    if (g == 0 && first < ntiles) stage(first);
+    __syncthreads();
+#pragma unroll 1
+    for (int sl = 0; sl <= 2 * rounds; ++sl) {
+        if (((sl + g) & 1) == 0) {
+            const int t = first + ((sl - g) >> 1) * stride;
+            if (sl < 2 * rounds && t < ntiles) contract(t);
+        } else {
+            const int tp = first + ((sl - 1 - g) >> 1) * stride, tn = first + ((sl + 1 - g) >> 1) * stride;
+            if (sl - 1 - g >= 0 && tp < ntiles) store(tp);
+            if (sl < 2 * rounds && tn < ntiles) stage(tn);
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T, int CK, int NF> static int launch_conv_pingpong16(const ConvParams &p, hipStream_t s)
+{
+    constexpr int LDS_BYTES = 9 * (CK / 32) * NF * 2 * 1024 + 2 * (((10 * 34 * 8) + 63) / 64) * 1024;
+    static std::once_flag once;
+    static hipError_t init_err = hipSuccess;
+    std::call_once(once, [] {
+        init_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_pingpong16_kernel<T, CK, NF>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    });
+    if (init_err != hipSuccess) return (int)init_err;
+    const int ncu = device_cu_count();
+    if (ncu <= 0) return (int)hipErrorInvalidDevice;
+    const int ntiles = ((p.Wout + 31) / 32) * ((p.Hout + 7) / 8) * p.B;
+    const int wgs = (ntiles + 1) / 2;
+    conv3x3_pingpong16_kernel<T, CK, NF><<<wgs < ncu ? wgs : ncu, 512, LDS_BYTES, s>>>(p);
+    return (int)hipGetLastError();
+}
+
 // weights packed for the 16x16x32 shape (ConvParams::mfma16): 64 -> 64 (four blocks), 64 -> 32 (two), 64 -> planes (one)
 template <typename T> static int launch_conv_mfma16(const ConvParams &p, hipStream_t s)
 {
     if (p.ck != 64 || p.stride != 1 || p.nchunk != 1 || p.npass != 1) return -2;
     const bool planar = p.epi == EPI_PLANAR || p.epi == EPI_PLANAR_TANH01;
     if (!planar && p.epi != EPI_NONE && p.epi != EPI_RELU) return -2;
+    // 64 -> 64: the ping-pong schedule is the default here (530 vs 612 us; the step keeps 1.7 % of it after the board's clock
+    // response); EMAVFI_CONV_PINGPONG=0 selects the lock-step kernel (read per call: parity test)
+    const char *pp_ = getenv("EMAVFI_CONV_PINGPONG");
+    if (p.nf == 2 && !planar && !(pp_ != nullptr && pp_[0] == '0')) return launch_conv_pingpong16<T, 64, 2>(p, s);
     if (p.nf == 2 && !planar) return launch_conv_persist16<T, 64, 2, 4>(p, s);
     if (p.nf == 1 && !planar) return launch_conv_persist16<T, 64, 1, 2>(p, s);
     if (p.nf == 1 && planar && p.nplanes <= 4) return launch_conv_persist16<T, 64, 1, 1>(p, s);
