@@ -44,6 +44,32 @@ __global__ __launch_bounds__(512) void loop(float *sink, int iters)
         float s = 0;
         for (int m = 0; m < 2; ++m) for (int n = 0; n < 2; ++n) s += acc[m][n][0];
         if (s == 123.456f) sink[0] = s;
+    } else if (SHAPE == 2) {
+        // 16x16x32 with the conv kernels' software pipeline: the next step's 8 fragments are read (ds_read_b128, inline asm so that
+        // they are real LDS reads inside the loop) BEFORE this step's 16 MFMAs; counted lgkmcnt wait in front of the MFMAs
+        f32x4 acc[4][4] = {};
+        bf16x8 a2[2][4], b2[2][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a2[0][k] = a[k]; b2[0][k] = b[k]; }
+        const unsigned la = (unsigned)(wave * 8192 + lane * 16);   // byte address inside the dynamic LDS (it starts at 0)
+        for (int it = 0; it < iters; it += 2) {
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(a2[ph ^ 1][k]) : "v"(la), "i"(k * 1024));
+                    asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(b2[ph ^ 1][k]) : "v"(la), "i"((4 + k) * 1024));
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[ph][m], b2[ph][n], acc[m][n], 0, 0, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads had 16 MFMAs (256 cycles) to land
+            }
+        }
+        float s = 0;
+        for (int m = 0; m < 4; ++m) for (int n = 0; n < 4; ++n) s += acc[m][n][0];
+        if (s == 123.456f) sink[0] = s;
     } else {
         f32x4 acc[4][4] = {};
         for (int it = 0; it < iters; ++it) {
@@ -102,5 +128,6 @@ int main()
     if (run<1, false>("16x16x32 bf16, operands in registers", sink)) return 1;
     if (run<0, true>("32x32x16 bf16, 1 KiB of LDS reads per MFMA", sink)) return 1;
     if (run<1, true>("16x16x32 bf16, 0.5 KiB of LDS reads per MFMA", sink)) return 1;
+    if (run<2, true>("16x16x32 bf16, LDS-fed, reads one step ahead", sink)) return 1;
     return 0;
 }

@@ -25,6 +25,36 @@
 #include <cstdlib>
 #include <mutex>
 
+// Diagnostic build only (-DEMAVFI_CONV_STAMPS=1): s_memtime sums per phase of conv3x3_pingpong16_kernel, accumulated over all waves
+// into g_conv_stamps {contract, store, stage issue, wait at barrier (vmcnt + s_barrier), slots, waves}; read with
+// emavfi_debug_conv_stamps() (conv3x3_bf16.hip).  s_memtime counts at 100 MHz on gfx950.
+#ifndef EMAVFI_CONV_STAMPS
+#define EMAVFI_CONV_STAMPS 0
+#endif
+#if EMAVFI_CONV_STAMPS
+__device__ unsigned long long g_conv_stamps[8];
+__device__ __forceinline__ unsigned long long conv_stamp()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#endif
+
+// Source address of one 16-byte DMA piece: piece pc of input pixel (gy, gx) of the sample starting at gin, or the zero page when
+// the pixel lies outside the image (or `valid` is false).  32-bit offset arithmetic (a sample is < 4 GiB: checked at the API) and
+// a select instead of a branch: the straightforward 64-bit form cost ~25 instructions, two of them 64-bit multiply-adds, and an
+// EXEC-masked branch PER DMA instruction - 590 cycles each beside the other group's MFMAs (tools/conv_stamps.py).
+__device__ __forceinline__ const char *conv_dma_src(const char *gin, const char *zeros, int gy, int gx, int pc, int Hin, int Win, unsigned pixbytes, bool valid)
+{
+    const bool ok = valid && (unsigned)gy < (unsigned)Hin && (unsigned)gx < (unsigned)Win;
+    const unsigned pix = __umul24((unsigned)gy & 0xffffffu, (unsigned)Win) + (unsigned)gx;
+    const unsigned off = pix * pixbytes + (unsigned)pc * 16u;
+    return ok ? gin + off : zeros;
+}
+
 #ifndef EMAVFI_CONV_PIPELINE
 #define EMAVFI_CONV_PIPELINE 1   // persistent kernel: operands one step ahead of their MFMAs (0 = the compiler's own order)
 #endif
@@ -475,6 +505,7 @@ __global__ __launch_bounds__(512) void conv3x3_persist16_kernel(const ConvParams
     const int j = lane & 15, kb = lane >> 4;
     const char *zeros = (const char *)p.zeros;
     const int npieces = p.in_pieces > 0 ? p.in_pieces : C::PIECES;
+    const unsigned pixbytes = (unsigned)p.in_ps * (unsigned)sizeof(T);
 
 #pragma unroll 1
     for (int i = wave; i < C::WINST; i += C::WAVES)
@@ -498,8 +529,7 @@ __global__ __launch_bounds__(512) void conv3x3_persist16_kernel(const ConvParams
                 const int pix = sl >> 3, pc = (sl & 7) ^ ((pix >> 1) & 7);   // slot -> the piece stored there
                 const int ly = pix / IW, lx = pix - ly * IW;
                 const int gy = iy0 + ly, gx = ix0 + lx;
-                const bool ok = sl < C::NSLOT && pc < npieces && gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
-                const char *src = ok ? gin + ((size_t)gy * p.Win + gx) * p.in_ps * sizeof(T) + pc * 16 : zeros;
+                const char *src = conv_dma_src(gin, zeros, gy, gx, pc, p.Hin, p.Win, pixbytes, sl < C::NSLOT && pc < npieces);
                 __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)(lds_in + jn * 1024), 16, 0, 0);
             }
         }
@@ -637,6 +667,7 @@ __global__ __launch_bounds__(512) void conv3x3_pingpong16_kernel(const ConvParam
     const int j = lane & 15, kb = lane >> 4;
     const char *zeros = (const char *)p.zeros;
     const int npieces = p.in_pieces > 0 ? p.in_pieces : 8;
+    const unsigned pixbytes = (unsigned)p.in_ps * (unsigned)sizeof(T);
 #pragma unroll 1
     for (int i = wave; i < WINST; i += 8)
         __builtin_amdgcn_global_load_lds((gptr_t *)((const char *)p.w + i * 1024 + lane * 16), (lptr_t *)(lds_w + i * 1024), 16, 0, 0);
@@ -659,8 +690,7 @@ __global__ __launch_bounds__(512) void conv3x3_pingpong16_kernel(const ConvParam
                 const int pix = sl >> 3, pc = (sl & 7) ^ ((pix >> 1) & 7);
                 const int ly = pix / IW, lx = pix - ly * IW;
                 const int gy = iy0 + ly, gx = ix0 + lx;
-                const bool ok = sl < NSLOT && pc < npieces && gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
-                const char *src = ok ? gin + ((size_t)gy * p.Win + gx) * p.in_ps * sizeof(T) + pc * 16 : zeros;
+                const char *src = conv_dma_src(gin, zeros, gy, gx, pc, p.Hin, p.Win, pixbytes, sl < NSLOT && pc < npieces);
                 __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)(lds_in + jn * 1024), 16, 0, 0);
             }
         }
@@ -738,18 +768,46 @@ __global__ __launch_bounds__(512) void conv3x3_pingpong16_kernel(const ConvParam
     };
     if (g == 0 && first < ntiles) stage(first);
     __syncthreads();
+#if EMAVFI_CONV_STAMPS
+    unsigned long long st_c = 0, st_s = 0, st_g = 0, st_w = 0;
+#endif
 #pragma unroll 1
     for (int sl = 0; sl <= 2 * rounds; ++sl) {
+#if EMAVFI_CONV_STAMPS
+        const unsigned long long t0 = conv_stamp();
+        unsigned long long t1 = t0, t2 = t0;
+#endif
         if (((sl + g) & 1) == 0) {
             const int t = first + ((sl - g) >> 1) * stride;
             if (sl < 2 * rounds && t < ntiles) contract(t);
+#if EMAVFI_CONV_STAMPS
+            t1 = t2 = conv_stamp();
+            st_c += t1 - t0;
+#endif
         } else {
             const int tp = first + ((sl - 1 - g) >> 1) * stride, tn = first + ((sl + 1 - g) >> 1) * stride;
             if (sl - 1 - g >= 0 && tp < ntiles) store(tp);
+#if EMAVFI_CONV_STAMPS
+            t1 = conv_stamp();
+            st_s += t1 - t0;
+#endif
             if (sl < 2 * rounds && tn < ntiles) stage(tn);
+#if EMAVFI_CONV_STAMPS
+            t2 = conv_stamp();
+            st_g += t2 - t1;
+#endif
         }
         __syncthreads();
+#if EMAVFI_CONV_STAMPS
+        st_w += conv_stamp() - t2;
+#endif
     }
+#if EMAVFI_CONV_STAMPS
+    if (lane == 0) {
+        atomicAdd(&g_conv_stamps[0], st_c); atomicAdd(&g_conv_stamps[1], st_s); atomicAdd(&g_conv_stamps[2], st_g);
+        atomicAdd(&g_conv_stamps[3], st_w); atomicAdd(&g_conv_stamps[4], (unsigned long long)(2 * rounds + 1)); atomicAdd(&g_conv_stamps[5], 1ull);
+    }
+#endif
 }
 
 template <typename T, int CK, int NF> static int launch_conv_pingpong16(const ConvParams &p, hipStream_t s)

@@ -6,3 +6,13 @@ int launch_conv3x3_bf16(const ConvParams &p, hipStream_t s)
     return launch_conv16<bf16_t>(p, s, off);
 }
 int launch_conv_tail_bf16(const TailParams &p, hipStream_t s) { return launch_conv_tail<bf16_t>(p, s); }
+#if EMAVFI_CONV_STAMPS
+extern "C" int emavfi_debug_conv_stamps(unsigned long long *out, int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_stamps), 8 * sizeof(unsigned long long)) != hipSuccess) return -2;
+    unsigned long long z[8] = {0};
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_conv_stamps), z, sizeof z) != hipSuccess) return -3;
+    return 0;
+}
+#endif
