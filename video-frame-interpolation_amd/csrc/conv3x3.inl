@@ -558,9 +558,11 @@ __global__ __launch_bounds__(512) void conv3x3_persist16_kernel(const ConvParams
                 const int tap = s / C::K32, k32 = s - tap * C::K32;
                 const int dy = tap / 3, dx = tap - 3 * dy;
 #pragma unroll
-                for (int pb = 0; pb < PB; ++pb) {
-                    const int q = ((wave * MF + (pb >> 1)) + dy) * IW + (pb & 1) * 16 + j + dx;
-                    xd[pb] = *reinterpret_cast<const vec *>(lds_in + q * PSTR + (((k32 * 4 + kb) ^ ((q >> 1) & 7)) << 4));
+                for (int m = 0; m < MF; ++m) {   // see conv3x3_pingpong16_kernel: +16 pixels keeps the slot permutation, k32 flips byte 64
+                    const int q = ((wave * MF + m) + dy) * IW + j + dx;
+                    const int off = (q * PSTR + ((kb ^ ((q >> 1) & 7)) << 4)) ^ (k32 * 64);
+                    xd[2 * m] = *reinterpret_cast<const vec *>(lds_in + off);
+                    xd[2 * m + 1] = *reinterpret_cast<const vec *>(lds_in + off + 2048);
                 }
                 const char *wb = lds_w + tap * C::WTAP + k32 * NBP * 1024 + lane * 16;
 #pragma unroll
@@ -718,10 +720,14 @@ __global__ __launch_bounds__(512) void conv3x3_pingpong16_kernel(const ConvParam
         auto load_step = [&](int s, vec (&xd)[PB], vec (&wd)[NB]) {
             const int tap = s / K32, k32 = s - tap * K32;
             const int dy = tap / 3, dx = tap - 3 * dy;
+            // one address per row m: the second column block is 16 pixels = 2048 bytes further with the SAME slot permutation
+            // ((q + 16) >> 1 == (q >> 1) + 8), and the second 32-channel step flips bit 2 of the piece index = byte 64
 #pragma unroll
-            for (int pb = 0; pb < PB; ++pb) {
-                const int q = ((wq * MF + (pb >> 1)) + dy) * IW + (pb & 1) * 16 + j + dx;
-                xd[pb] = *reinterpret_cast<const vec *>(lds_in + q * PSTR + (((k32 * 4 + kb) ^ ((q >> 1) & 7)) << 4));
+            for (int m = 0; m < MF; ++m) {
+                const int q = ((wq * MF + m) + dy) * IW + j + dx;
+                const int off = (q * PSTR + ((kb ^ ((q >> 1) & 7)) << 4)) ^ (k32 * 64);   // bit 6 lies inside the 128-byte pixel
+                xd[2 * m] = *reinterpret_cast<const vec *>(lds_in + off);
+                xd[2 * m + 1] = *reinterpret_cast<const vec *>(lds_in + off + 2048);
             }
             const char *wb = lds_w + tap * WTAP + k32 * NB * 1024 + lane * 16;
 #pragma unroll
