@@ -55,6 +55,9 @@ __device__ __forceinline__ const char *conv_dma_src(const char *gin, const char 
     return ok ? gin + off : zeros;
 }
 
+#ifndef EMAVFI_CONV_INTERLEAVE
+#define EMAVFI_CONV_INTERLEAVE 1
+#endif
 #ifndef EMAVFI_CONV_PIPELINE
 #define EMAVFI_CONV_PIPELINE 1   // persistent kernel: operands one step ahead of their MFMAs (0 = the compiler's own order)
 #endif
@@ -736,12 +739,21 @@ __global__ __launch_bounds__(512) void conv3x3_pingpong16_kernel(const ConvParam
         load_step(0, xq[0], wv[0]);
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
-            if (s + 1 < NSTEP) load_step(s + 1, xq[(s + 1) & 1], wv[(s + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < NSTEP) load_step(s + 1, xq[(s + 1) & 1], wv[(s + 1) & 1]);
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                 for (int pb = 0; pb < PB; ++pb) mma_k32(acc[pb][nb], wv[s & 1][nb], xq[s & 1][pb]);
+#if EMAVFI_CONV_INTERLEAVE
+            // one contracting wave per SIMD: a burst of 8 LDS reads in front of the 16 MFMAs leaves the matrix pipe idle while the
+            // wave issues them; spread the next step's reads between this step's MFMAs instead (1 read : 2 MFMAs)
+#pragma unroll
+            for (int u = 0; u < (PB + NB); ++u) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one DS read
+                __builtin_amdgcn_sched_group_barrier(0x008, (PB * NB) / (PB + NB), 0);   // MFMAs
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
     };
