@@ -26,15 +26,20 @@ __global__ __launch_bounds__(512) void loop(float *sink, int iters)
     for (int i = tid; i < 64 * 1024 / 4; i += 512) reinterpret_cast<float *>(smem)[i] = 0.001f * (float)(i & 255);
     __syncthreads();
     const char *base = smem + wave * 8192 + lane * 16;   // 8 fragments of 1 KiB per wave, lane-linear = conflict free
+    const unsigned la = (unsigned)(wave * 8192 + lane * 16);   // byte address inside the dynamic LDS (it starts at 0)
     bf16x8 a[4], b[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { a[k] = *reinterpret_cast<const bf16x8 *>(base + k * 1024); b[k] = *reinterpret_cast<const bf16x8 *>(base + (4 + k) * 1024); }
     if (SHAPE == 0) {
         f32x16 acc[2][2] = {};
         for (int it = 0; it < iters; ++it) {
-            if (READS) {
+            if (READS) {   // real LDS reads inside the loop (inline asm: a volatile C++ load becomes a FLAT load), waited for before the MFMAs
 #pragma unroll
-                for (int k = 0; k < 2; ++k) { a[k] = *reinterpret_cast<const volatile bf16x8 *>(base + k * 1024); b[k] = *reinterpret_cast<const volatile bf16x8 *>(base + (4 + k) * 1024); }
+                for (int k = 0; k < 2; ++k) {
+                    asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(a[k]) : "v"(la), "i"(k * 1024));
+                    asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(b[k]) : "v"(la), "i"((4 + k) * 1024));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
 #pragma unroll
             for (int m = 0; m < 2; ++m)
@@ -51,7 +56,6 @@ __global__ __launch_bounds__(512) void loop(float *sink, int iters)
         bf16x8 a2[2][4], b2[2][4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { a2[0][k] = a[k]; b2[0][k] = b[k]; }
-        const unsigned la = (unsigned)(wave * 8192 + lane * 16);   // byte address inside the dynamic LDS (it starts at 0)
         for (int it = 0; it < iters; it += 2) {
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph) {
@@ -75,7 +79,11 @@ __global__ __launch_bounds__(512) void loop(float *sink, int iters)
         for (int it = 0; it < iters; ++it) {
             if (READS) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { a[k] = *reinterpret_cast<const volatile bf16x8 *>(base + k * 1024); b[k] = *reinterpret_cast<const volatile bf16x8 *>(base + (4 + k) * 1024); }
+                for (int k = 0; k < 4; ++k) {
+                    asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(a[k]) : "v"(la), "i"(k * 1024));
+                    asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(b[k]) : "v"(la), "i"((4 + k) * 1024));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
 #pragma unroll
             for (int m = 0; m < 4; ++m)
@@ -126,8 +134,8 @@ int main()
     CHECK(hipMalloc(&sink, 64));
     if (run<0, false>("32x32x16 bf16, operands in registers", sink)) return 1;
     if (run<1, false>("16x16x32 bf16, operands in registers", sink)) return 1;
-    if (run<0, true>("32x32x16 bf16, 1 KiB of LDS reads per MFMA", sink)) return 1;
-    if (run<1, true>("16x16x32 bf16, 0.5 KiB of LDS reads per MFMA", sink)) return 1;
+    if (run<0, true>("32x32x16 bf16, LDS-fed (1 KiB / MFMA), reads waited for", sink)) return 1;
+    if (run<1, true>("16x16x32 bf16, LDS-fed (0.5 KiB / MFMA), reads waited for", sink)) return 1;
     if (run<2, true>("16x16x32 bf16, LDS-fed, reads one step ahead", sink)) return 1;
     return 0;
 }

@@ -56,7 +56,8 @@ __device__ __forceinline__ void mma_kg(f32x16 &acc, const f16x8 &w, const f16x8 
 }
 // the 16x16x32 shape: D[16 cout][16 pixel] += W[16][32] * X[32][16].  Lane (i = lane & 15, kb = lane >> 4) holds row / column i,
 // K elements kb*8 .. kb*8+7; the result lane (j = lane & 15, ib = lane >> 4) holds rows ib*4 .. ib*4+3 of column j.
-// tools/microbench/mfma_shape_power.hip: on this power-managed board it delivers 11 % more FLOP/s than 32x32x16, bare and LDS-fed.
+// tools/microbench/mfma_shape_power.hip: on this power-managed board it delivers 11-15 % more FLOP/s than 32x32x16 in a bare loop and
+// the same LDS-fed rate at 7 % less package power.
 __device__ __forceinline__ void mma_k32(f32x4 &acc, const bf16x8 &w, const bf16x8 &x)
 {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, acc, 0, 0, 0);

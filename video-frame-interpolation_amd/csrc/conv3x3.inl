@@ -470,8 +470,8 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_persist_kernel(const ConvP
 // ------------------------------------------------------------------------------------------
 // The persistent kernel on v_mfma_f32_16x16x32 (16-bit types, CK = 64, two 32-channel fragments = 64 -> 64: five launches and a
 // quarter of the step).  The board is power-managed and this MFMA shape does the same MACs with half
-// the fp32 accumulator traffic: tools/microbench/mfma_shape_power.hip measures 11 % more FLOP/s at lower package power,
-// bare and LDS-fed.  Per wave and tile still 2 rows x 32 pixels x 64 channels: 4 pixel blocks x 4 channel blocks of 16 x 16,
+// the fp32 accumulator traffic: tools/microbench/mfma_shape_power.hip measures 11-15 % more FLOP/s in a bare loop and the same
+// LDS-fed rate at 7 % less package power.  Per wave and tile still 2 rows x 32 pixels x 64 channels: 4 pixel blocks x 4 channel blocks of 16 x 16,
 // 16 MFMAs per 32-channel step against 4 weight + 4 pixel fragments (the same 1 KiB of LDS per 16 K MACs as before).
 // The tile is stored unpadded with the XOR slot swizzle of the ping-pong kernel (a 16-lane ds_read_b128 group here mixes two
 // adjacent pieces of 8 + 8 consecutive pixels, which no padded stride serves without conflicts; the swizzle does for the
