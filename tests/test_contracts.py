@@ -36,6 +36,11 @@ def test_size_limits_are_argument_errors_not_crashes():
     assert rc == -1 and "2^24" in lib.last_error()
     rc = L.emavfi_forward(3, 64, 3, None, None, None, None, None, 0, 1, 8192, 4096, lib.F32, None, None)
     assert rc == -1 and "4 GiB" in lib.last_error()
+    # stage-level conv entry: 32-bit DMA source offsets inside one sample (refused before anything is launched or dereferenced)
+    import ctypes
+    fake = ctypes.c_void_p(256)
+    rc = L.emavfi_conv3x3(fake, fake, fake, fake, 1, 64, 64, 32768, 32768, 1, 0, lib.BF16, fake, 0, None)
+    assert rc == -1 and "4 GiB" in lib.last_error()
     assert L.emavfi_forward_launches(3, 64, 3, 1, 64, 64, lib.BF16, None, 0, None, None, 0) == 20
     assert L.emavfi_forward_launches(3, 64, 3, 1, 64, 64, lib.F32, None, 0, None, None, 0) == 23
     assert L.emavfi_forward_launches(3, 7, 3, 1, 64, 64, lib.BF16, None, 0, None, None, 0) == -2

@@ -21,6 +21,14 @@
 //     D[cout][pixel] accumulates in MF*NF 32x32 fp32 tiles.
 // LDS pixel stride is an odd number of 16-byte slots (LdsPix), so the ds_read_b128 operand
 // fetches of 32 consecutive pixels are bank-conflict free for stride 1.
+//
+// Kernels in this file (which layer runs where: launch_conv16 / launch_conv_mfma16 at the end):
+//   conv3x3_kernel            the tile-per-workgroup kernel described above (every shape; the only one for fp32, stride 2, chunked K)
+//   conv3x3_persist_kernel    persistent, nine taps' weights resident, 16 x 32 tiles, 8 waves in lock step (32x32x16 MFMAs)
+//   conv3x3_persist16_kernel  the same on v_mfma_f32_16x16x32 with an unpadded XOR-swizzled tile: 64 -> 32 and 64 -> planes
+//   conv3x3_pingpong16_kernel two four-wave groups half a tile out of phase on that shape: the 64 -> 64 layers (product)
+//   conv3x3_pingpong_kernel   the ping-pong schedule on 32x32x16 MFMAs (opt-in, measurement)
+//   conv3x3_tail_kernel       reconstruction.1 + .2 through the LDS (opt-in: bit-identical, slower)
 #include "common.h"
 #include <cstdlib>
 #include <mutex>

@@ -770,6 +770,8 @@ int emavfi_conv3x3(const float *x, const float *weight, const float *bias, float
     Layer L;
     if (!single_conv_layer(L, Cin, Cout, stride, P.esize))
         return fail(EMAVFI_E_UNSUPPORTED, "conv3x3: no kernel instantiation for Cin=%d Cout=%d stride=%d", Cin, Cout, stride);
+    // the kernels' DMA source offsets inside one sample are 32-bit (conv3x3.inl, conv_dma_src)
+    if ((size_t)H * W * L.cin_pad * P.esize >= ((size_t)1 << 32)) return fail(EMAVFI_E_ARG, "conv3x3: one sample's input plane must be < 4 GiB");
     const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride, ops = rup(Cout, 16);
     Workspace ws{(char *)workspace, workspace_bytes, 0};
     void *xcl = ws.take((size_t)B * H * W * L.cin_pad * P.esize);
