@@ -29,13 +29,19 @@ with torch.no_grad():
     assert fn(None, ROWS, 1) == 0
     m(f1, f2)   # each pack overwrites the rows: what is read back is the LAST pack of this forward
 assert fn(buf.ctypes.data, ROWS, 0) == 0
-v = buf[buf[:, 6] == 1].astype(np.float64)
-names = ["prologue (window DMA + barrier)", "offset_conv (90 MFMAs/wave)", "pick + geometry (9 taps)",
+sel = buf[buf[:, 6] == 1]
+n_out = ((sel[:, 4] >> np.uint64(32)) & np.uint64(0xff)).astype(np.float64)      # (tap, row) steps with a lane outside the window, of 18
+n_lanes = (sel[:, 4] >> np.uint64(40)).astype(np.float64)                          # lanes outside, of 18 * 64
+sel[:, 4] &= np.uint64(0xffffffff)
+v = sel.astype(np.float64)
+names = ["prologue (window DMA + barrier)", "offset_conv", "pick + geometry (9 taps)",
          "gather + blend + MFMA steps (9 taps)", "epilogue stores (drained)", "total"]
 print(f"{dtype}: {len(v)} waves sampled (median cycles per wave and tile)")
 tot = np.median(v[:, 5])
 for i, n in enumerate(names):
     print(f"  {n:42s} {np.median(v[:, i]):10.0f}  {100.0 * np.median(v[:, i]) / tot:5.1f} %   (p10 {np.percentile(v[:, i], 10):.0f}, p90 {np.percentile(v[:, i], 90):.0f})")
+print(f"  fallback: {n_out.mean():.2f} of 18 (tap, row) groups per wave have a lane outside the window ({100 * n_out.mean() / 18:.1f} %), "
+      f"{n_lanes.mean():.2f} of 1152 lane samples ({100 * n_lanes.mean() / 1152:.2f} %)")
 d = buf[buf[:, 6] == 1][:, 7]
 parts = [((d >> np.uint64(16 * i)) & np.uint64(0xffff)).astype(np.float64) * 4 for i in range(4)]
 print("  prologue detail (median cycles): tile mapping + small loads + DMA issue %.0f, DMA landed after %.0f, convert %.0f, barrier wait %.0f"

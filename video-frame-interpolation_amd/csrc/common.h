@@ -195,7 +195,10 @@ struct DeformParams {
     int H, W, B;
     int cstore;
     int cin_real;  // real (unpadded) input channels
+    int cout_real; // real output channels (0 = unknown: nf * 32)
     int ck, nf;    // host-side template selectors
+    int pack3;     // weights are in the deform_pack3.inl layout (K = 64 per tap + im2col tail, third fragment as an LDS table)
+    int in_f16, out_f16;  // bf16 storage only: x (and x_tail) / out hold IEEE f16 bit patterns (tensors handed between consecutive packs)
     unsigned long long *stamps;  // diagnostic build (-DEMAVFI_DEFORM_STAMPS=1) only, else null
 };
 #define DEFORM_STAMP_STRIDE 14
@@ -212,5 +215,13 @@ int launch_conv_tail_f16(const TailParams &p, hipStream_t s);
 int launch_deform_f32(const DeformParams &p, hipStream_t s);
 int launch_deform_bf16(const DeformParams &p, hipStream_t s);
 int launch_deform_f16(const DeformParams &p, hipStream_t s);
-// 16-bit dtypes at the reference width: the whole ModulatedDeformConvPack is one launch (deform_lds.inl)
+// 16-bit dtypes at the reference width: the whole ModulatedDeformConvPack is one launch (deform_pack3.inl / deform_pack.inl)
+#ifndef EMAVFI_PACK3
+#define EMAVFI_PACK3 1   // 0: the round-2 kernel (deform_pack.inl) and its weight layout (A/B builds)
+#endif
+// shape served by deform_pack3_kernel: 65..67 input channels (4 k-groups + a 3-channel tail), 65..67 output channels
+static inline bool deform_pack3_shape(int ck, int nf, int cin_real, int cout_real)
+{
+    return EMAVFI_PACK3 && ck == 80 && nf == 3 && cin_real > 64 && cin_real <= 67 && cout_real > 64 && cout_real <= 67;
+}
 bool deform16_can_fuse_offset_conv(int ck, int nf, int cin_real, int off_ck, int off_nf);

@@ -35,6 +35,9 @@
 #ifndef EMAVFI_DEFORM_ABL_NO_WLOADS
 #define EMAVFI_DEFORM_ABL_NO_WLOADS 0  // timing-only ablation (wrong results): no weight-fragment loads after the first
 #endif
+#ifndef EMAVFI_DEFORM_ABL_NO_FALLBACK
+#define EMAVFI_DEFORM_ABL_NO_FALLBACK 0  // timing-only ablation (wrong results): samples leaving the window read clamped window pixels
+#endif
 
 // Diagnostic build only (-DEMAVFI_DEFORM_STAMPS=1; cdna_hip_programming.md section 7, in-kernel stamps): s_memtime at
 // the seams of the kernel, per-wave segment sums written to DeformParams::stamps (a buffer the diagnostic build of
@@ -52,6 +55,8 @@ __device__ __forceinline__ unsigned long long deform_stamp()
     return t;
 }
 #define DEFORM_STAMP(var) const unsigned long long var = deform_stamp()
+#elif defined(EMAVFI_DEFORM_FENCES)
+#define DEFORM_STAMP(var) __builtin_amdgcn_sched_barrier(0)   // experiment: the stamped build's scheduling fences without its stamps
 #else
 #define DEFORM_STAMP(var)
 #endif
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(16 * TCOLS, 2) void deform_pack_kernel(const Deform
     const int H = p.H, W = p.W;
     DEFORM_STAMP(ts_begin);
 #if EMAVFI_DEFORM_STAMPS
-    unsigned long long sum_geom = 0, sum_steps = 0;
+    unsigned long long sum_geom = 0, sum_steps = 0, cnt_out = 0, cnt_lanes = 0;
 #endif
 
     // ---- tile of this workgroup.  XCD-aware order (placement only affects speed): workgroups are dealt round-robin
@@ -423,8 +428,12 @@ __global__ __launch_bounds__(16 * TCOLS, 2) void deform_pack_kernel(const Deform
         bool lane_out[2], any_out[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            lane_out[m] = (base[m] & 1u) != 0;
+            lane_out[m] = !EMAVFI_DEFORM_ABL_NO_FALLBACK && (base[m] & 1u) != 0;
             any_out[m] = __any(lane_out[m]);
+#if EMAVFI_DEFORM_STAMPS
+            cnt_out += any_out[m] ? 1 : 0;
+            cnt_lanes += __popcll(__ballot(lane_out[m]));
+#endif
             base[m] &= ~1u;
         }
         DEFORM_STAMP(ts_geom);
@@ -510,7 +519,7 @@ __global__ __launch_bounds__(16 * TCOLS, 2) void deform_pack_kernel(const Deform
         if (row < DEFORM_STAMP_ROWS) {
             unsigned long long *o = p.stamps + (size_t)row * 8;
             o[0] = ts_window - ts_begin; o[1] = ts_offconv - ts_window; o[2] = sum_geom; o[3] = sum_steps;
-            o[4] = ts_done - ts_loop; o[5] = ts_done - ts_begin; o[6] = 1;
+            o[4] = (ts_done - ts_loop) | (cnt_out << 32) | (cnt_lanes << 40); o[5] = ts_done - ts_begin; o[6] = 1;
             // prologue detail packed into o[7]: 16 bits each (units of 4 cycles): issue, landed - issued, convert, barrier wait
             auto q16 = [](unsigned long long v) { v >>= 2; return v > 0xffffull ? 0xffffull : v; };
             o[7] = q16(ts_issued - ts_begin) | (q16(ts_landed - ts_issued) << 16) | (q16(ts_converted - ts_landed) << 32) | (q16(ts_window - ts_converted) << 48);
@@ -543,8 +552,14 @@ template <typename TS, int TCOLS, int R, bool FUSE_OFF, int TQ> static int launc
 // the reference width (mid_channels 64 -> 67 channels, k-groups to 80): LDS-staged window of 72 channels
 static inline bool deform16_lds_shape(int ck, int nf, int cin_real) { return ck == 80 && nf == 3 && cin_real <= 72; }
 
+template <typename TS, bool FUSE_OFF> static int launch_deform_pack3(const DeformParams &p, hipStream_t s);
+
 template <typename TS> static int launch_deform16(const DeformParams &p, hipStream_t s)
 {
+    if (p.pack3) {  // weights in the deform_pack3.inl layout (host: deform_pack3_shape)
+        if (!deform_pack3_shape(p.ck, p.nf, p.cin_real, p.cout_real)) return -2;
+        return p.off_w ? launch_deform_pack3<TS, true>(p, s) : launch_deform_pack3<TS, false>(p, s);
+    }
     if (deform16_lds_shape(p.ck, p.nf, p.cin_real)) {
         constexpr int TC = EMAVFI_DEFORM_TCOLS;
         if (p.cin_real <= 68) {  // the reference width: 3 real channels in the last k-group

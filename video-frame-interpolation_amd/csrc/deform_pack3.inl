@@ -1,0 +1,609 @@
+// ModulatedDeformConvPack (ema_vfi.py:23-60) at the reference width (67 -> 27 offsets/masks, 67 -> 67) as ONE launch,
+// 16-bit storage types - round 3 rebuild of deform_pack.inl around what its counters and ISA showed:
+// the kernel is bound by instruction issue at two waves per SIMD, so this version removes issued work.
+//
+//   * K = 64 + 3.  The three warped-frame channels (64..66) used to cost a fifth k-group in every tap (3 real of 16
+//     input channels: 6 of 30 MFMAs, 6 of 15 weight-fragment loads, 8 corner reads and 16 blend instructions per tap).
+//     Now every tap contracts exactly the 64 feature channels (4 k-groups), and the three tail channels of ALL NINE taps
+//     are one im2col step at the end: each half-lane blends the tail of ITS OWN pixel per tap (4 eight-byte corner
+//     reads, 8 packed FMAs), keeps the 9 x 3 values in registers, and three k-groups (K index = tap slot * 4 + channel,
+//     27 real of 48) contract them after the tap loop.  The offset_conv does the same with the undeformed window.
+//     Issued MFMAs per wave: 90 + 270 -> 78 + 234; blend instructions per tap 144 -> 136; LDS reads 40 -> 36.
+//   * The third output fragment (channels 64..66: 3 real rows of 32) takes its A operand from a 4.5 KiB table in LDS
+//     ([tap][k-group][row 0..2 | zero row][half][16 B], every lane of a zero row reads the same 16 bytes: a broadcast)
+//     instead of a 1 KiB global fragment per k-group: weight-fragment traffic L2/L1 -> registers 15 -> 8 KiB per wave and tap
+//     (64 B/clk per CU was a co-limit: 8 waves x 15 KiB per tap).
+//   * Window DMA by rows: wave w owns pixels [7w, 7w+7) of every window row (wave 3: the last two), so a lane's
+//     (pixel, piece) and its source pointer / row increment are computed ONCE and a DMA instruction costs one 64-bit add
+//     and one select (was ~25 address instructions per DMA instruction, 6 200 cycles of issue per tile).
+//   * The blend is issued corner-major (four independent chains), which hipcc's scheduler had turned back into four dependent
+//     chains with a wait state behind every v_pk_fma_f16 (63 s_nop per tap); the sample-outside-the-window fallback is a
+//     separate copy of the tap body, so the common path carries none of its address arithmetic or EXEC regions.
+//   * bf16 storage may hand f16 bit patterns between consecutive packs (DeformParams::in_f16 / out_f16): the window is f16 on
+//     chip anyway (deform_pack.inl), so pack i+1 skips the in-LDS conversion pass and the intermediate fusion tensor keeps 11
+//     significant bits instead of 8.
+//
+// Geometry, lane <-> pixel assignment, the f16 on-chip arithmetic and the fallback semantics are those of deform_pack.inl.
+#pragma once
+#include "deform_pack.inl"
+
+struct Pack3 {
+    static constexpr int R = 2, TROWS = 16, TCOLS = 16, WAVES = 4, THREADS = 256;
+    static constexpr int TR = TROWS + 3 + 2 * R, TC = TCOLS + 3 + 2 * R;                 // 23 x 23 window pixels
+    static constexpr int SP = 9, PSB = SP * 16, ROWB = TC * PSB, WIN_BYTES = TR * ROWB;  // 144 B pixels, 3312 B rows, 76 176 B
+    static constexpr int SEG_PX = 7, SEG_BYTES = SEG_PX * PSB;                            // one DMA instruction = 7 pixels x 9 pieces
+    static constexpr int LAST_PX = TC - 3 * SEG_PX;                                       // wave 3: the last 2 pixels of a row
+    static constexpr int W3_OFF = WIN_BYTES, W3_TAP = 4 * 4 * 2 * 16, W3_BYTES = 9 * W3_TAP;  // third-fragment A operands
+    static constexpr int LDS_BYTES = W3_OFF + W3_BYTES;                                   // 80 784 B: two workgroups per CU
+    // packed weights (bytes): DCN = [tap][kg 4][nf 2][lane][16] | W3 table | tail [j 3][nf 3][lane][16]
+    static constexpr int DCN_TAP = 4 * 2 * 1024, DCN_W3 = 9 * DCN_TAP, DCN_TAIL = DCN_W3 + W3_BYTES, DCN_BYTES = DCN_TAIL + 9 * 1024;
+    // offset_conv = [tap][kg 4][lane][16] | tail [j 3][lane][16]
+    static constexpr int OFF_TAP = 4 * 1024, OFF_TAIL = 9 * OFF_TAP, OFF_BYTES = OFF_TAIL + 3 * 1024;
+    static_assert(SEG_PX * SP <= 64 && LAST_PX > 0 && LAST_PX <= SEG_PX, "row segments");
+    static_assert(WIN_BYTES % 16 == 0 && 2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+    static_assert(ROWB + PSB + 8 * 16 + 15 < 65536, "corner offsets must fit the ds_read immediate");
+};
+
+// window byte offset of plain tap t relative to tap 0 (taps past 8 re-read tap 8: finite data against zero weights)
+__host__ __device__ constexpr int pack3_tap_off(int t) { return t < 9 ? ((t / 3) * Pack3::TC + (t % 3)) * Pack3::PSB : (2 * Pack3::TC + 2) * Pack3::PSB; }
+
+// storage -> on-chip f16: bf16 storage converts unless the producer already wrote f16 bit patterns (DeformParams::in_f16)
+template <typename TS> __device__ __forceinline__ u32x4_t to_f16_piece_rt(u32x4_t v, int in_f16)
+{
+    if constexpr (std::is_same<TS, bf16_t>::value) return in_f16 ? v : to_f16_piece<TS>(v);
+    return v;
+}
+
+// corner-major blend with the four passes pinned in order for VALU (other instruction classes may move across)
+template <int NQ> __device__ __forceinline__ void blend_corners_cm(const unsigned (&d)[4][4], unsigned w01, unsigned w23, unsigned (&out)[4])
+{
+    f16x2_t a[4];
+    constexpr int KEEP = 0x0008 | 0x0010 | 0x0080 | 0x0004;  // MFMA, VMEM, DS, SALU may cross; VALU may not
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) a[q] = __builtin_bit_cast(f16x2_t, d[0][q]) * bcast_half<0>(w01);
+    __builtin_amdgcn_sched_barrier(KEEP);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) a[q] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d[1][q]), bcast_half<1>(w01), a[q]);
+    __builtin_amdgcn_sched_barrier(KEEP);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) a[q] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d[2][q]), bcast_half<0>(w23), a[q]);
+    __builtin_amdgcn_sched_barrier(KEEP);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) a[q] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d[3][q]), bcast_half<1>(w23), a[q]);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) out[q] = __builtin_bit_cast(unsigned, a[q]);
+}
+
+template <typename TS, bool FUSE_OFF>
+__global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams p)
+{
+    using C = Pack3;
+    constexpr int R = C::R;
+    static_assert(sizeof(TS) == 2, "16-bit storage types only");
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    lds_cchar_t *lds_r = (lds_cchar_t *)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int H = p.H, W = p.W;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    DEFORM_STAMP(ts_begin);
+#if EMAVFI_DEFORM_STAMPS
+    unsigned long long sum_geom = 0, sum_steps = 0, cnt_out = 0;
+#endif
+
+    // ---- tile of this workgroup (XCD-aware order: deform_pack.inl)
+    const int ntx = (W + C::TCOLS - 1) / C::TCOLS, nty = (H + C::TROWS - 1) / C::TROWS, nt = ntx * nty;
+    int tile_x, tile_y, b;
+    {
+        constexpr int SROWS = 4;
+        const int nwg = gridDim.x, grp = blockIdx.x & 7, kk = blockIdx.x >> 3, qq = nwg >> 3, rr = nwg & 7;
+        const int wg = (grp < rr ? grp * (qq + 1) : rr * (qq + 1) + (grp - rr) * qq) + kk;
+        b = wg / nt;
+        const int t = wg - b * nt, strip = t / (SROWS * ntx), tt = t - strip * SROWS * ntx;
+        const int rows = min(SROWS, nty - strip * SROWS);
+        tile_x = tt / rows;
+        tile_y = strip * SROWS + (tt - tile_x * rows);
+    }
+    const unsigned ps_bytes = (unsigned)p.x_ps * 2u, tail_bytes = (unsigned)p.tail_ps * 2u;
+    const int ty0 = tile_y * C::TROWS - 1 - R, tx0 = tile_x * C::TCOLS - 1 - R;
+    const char *gplane = (const char *)p.x + (size_t)b * H * W * ps_bytes;
+    const char *tplane = p.x_tail ? (const char *)p.x_tail + (size_t)b * H * W * tail_bytes : nullptr;
+    const char *zeros = (const char *)p.zeros;
+    const char *wbase_g = (const char *)p.w;       // wave-uniform bases: fragment loads are base + lane16 + immediate
+    const char *owbase_g = (const char *)p.off_w;
+
+    // ---- small loads first (L2-resident): the first two taps' offset_conv fragments
+    f16x8 ow[FUSE_OFF ? 3 : 1][4];
+    if constexpr (FUSE_OFF) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) ow[t][kg] = *reinterpret_cast<const f16x8 *>(owbase_g + (t * 4 + kg) * 1024 + lane16);
+    }
+
+    // ---- DMA the window, row by row: wave w fetches pixels [7w, 7w + 7) (wave 3: 2 pixels) x 9 pieces of every row.
+    // A lane's pixel column and piece never change; out-of-image pixels read the zero page.
+    const bool dact = wave < 3 ? lane < C::SEG_PX * C::SP : lane < C::LAST_PX * C::SP;
+    {
+        const int dp = lane / C::SP, dpc = lane - dp * C::SP;
+        const int dgx = tx0 + wave * C::SEG_PX + dp;
+        const bool dcol = (unsigned)dgx < (unsigned)W;
+        const long long pix0 = (long long)ty0 * W + dgx;
+        const bool from_tail = tplane != nullptr && dpc == C::SP - 1;   // channels 64..71 from the compact tail buffer
+        const char *src = from_tail ? tplane + pix0 * (long long)tail_bytes : gplane + pix0 * (long long)ps_bytes + dpc * 16;
+        const unsigned inc = (unsigned)W * (from_tail ? tail_bytes : ps_bytes);
+        if (dact) {
+#pragma unroll
+            for (int ly = 0; ly < C::TR; ++ly) {
+                const bool ok = dcol && (unsigned)(ty0 + ly) < (unsigned)H;
+                const char *s = ok ? src : zeros;
+                __builtin_amdgcn_global_load_lds((gptr_t *)s, (lptr_t *)(smem + ly * C::ROWB + wave * C::SEG_BYTES), 16, 0, 0);
+                src += inc;
+            }
+        }
+        // the third fragment's A operands (4 608 B): one DMA instruction per wave + half an instruction
+        const char *w3g = wbase_g + C::DCN_W3;
+        __builtin_amdgcn_global_load_lds((gptr_t *)(w3g + wave * 1024 + lane16), (lptr_t *)(smem + C::W3_OFF + wave * 1024), 16, 0, 0);
+        if (wave == 0 && lane < 32)
+            __builtin_amdgcn_global_load_lds((gptr_t *)(w3g + 4096 + lane16), (lptr_t *)(smem + C::W3_OFF + 4096), 16, 0, 0);
+    }
+    DEFORM_STAMP(ts_issued);
+#if EMAVFI_DEFORM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    DEFORM_STAMP(ts_landed);
+    if constexpr (std::is_same<TS, bf16_t>::value) {
+        // bf16 -> f16 in place: every wave converts exactly the pieces its own DMA instructions fetched, so its own
+        // vmcnt(0) is the only wait needed before it reads them back.  Skipped when the producer already wrote f16.
+        if (!p.in_f16) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (dact) {
+#pragma unroll
+                for (int ly = 0; ly < C::TR; ++ly) {
+                    lds_char_t *q = (lds_char_t *)smem + ly * C::ROWB + wave * C::SEG_BYTES + lane16;
+                    const u32x4_t v = to_f16_piece<TS>(lds_read16(q));
+                    *reinterpret_cast<__attribute__((address_space(3))) u32x4_t *>(q) = v;
+                }
+            }
+        }
+    }
+
+    // ---- this lane's pixel in each of its wave's two fragments (2 rows x 16 columns; hardware ds_read_b128 lane groups
+    // get one row of 16 consecutive pixels each: deform_pack.inl)
+    const bool g2 = (r >= 4 && r < 12) || (r >= 16 && r < 20) || r >= 28;
+    const int fr_row = g2 ? 1 : 0;
+    const int fr_col = g2 ? (r < 12 ? r - 4 : (r < 20 ? r - 8 : r - 16)) : (r < 4 ? r : (r < 16 ? r - 8 : r - 12));
+    const int px_x = tile_x * C::TCOLS + fr_col;
+    int py_y[2], wrow[2];
+    bool in_img[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        wrow[m] = (wave * 2 + m) * 2 + fr_row;
+        py_y[m] = tile_y * C::TROWS + wrow[m];
+        in_img[m] = py_y[m] < H && px_x < W;
+    }
+    const int my_y = h ? py_y[1] : py_y[0];
+    const bool my_in = h ? in_img[1] : in_img[0];
+    const float *om_my = p.om + (((size_t)b * H + (my_in ? my_y : 0)) * W + (my_in ? px_x : 0)) * 32;
+    const float fy_base = (float)(my_y - 1), fx_base = (float)(px_x - 1);
+    const float fy_max = (float)(H + 1), fx_max = (float)(W + 1);
+    // LDS byte offset of this lane's piece (h) of the plain tap-0 pixel of fragment row m
+    unsigned xbase[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) xbase[m] = (unsigned)(((wrow[m] + R) * C::TC + fr_col + R) * C::PSB + h * 16);
+    const unsigned w3lane = (unsigned)(C::W3_OFF + (min(r, 3) * 2 + h) * 16);
+    DEFORM_STAMP(ts_converted);
+    __syncthreads();  // hipcc drains the DMA (vmcnt(0)) ahead of the barrier
+    DEFORM_STAMP(ts_window);
+
+    f32x16 omr[FUSE_OFF ? 2 : 1];
+    if constexpr (FUSE_OFF) {
+        // ---- the pack's offset_conv (ema_vfi.py:41,56: 3x3, pad 1, 67 -> 27) on the staged window: 4 k-groups per tap
+        // on the window pieces as they lie, then the three tail channels of all nine taps as three im2col k-groups
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) omr[m][i] = p.off_bias[acc_channel(i, h)];
+        u32x4_t xq[2][2][4];
+        auto load_x = [&](auto tc, u32x4_t (&dst)[2][4]) {
+            constexpr int toff = pack3_tap_off(decltype(tc)::value);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int kg = 0; kg < 4; ++kg) dst[m][kg] = lds_read16(lds_r + xbase[m] + (unsigned)(toff + kg * 32));
+        };
+        load_x(std::integral_constant<int, 0>{}, xq[0]);
+        auto off_tap = [&](auto tc) {
+            constexpr int tap = decltype(tc)::value;
+            if constexpr (tap < 7) {  // weight fragments two taps ahead
+#pragma unroll
+                for (int kg = 0; kg < 4; ++kg) ow[(tap + 2) % 3][kg] = *reinterpret_cast<const f16x8 *>(owbase_g + ((tap + 2) * 4 + kg) * 1024 + lane16);
+            }
+            if constexpr (tap < 8) load_x(std::integral_constant<int, tap + 1>{}, xq[(tap + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int kg = 0; kg < 4; ++kg) mma_kg(omr[m], ow[tap % 3][kg], __builtin_bit_cast(f16x8, xq[tap & 1][m][kg]));
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        off_tap(std::integral_constant<int, 0>{}); off_tap(std::integral_constant<int, 1>{}); off_tap(std::integral_constant<int, 2>{});
+        off_tap(std::integral_constant<int, 3>{}); off_tap(std::integral_constant<int, 4>{}); off_tap(std::integral_constant<int, 5>{});
+        off_tap(std::integral_constant<int, 6>{}); off_tap(std::integral_constant<int, 7>{}); off_tap(std::integral_constant<int, 8>{});
+        // tail: k-group j, lane (r, h) holds K = 16j + 8h + e = tap slot 4j + 2h + (e >> 2), channel 64 + (e & 3)
+        {
+            f16x8 ot[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) ot[j] = *reinterpret_cast<const f16x8 *>(owbase_g + C::OFF_TAIL + j * 1024 + lane16);
+            u32x2_t ta[2][3][2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const unsigned tb = xbase[m] - (unsigned)(h * 16) + 128u;   // tail piece of the plain tap-0 pixel
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const unsigned o = h ? (unsigned)pack3_tap_off(4 * j + 2 + u) : (unsigned)pack3_tap_off(4 * j + u);
+                        ta[m][j][u] = lds_read8(lds_r + tb + o);
+                    }
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const u32x4_t bq = {ta[m][j][0][0], ta[m][j][0][1], ta[m][j][1][0], ta[m][j][1][1]};
+                    mma_kg(omr[m], ot[j], __builtin_bit_cast(f16x8, bq));
+                }
+        }
+        // mask = sigmoid(third chunk), ema_vfi.py:59 (channels 18..26 after the pack-time routing)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int c = acc_channel(i, h);
+                const float v = omr[m][i];
+                omr[m][i] = (c >= 18 && c < 27) ? 1.0f / (1.0f + expf(-v)) : v;
+            }
+    }
+
+    // ---- DCN: 9 taps x 4 k-groups x 2 rows, two fragments from global fragments + the third from the LDS table
+    f16x8 wq[2][2];  // [kg & 1][n]
+#pragma unroll
+    for (int n = 0; n < 2; ++n) wq[0][n] = *reinterpret_cast<const f16x8 *>(wbase_g + n * 1024 + lane16);
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][n][i] = p.bias[n * 32 + acc_channel(i, h)];
+    unsigned tl[12][2];  // blended tail (channels 64..66 of this half-lane's own pixel) per tap slot; slots 9..11 stay zero
+#pragma unroll
+    for (int t = 0; t < 12; ++t) tl[t][0] = tl[t][1] = 0u;
+    DEFORM_STAMP(ts_offconv);
+
+    // (dy, dx, mask) of this half-lane's row for tap `tap` (wave-uniform): fused, channel c of (row 0 | row 1) of this lane's
+    // pixels is delivered to (half 0 | half 1) by one swap - swap(a, b) -> {(a.lo, b.lo), (a.hi, b.hi)}, the channel lives in
+    // half-lane (c >> 2) & 1, register (c & 3) + 4 * (c >> 3) of the offset_conv's accumulators; else read from p.om
+    auto tap_om = [&](int tap) {
+        OmTap o;
+        if constexpr (FUSE_OFF) {
+            auto pick = [&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                constexpr int reg = (c & 3) + 4 * (c >> 3);
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(omr[0][reg]), __float_as_uint(omr[1][reg]), false, false);
+                return __uint_as_float(((c >> 2) & 1) ? sw[1] : sw[0]);
+            };
+            auto take = [&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                o.dy = pick(std::integral_constant<int, 2 * k>{});
+                o.dx = pick(std::integral_constant<int, 2 * k + 1>{});
+                o.mk = pick(std::integral_constant<int, 18 + k>{});
+            };
+            switch (tap) {  // registers cannot be indexed by a loop variable
+            case 0: take(std::integral_constant<int, 0>{}); break;
+            case 1: take(std::integral_constant<int, 1>{}); break;
+            case 2: take(std::integral_constant<int, 2>{}); break;
+            case 3: take(std::integral_constant<int, 3>{}); break;
+            case 4: take(std::integral_constant<int, 4>{}); break;
+            case 5: take(std::integral_constant<int, 5>{}); break;
+            case 6: take(std::integral_constant<int, 6>{}); break;
+            case 7: take(std::integral_constant<int, 7>{}); break;
+            default: take(std::integral_constant<int, 8>{}); break;
+            }
+            if (!my_in) o.mk = 0.0f;   // pixels of the tile overhang contribute nothing (and are never stored)
+        } else {
+            o = load_om(om_my, tap, my_in);
+        }
+        return o;
+    };
+    unsigned fb_taps = 0;  // wave-uniform: taps in which some lane's sample left the window
+    OmTap nxt;
+    if (!FUSE_OFF) nxt = load_om(om_my, 0, my_in);   // offsets / masks from memory: one tap ahead
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+        DEFORM_STAMP(ts_tap);
+        const char *wtap = wbase_g + (size_t)tap * C::DCN_TAP;   // wave-uniform
+        OmTap o;
+        if constexpr (FUSE_OFF) o = tap_om(tap);
+        else {
+            o = nxt;
+            if (tap < 8) nxt = load_om(om_my, tap + 1, my_in);
+        }
+        // ---- sampling geometry (fp32, compare-free clamps: NaN -> -2; positions <= -1 or >= size sample zeros)
+        const int ti = tap / 3, tj = tap - 3 * ti;
+        const float py = fminf(fmaxf((fy_base + (float)ti) + o.dy, -2.0f), fy_max);
+        const float px = fminf(fmaxf((fx_base + (float)tj) + o.dx, -2.0f), fx_max);
+        const float fy = floorf(py), fx = floorf(px);
+        const int hl = (int)fy, wl = (int)fx;
+        const float lh = py - fy, lw = px - fx, uh = 1.0f - lh, uw = 1.0f - lw;
+        float w4[4] = {o.mk * (uh * uw), o.mk * (uh * lw), o.mk * (lh * uw), o.mk * (lh * lw)};
+        const int ly0 = hl - ty0, lx0 = wl - tx0;
+        const bool inside = (unsigned)ly0 <= (unsigned)(C::TR - 2) && (unsigned)lx0 <= (unsigned)(C::TC - 2);
+        const unsigned mybase = __umul24((unsigned)min(max(ly0, 0), C::TR - 2), (unsigned)C::ROWB) +
+                                __umul24((unsigned)min(max(lx0, 0), C::TC - 2), (unsigned)C::PSB);
+        // pixels of the tile overhang (mask forced to 0) read their clamped window position: 0 x finite data
+        const bool need_fb = !inside && my_in;
+        const bool any_out = !EMAVFI_DEFORM_ABL_NO_FALLBACK && __any(need_fb);   // wave-uniform: both rows
+        // A sample that leaves the window (|offset| > R near the tile edge: rare) contributes NOTHING here - its weights
+        // are zeroed, its reads go to the clamped window position - and the tap is marked: the fix-up loop behind this
+        // one adds the marked taps' missing samples from global memory.  The common path carries no fallback code.
+        if (any_out) fb_taps |= 1u << tap;
+        if (need_fb) { w4[0] = 0.0f; w4[1] = 0.0f; w4[2] = 0.0f; w4[3] = 0.0f; }
+        const unsigned w01h = __builtin_bit_cast(unsigned, f16x2_t{(half_t)w4[0], (half_t)w4[1]});
+        const unsigned w23h = __builtin_bit_cast(unsigned, f16x2_t{(half_t)w4[2], (half_t)w4[3]});
+        unsigned base[2], w01[2], w23[2];
+        {
+            auto both = [&](unsigned x, unsigned (&out)[2]) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+                out[0] = sw[0]; out[1] = sw[1];
+            };
+            both(w01h, w01); both(w23h, w23);
+            // swap(a, b) = {(a.lo, b.lo), (a.hi, b.hi)}: the h = 1 receivers take b = base + 16 (their piece of the pixel)
+            const auto sw = __builtin_amdgcn_permlane32_swap(mybase, mybase + 16u, false, false);
+            base[0] = sw[0]; base[1] = sw[1];
+        }
+        DEFORM_STAMP(ts_geom);
+        const unsigned w3a = w3lane + (unsigned)(tap * C::W3_TAP);
+        constexpr int OFF[4] = {0, C::PSB, C::ROWB, C::ROWB + C::PSB};
+        auto gather = [&](int s, unsigned (&d)[4][4]) {
+            const int kg = s >> 1, m = s & 1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const u32x4_t v = lds_read16(lds_r + base[m] + (unsigned)(kg * 32 + OFF[c]));
+                d[c][0] = v[0]; d[c][1] = v[1]; d[c][2] = v[2]; d[c][3] = v[3];
+            }
+        };
+        unsigned vb[2][4][4];
+        gather(0, vb[0]);
+        // tail of this half-lane's own pixel: four 8-byte corner reads
+        unsigned vt[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const u32x2_t t2 = lds_read8(lds_r + mybase + (unsigned)(128 + OFF[c]));
+            vt[c][0] = t2[0]; vt[c][1] = t2[1]; vt[c][2] = 0u; vt[c][3] = 0u;
+        }
+        unsigned tval[2];
+        f16x8 w3f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int kg = s >> 1, m = s & 1;
+            if (s + 1 < 8) gather(s + 1, vb[(s + 1) & 1]);
+            if (m == 0) {
+                w3f = __builtin_bit_cast(f16x8, lds_read16(lds_r + w3a + (unsigned)(kg * 128)));
+                if (kg + 1 < 4) {
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) wq[(kg + 1) & 1][n] = *reinterpret_cast<const f16x8 *>(wtap + ((kg + 1) * 2 + n) * 1024 + lane16);
+                } else if (tap < 8) {
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) wq[0][n] = *reinterpret_cast<const f16x8 *>(wtap + C::DCN_TAP + n * 1024 + lane16);
+                }
+            }
+            unsigned xd[4];
+            blend_corners_cm<4>(vb[s & 1], w01[m], w23[m], xd);
+            const f16x8 xf = __builtin_bit_cast(f16x8, u32x4_t{xd[0], xd[1], xd[2], xd[3]});
+            mma_kg(acc[m][0], wq[kg & 1][0], xf);
+            mma_kg(acc[m][1], wq[kg & 1][1], xf);
+            mma_kg(acc[m][2], w3f, xf);
+            if (s == 3) {
+                unsigned td[4];
+                blend_corners_cm<2>(vt, w01h, w23h, td);
+                tval[0] = td[0]; tval[1] = td[1];
+            }
+        }
+        switch (tap) {  // wave-uniform register select
+        case 0: tl[0][0] = tval[0]; tl[0][1] = tval[1]; break;
+        case 1: tl[1][0] = tval[0]; tl[1][1] = tval[1]; break;
+        case 2: tl[2][0] = tval[0]; tl[2][1] = tval[1]; break;
+        case 3: tl[3][0] = tval[0]; tl[3][1] = tval[1]; break;
+        case 4: tl[4][0] = tval[0]; tl[4][1] = tval[1]; break;
+        case 5: tl[5][0] = tval[0]; tl[5][1] = tval[1]; break;
+        case 6: tl[6][0] = tval[0]; tl[6][1] = tval[1]; break;
+        case 7: tl[7][0] = tval[0]; tl[7][1] = tval[1]; break;
+        default: tl[8][0] = tval[0]; tl[8][1] = tval[1]; break;
+        }
+#if EMAVFI_DEFORM_STAMPS
+        DEFORM_STAMP(ts_end);
+        sum_geom += ts_geom - ts_tap;
+        sum_steps += ts_end - ts_geom;
+#endif
+    }
+
+    // ---- fix-up: the marked taps' samples that left the window, gathered from global memory with clamped corners and
+    // validity-masked weights (the value deform_kernel computes); every other lane takes part with zero weights
+    if (__builtin_expect(fb_taps != 0, 0)) {
+#if EMAVFI_DEFORM_STAMPS
+        cnt_out += __popc(fb_taps);
+#endif
+        const char *gx = gplane + h * 16;
+#pragma unroll 1
+        for (unsigned left = fb_taps; left != 0; left &= left - 1) {
+            const int tap = __builtin_ctz(left);
+            const char *wtap = wbase_g + (size_t)tap * C::DCN_TAP;
+            const OmTap o = tap_om(tap);
+            const int ti = tap / 3, tj = tap - 3 * ti;
+            const float py = fminf(fmaxf((fy_base + (float)ti) + o.dy, -2.0f), fy_max);
+            const float px = fminf(fmaxf((fx_base + (float)tj) + o.dx, -2.0f), fx_max);
+            const float fy = floorf(py), fx = floorf(px);
+            const int hl = (int)fy, wl = (int)fx, hh = hl + 1, wh = wl + 1;
+            const float lh = py - fy, lw = px - fx, uh = 1.0f - lh, uw = 1.0f - lw;
+            const int ly0 = hl - ty0, lx0 = wl - tx0;
+            const bool inside = (unsigned)ly0 <= (unsigned)(C::TR - 2) && (unsigned)lx0 <= (unsigned)(C::TC - 2);
+            const bool need_fb = !inside && my_in;
+            const int hlc = min(max(hl, 0), H - 1), wlc = min(max(wl, 0), W - 1);
+            const int hhc = min(max(hh, 0), H - 1), whc = min(max(wh, 0), W - 1);
+            const bool vhl = (unsigned)hl < (unsigned)H, vhh = (unsigned)hh < (unsigned)H;
+            const bool vwl = (unsigned)wl < (unsigned)W, vwh = (unsigned)wh < (unsigned)W;
+            const float w4[4] = {need_fb && vhl && vwl ? o.mk * (uh * uw) : 0.0f, need_fb && vhl && vwh ? o.mk * (uh * lw) : 0.0f,
+                                 need_fb && vhh && vwl ? o.mk * (lh * uw) : 0.0f, need_fb && vhh && vwh ? o.mk * (lh * lw) : 0.0f};
+            // top-left pixel index | (x1 - x0) << 24 | (y1 - y0) << 25 (clamped corners) | flag << 26
+            const unsigned gpk = (__umul24((unsigned)hlc, (unsigned)W) + (unsigned)wlc) | ((unsigned)(whc - wlc) << 24) |
+                                 ((unsigned)(hhc - hlc) << 25) | (need_fb ? 1u << 26 : 0u);
+            const unsigned w01h = __builtin_bit_cast(unsigned, f16x2_t{(half_t)w4[0], (half_t)w4[1]});
+            const unsigned w23h = __builtin_bit_cast(unsigned, f16x2_t{(half_t)w4[2], (half_t)w4[3]});
+            unsigned w01[2], w23[2], gp[2];
+            {
+                auto both = [&](unsigned x, unsigned (&out)[2]) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+                    out[0] = sw[0]; out[1] = sw[1];
+                };
+                both(w01h, w01); both(w23h, w23); both(gpk, gp);
+            }
+            auto corners_of = [&](unsigned g, unsigned (&pc)[4]) {
+                const unsigned pix = g & 0xffffffu, ddx = (g >> 24) & 1u, ddy = (g >> 25) & 1u;
+                pc[0] = pix; pc[1] = pix + ddx; pc[2] = pix + (ddy ? (unsigned)W : 0u); pc[3] = pc[2] + ddx;
+            };
+            const unsigned w3a = w3lane + (unsigned)(tap * C::W3_TAP);
+#pragma unroll 1
+            for (int kg = 0; kg < 4; ++kg) {
+                f16x8 wf[2];
+#pragma unroll
+                for (int n = 0; n < 2; ++n) wf[n] = *reinterpret_cast<const f16x8 *>(wtap + (kg * 2 + n) * 1024 + lane16);
+                const f16x8 w3f = __builtin_bit_cast(f16x8, lds_read16(lds_r + w3a + (unsigned)(kg * 128)));
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    unsigned d[4][4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) d[c][0] = d[c][1] = d[c][2] = d[c][3] = 0u;
+                    if ((gp[m] >> 26) & 1u) {
+                        unsigned pc[4];
+                        corners_of(gp[m], pc);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const u32x4_t v = to_f16_piece_rt<TS>(*reinterpret_cast<const u32x4_t *>(gx + (size_t)__umul24(pc[c], ps_bytes) + (unsigned)(kg * 32)), p.in_f16);
+                            d[c][0] = v[0]; d[c][1] = v[1]; d[c][2] = v[2]; d[c][3] = v[3];
+                        }
+                    }
+                    unsigned xd[4];
+                    blend_corners_cm<4>(d, w01[m], w23[m], xd);
+                    const f16x8 xf = __builtin_bit_cast(f16x8, u32x4_t{xd[0], xd[1], xd[2], xd[3]});
+                    mma_kg(acc[m][0], wf[0], xf);
+                    mma_kg(acc[m][1], wf[1], xf);
+                    mma_kg(acc[m][2], w3f, xf);
+                }
+            }
+            if (need_fb) {   // tail of this half-lane's own pixel replaces the zero the tap loop left
+                unsigned pc[4], vt[4][4];
+                corners_of(gpk, pc);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const char *src = tplane ? tplane + (size_t)__umul24(pc[c], tail_bytes) : gplane + (size_t)__umul24(pc[c], ps_bytes) + 128;
+                    const u32x2_t raw = *reinterpret_cast<const u32x2_t *>(src);
+                    const u32x4_t cv = to_f16_piece_rt<TS>(u32x4_t{raw[0], raw[1], 0u, 0u}, p.in_f16);
+                    vt[c][0] = cv[0]; vt[c][1] = cv[1]; vt[c][2] = 0u; vt[c][3] = 0u;
+                }
+                unsigned td[4];
+                blend_corners_cm<2>(vt, w01h, w23h, td);
+                switch (tap) {
+                case 0: tl[0][0] = td[0]; tl[0][1] = td[1]; break;
+                case 1: tl[1][0] = td[0]; tl[1][1] = td[1]; break;
+                case 2: tl[2][0] = td[0]; tl[2][1] = td[1]; break;
+                case 3: tl[3][0] = td[0]; tl[3][1] = td[1]; break;
+                case 4: tl[4][0] = td[0]; tl[4][1] = td[1]; break;
+                case 5: tl[5][0] = td[0]; tl[5][1] = td[1]; break;
+                case 6: tl[6][0] = td[0]; tl[6][1] = td[1]; break;
+                case 7: tl[7][0] = td[0]; tl[7][1] = td[1]; break;
+                default: tl[8][0] = td[0]; tl[8][1] = td[1]; break;
+                }
+            }
+        }
+    }
+
+    // ---- the tail channels of all nine taps: three im2col k-groups.  Half-lane h holds its OWN row's values; one swap per
+    // dword hands tap slots (4j + 2h, 4j + 2h + 1) of row m to lane (r, h) of fragment m.
+    {
+        const char *wtl = wbase_g + C::DCN_TAIL;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            f16x8 wt[3];
+#pragma unroll
+            for (int n = 0; n < 3; ++n) wt[n] = *reinterpret_cast<const f16x8 *>(wtl + (j * 3 + n) * 1024 + lane16);
+            unsigned bm[2][4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(tl[4 * j + u][d], tl[4 * j + 2 + u][d], false, false);
+                    bm[0][2 * u + d] = sw[0];
+                    bm[1][2 * u + d] = sw[1];
+                }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const f16x8 xf = __builtin_bit_cast(f16x8, u32x4_t{bm[m][0], bm[m][1], bm[m][2], bm[m][3]});
+#pragma unroll
+                for (int n = 0; n < 3; ++n) mma_kg(acc[m][n], wt[n], xf);
+            }
+        }
+    }
+    DEFORM_STAMP(ts_loop);
+
+    // ---- epilogue (no activation: ema_vfi.py:136-138 chains the blocks directly)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        if (!in_img[m]) continue;
+        TS *op = reinterpret_cast<TS *>(p.out) + (((size_t)b * H + py_y[m]) * W + px_x) * p.out_ps;
+        if (std::is_same<TS, bf16_t>::value && p.out_f16) {
+            half_t *oh = reinterpret_cast<half_t *>(op);
+#pragma unroll
+            for (int n = 0; n < 3; ++n)
+                if (p.cstore - n * 32 > 0) store_frag(oh + n * 32, acc[m][n], h, p.cstore - n * 32, [](float v, int) { return v; });
+        } else {
+#pragma unroll
+            for (int n = 0; n < 3; ++n)
+                if (p.cstore - n * 32 > 0) store_frag(op + n * 32, acc[m][n], h, p.cstore - n * 32, [](float v, int) { return v; });
+        }
+    }
+#if EMAVFI_DEFORM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DEFORM_STAMP(ts_done);
+    if (p.stamps && lane == 0 && blockIdx.x % DEFORM_STAMP_STRIDE == 0) {
+        const unsigned row = (blockIdx.x / DEFORM_STAMP_STRIDE) * C::WAVES + wave;
+        if (row < DEFORM_STAMP_ROWS) {
+            unsigned long long *o = p.stamps + (size_t)row * 8;
+            o[0] = ts_window - ts_begin; o[1] = ts_offconv - ts_window; o[2] = sum_geom; o[3] = sum_steps;
+            o[4] = (ts_done - ts_loop) | (cnt_out << 32); o[5] = ts_done - ts_begin; o[6] = 1;
+            auto q16 = [](unsigned long long v) { v >>= 2; return v > 0xffffull ? 0xffffull : v; };
+            o[7] = q16(ts_issued - ts_begin) | (q16(ts_landed - ts_issued) << 16) | (q16(ts_converted - ts_landed) << 32) | (q16(ts_window - ts_converted) << 48);
+        }
+    }
+#endif
+}
+
+template <typename TS, bool FUSE_OFF> static int launch_deform_pack3(const DeformParams &p, hipStream_t s)
+{
+    using C = Pack3;
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&deform_pack3_kernel<TS, FUSE_OFF>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    });
+    if (attr_err != hipSuccess) return (int)attr_err;
+    const long long nwg = (long long)((p.W + C::TCOLS - 1) / C::TCOLS) * ((p.H + C::TROWS - 1) / C::TROWS) * p.B;
+    if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    deform_pack3_kernel<TS, FUSE_OFF><<<(unsigned)nwg, C::THREADS, C::LDS_BYTES, s>>>(p);
+    return (int)hipGetLastError();
+}

@@ -55,6 +55,7 @@ struct Layer {
     bool deform = false;
     bool f16_of_bf16 = false;  // bf16 model, layer consumed by deform_pack_kernel: bf16-rounded weights stored as f16
     bool mfma16 = false;       // packed for and run by conv3x3_persist16_kernel (v_mfma_f32_16x16x32): 16-bit full-resolution 64 -> (1..64) layers
+    int pack3 = 0;             // deform_pack3.inl layouts: 1 = DCN, 2 = offset_conv (f16 elements)
 };
 
 bool conv_geometry(Layer &L, int esize)
@@ -122,6 +123,13 @@ bool deform_geometry(Layer &L, int esize)
 
 // shape served by deform_pack_kernel (keep in sync with deform16_lds_shape in deform_pack.inl)
 bool deform16_lds_shape_host(int ck, int nf, int cin_real) { return ck == 80 && nf == 3 && cin_real <= 72; }
+// bf16 model: consecutive one-launch packs hand each other f16 bit patterns (the window is f16 on chip anyway; the
+// receiving pack skips its in-LDS conversion pass).  EMAVFI_PACK_F16_CHAIN=0 keeps bf16 between them (A/B switch).
+bool pack_f16_chain()
+{
+    static const bool off = [] { const char *e = getenv("EMAVFI_PACK_F16_CHAIN"); return e && e[0] == '0'; }();
+    return !off;
+}
 
 constexpr int kMaxBlocks = 8;
 
@@ -213,12 +221,18 @@ bool build_plan(Plan &P, int in_ch, int mid, int nb, int dtype)
         if (!ok) { P.why = "no fp32 deformable-conv instantiation for these channel widths"; return false; }
     }
     P.has_offh = false;
-    if (ok && dtype == EMAVFI_BF16 && nb > 0 && deform16_lds_shape_host(P.dcn[0].ck, P.dcn[0].nf, P.dcn[0].cin_take)) {
+    const bool p3 = ok && !P.amp && dtype != EMAVFI_F32 && nb > 0 && deform_pack3_shape(P.dcn[0].ck, P.dcn[0].nf, P.dcn[0].cin_take, P.dcn[0].cout) &&
+                    P.off[0].nchunk == 1 && P.off[0].npass == 1 && P.off[0].ck == 80 && P.off[0].nf == 1;
+    if (p3 || (ok && dtype == EMAVFI_BF16 && nb > 0 && deform16_lds_shape_host(P.dcn[0].ck, P.dcn[0].nf, P.dcn[0].cin_take))) {
+        // a second copy of offset_conv for the one-launch pack: f16 fragments (bf16 model: the bf16-rounded values), and in
+        // the deform_pack3.inl layout where that kernel serves the shape (both 16-bit models); off[i] keeps the conv3x3 layout
         P.has_offh = true;
         for (int i = 0; i < nb && ok; ++i) {
-            P.dcn[i].f16_of_bf16 = true;
+            P.dcn[i].f16_of_bf16 = dtype == EMAVFI_BF16;
+            P.dcn[i].pack3 = p3 ? 1 : 0;
             P.offh[i] = P.off[i];
-            P.offh[i].f16_of_bf16 = true;
+            P.offh[i].f16_of_bf16 = dtype == EMAVFI_BF16;
+            P.offh[i].pack3 = p3 ? 2 : 0;
             P.offh[i].w_off = o; o = rup256(o + P.offh[i].w_bytes);  // shares off[i]'s bias
         }
     }
@@ -267,7 +281,7 @@ unsigned long long *debug_stamp_buffer()
 
 int run_deform(const Plan &P, const Layer &L, const void *packed, const void *x, int x_ps, float *om, void *out,
                int out_ps, int cstore, int B, int H, int W, hipStream_t s, const void *zeros = nullptr, const Layer *off = nullptr,
-               const void *x_tail = nullptr, int tail_ps = 0, int force_dtype = -1)
+               const void *x_tail = nullptr, int tail_ps = 0, int force_dtype = -1, int in_f16 = 0, int out_f16 = 0)
 {
     const int kd = force_dtype >= 0 ? force_dtype : P.dtype;
     DeformParams d{};
@@ -281,8 +295,15 @@ int run_deform(const Plan &P, const Layer &L, const void *packed, const void *x,
     d.bias = (const float *)((const char *)packed + L.b_off);
     d.zeros = zeros ? zeros : (const char *)packed + P.zero_off;
     d.x_ps = x_ps; d.out_ps = out_ps; d.H = H; d.W = W; d.B = B; d.cstore = cstore; d.cin_real = L.cin_take; d.ck = L.ck; d.nf = L.nf;
+    d.cout_real = L.cout; d.pack3 = L.pack3; d.in_f16 = in_f16; d.out_f16 = out_f16;
 #if defined(EMAVFI_DEFORM_STAMPS) && EMAVFI_DEFORM_STAMPS
-    d.stamps = debug_stamp_buffer();
+    {   // diagnostic build: EMAVFI_STAMP_PACK=i records only the i-th deformable launch of every 3 (default: every launch,
+        // i.e. what is read back is the last pack of a forward)
+        static int calls = 0;
+        const char *sel = getenv("EMAVFI_STAMP_PACK");
+        if (!sel || (calls % 3) == atoi(sel)) d.stamps = debug_stamp_buffer();
+        ++calls;
+    }
 #endif
     return kd == EMAVFI_F32 ? launch_deform_f32(d, s) : kd == EMAVFI_F16 ? launch_deform_f16(d, s) : launch_deform_bf16(d, s);
 }
@@ -291,6 +312,7 @@ int pack_layer(const Layer &L, const void *const *params, void *packed, int dtyp
 {
     PackDesc d{L.cout, L.cin_raw, L.cin_off, L.cin_take, L.ck, L.nchunk, L.nf, L.npass, L.perm, L.f16_of_bf16 ? 1 : 0, bias_f16 ? 1 : 0};
     d.mfma16 = L.mfma16 ? 1 : 0;
+    d.pack3 = L.pack3;
     return launch_pack_conv((const float *)params[L.param], (const float *)params[L.param + 1], (char *)packed + L.w_off,
                             (float *)((char *)packed + L.b_off), d, L.f16_of_bf16 ? (int)EMAVFI_F16 : dtype, s);
 }
@@ -497,7 +519,13 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
         // them up from there: contiguous 16-byte pixels instead of 6 useful bytes scattered into every 160-byte fusion pixel.
         auto pack_fuses = [&](int i) {
             return dtype != EMAVFI_F32 && P.off[i].nchunk == 1 && P.off[i].npass == 1 && P.off[i].stride == 1 &&
-                   deform16_can_fuse_offset_conv(P.dcn[i].ck, P.dcn[i].nf, P.dcn[i].cin_take, P.off[i].ck, P.off[i].nf);
+                   deform16_can_fuse_offset_conv(P.dcn[i].ck, P.dcn[i].nf, P.dcn[i].cin_take, P.off[i].ck, P.off[i].nf) &&
+                   (P.dcn[i].pack3 == 0 || P.has_offh);
+        };
+        // bf16 model, consecutive one-launch packs in the deform_pack3 layout: pack i writes f16 bit patterns for pack i + 1
+        auto f16_link = [&](int i) {   // true: the tensor between pack i and pack i + 1 is f16
+            return dtype == EMAVFI_BF16 && pack_f16_chain() && i >= 0 && i + 1 < P.nb && P.dcn[i].pack3 && P.dcn[i + 1].pack3 &&
+                   pack_fuses(i) && pack_fuses(i + 1);
         };
         const bool split_tail = P.nb > 0 && pack_fuses(0) && P.fpad - mid == 16;
         EMAVFI_STEP(rec, std::string("warp_fused<") + dtype_name(dtype) + ">", 24.0 * px, px * (8.0 + 4.0 * C + C * e),
@@ -519,7 +547,7 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
                             px * (2.0 * cf * e) + 9.0 * cf * (cf + 27.0) * e,
                             run_deform(P, P.dcn[i], packed, x, P.fps, f.om, y, P.fps, P.fps, B, H, W, s, nullptr,
                                        P.has_offh ? &P.offh[i] : &P.off[i],
-                                       i == 0 && split_tail ? f.in16 : nullptr, 8));
+                                       i == 0 && split_tail ? f.in16 : nullptr, 8, -1, f16_link(i - 1) ? 1 : 0, f16_link(i) ? 1 : 0));
             } else {
                 EMAVFI_STEP(rec, conv_name(P, P.off[i]) + " offset_conv", fl, by,
                             run_conv(P, P.off[i], packed, x, P.fps, H, W, f.om, 32, 0, 32, EPI_OM, B, s));
@@ -528,7 +556,7 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
                             run_deform(P, P.dcn[i], packed, x, P.fps, f.om, y, P.fps, P.fps, B, H, W, s));
             }
             if (!rec.dry && taps && taps[5 + i])
-                EMAVFI_TRY(launch_cl_to_nchw(y, taps[5 + i], B, mid + 3, H, W, P.fps, 0, dtype, s), "tap fused");
+                EMAVFI_TRY(launch_cl_to_nchw(y, taps[5 + i], B, mid + 3, H, W, P.fps, 0, f16_link(i) ? (int)EMAVFI_F16 : dtype, s), "tap fused");
             void *t = x; x = y; y = t;
         }
     }
@@ -845,7 +873,9 @@ int emavfi_deform_conv2d(const float *x, const float *offset, const float *mask,
     L.b_off = (char *)bp - (char *)workspace;
     // the 16-bit LDS-window kernel contracts in f16 on chip: a bf16 call packs its bf16-rounded weights as f16 fragments
     const bool h_of_b = dtype == EMAVFI_BF16 && deform16_lds_shape_host(L.ck, L.nf, L.cin_take);
+    if (dtype != EMAVFI_F32 && deform_pack3_shape(L.ck, L.nf, L.cin_take, L.cout)) L.pack3 = 1;
     PackDesc d{L.cout, L.cin_raw, 0, L.cin_take, L.ck, 1, L.nf, 1, 0, h_of_b ? 1 : 0};
+    d.pack3 = L.pack3;
     if (hipMemsetAsync(zpage, 0, 256, s) != hipSuccess) return fail(EMAVFI_E_LAUNCH, "deform_conv2d: zero page memset failed");
     EMAVFI_TRY(launch_pack_conv(weight, bias, wp, bp, d, h_of_b ? (int)EMAVFI_F16 : dtype, s), "deform pack");
     EMAVFI_TRY(launch_nchw_to_cl(x, xcl, B, C, H, W, L.ck, dtype, s), "deform layout in");

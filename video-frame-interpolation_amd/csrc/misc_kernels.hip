@@ -75,8 +75,74 @@ __global__ void pack_conv_kernel(const float *__restrict__ w, const float *__res
     }
 }
 
+// deform_pack3.inl layouts (always f16 elements; via_bf16 rounds to bf16 first).  Input channels 0..63 are four k-groups per
+// tap; channels 64..66 of all nine taps form three im2col k-groups: K = 16 j + 8 h + e <-> tap slot 4 j + 2 h + (e >> 2),
+// channel 64 + (e & 3) (slots 9..11 and channel 67 are zero).
+//   pack3 = 1 (DCN):          [tap][kg 4][nf 2][lane][8] | third fragment as a table [tap][kg 4][row 0..3][h][8] (row 3 = zeros)
+//                             | tail [j 3][nf 3][lane][8]
+//   pack3 = 2 (offset_conv):  [tap][kg 4][lane][8] | tail [j 3][lane][8]
+__global__ void pack_deform3_kernel(const float *__restrict__ w, const float *__restrict__ bias, half_t *__restrict__ wp,
+                                    float *__restrict__ bp, PackDesc d)
+{
+    const int nA = d.pack3 == 1 ? 9 * 4 * 2 * 64 * 8 : 9 * 4 * 64 * 8;
+    const int nB = d.pack3 == 1 ? 9 * 4 * 4 * 2 * 8 : 0;
+    const int nC = d.pack3 == 1 ? 3 * 3 * 64 * 8 : 3 * 64 * 8;
+    const int nfm = d.pack3 == 1 ? 2 : 1, nft = d.pack3 == 1 ? 3 : 1;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < nA + nB + nC; idx += gridDim.x * blockDim.x) {
+        int co, ci, tap;
+        bool real = true;
+        if (idx < nA) {
+            int t = idx;
+            const int e = t % 8; t /= 8;
+            const int lane = t % 64; t /= 64;
+            const int n = t % nfm; t /= nfm;
+            const int kg = t % 4; t /= 4;
+            tap = t;
+            co = n * 32 + (lane & 31);
+            ci = kg * 16 + (lane >> 5) * 8 + e;
+        } else if (idx < nA + nB) {
+            int t = idx - nA;
+            const int e = t % 8; t /= 8;
+            const int hh = t % 2; t /= 2;
+            const int row = t % 4; t /= 4;
+            const int kg = t % 4; t /= 4;
+            tap = t;
+            co = 64 + row;
+            real = row < 3;
+            ci = kg * 16 + hh * 8 + e;
+        } else {
+            int t = idx - nA - nB;
+            const int e = t % 8; t /= 8;
+            const int lane = t % 64; t /= 64;
+            const int n = t % nft; t /= nft;
+            const int j = t;
+            tap = 4 * j + 2 * (lane >> 5) + (e >> 2);
+            co = n * 32 + (lane & 31);
+            ci = 64 + (e & 3);
+            real = tap < 9 && (e & 3) < 3;
+            if (!real) tap = 0;
+        }
+        co = route_cout(co, d.perm);
+        float v = 0.0f;
+        if (real && co < d.cout && ci < d.cin_take) v = w[((size_t)co * d.cin_raw + d.cin_off + ci) * 9 + tap];
+        if (d.via_bf16) v = (float)(bf16_t)v;
+        wp[idx] = (half_t)v;
+    }
+    const int coutpad = d.npass * d.nf * 32;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < coutpad; i += gridDim.x * blockDim.x) {
+        const int co = route_cout(i, d.perm);
+        float bv = (co < d.cout && bias) ? bias[co] : 0.0f;
+        if (d.bias_f16) bv = (float)(half_t)bv;
+        bp[i] = bv;
+    }
+}
+
 int launch_pack_conv(const float *w, const float *bias, void *wp, float *bp, const PackDesc &d, int dtype, hipStream_t s)
 {
+    if (d.pack3) {
+        pack_deform3_kernel<<<64, 256, 0, s>>>(w, bias, (half_t *)wp, bp, d);
+        return (int)hipGetLastError();
+    }
     if (dtype == 0)
         pack_conv_kernel<float><<<256, 256, 0, s>>>(w, bias, (float *)wp, bp, d);
     else if (dtype == 2)
