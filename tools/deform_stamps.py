@@ -34,7 +34,7 @@ n_out = ((sel[:, 4] >> np.uint64(32)) & np.uint64(0xff)).astype(np.float64)     
 n_lanes = (sel[:, 4] >> np.uint64(40)).astype(np.float64)                          # lanes outside, of 18 * 64
 sel[:, 4] &= np.uint64(0xffffffff)
 v = sel.astype(np.float64)
-names = ["prologue (window DMA + barrier)", "offset_conv", "pick + geometry (9 taps)",
+names = ["prologue (window DMA + barrier)", "offset_conv", "geometry + tail of all 9 taps (up front)",
          "gather + blend + MFMA steps (9 taps)", "epilogue stores (drained)", "total"]
 print(f"{dtype}: {len(v)} waves sampled (median cycles per wave and tile)")
 tot = np.median(v[:, 5])
@@ -46,4 +46,4 @@ d = buf[buf[:, 6] == 1][:, 7]
 parts = [((d >> np.uint64(16 * i)) & np.uint64(0xffff)).astype(np.float64) * 4 for i in range(4)]
 print("  prologue detail (median cycles): tile mapping + small loads + DMA issue %.0f, DMA landed after %.0f, convert %.0f, barrier wait %.0f"
       % tuple(np.median(x) for x in parts))
-print(f"  per tap: geometry {np.median(v[:, 2]) / 9:.0f}, steps {np.median(v[:, 3]) / 9:.0f} cycles")
+print(f"  per tap: steps {np.median(v[:, 3]) / 9:.0f} cycles")

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
     const unsigned lane16 = (unsigned)lane * 16u;
     DEFORM_STAMP(ts_begin);
 #if EMAVFI_DEFORM_STAMPS
-    unsigned long long sum_geom = 0, sum_steps = 0, cnt_out = 0;
+    unsigned long long sum_steps = 0, cnt_out = 0;
 #endif
 
     // ---- tile of this workgroup (XCD-aware order: deform_pack.inl)
@@ -265,11 +265,14 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
             for (int i = 0; i < 16; ++i) {
                 const int c = acc_channel(i, h);
                 const float v = omr[m][i];
-                omr[m][i] = (c >= 18 && c < 27) ? 1.0f / (1.0f + expf(-v)) : v;
+                // v_exp_f32 + v_rcp_f32 (1 ulp each): the value becomes an f16 blend weight; the IEEE division and libm expf of
+                // the stand-alone layer cost ~25 instructions per value, 18 values per lane
+                const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
+                omr[m][i] = (c >= 18 && c < 27) ? sg : v;
             }
     }
 
-    // ---- DCN: 9 taps x 4 k-groups x 2 rows, two fragments from global fragments + the third from the LDS table
+    // ---- DCN.  Accumulators; the first weight fragments.
     f16x8 wq[2][2];  // [kg & 1][n]
 #pragma unroll
     for (int n = 0; n < 2; ++n) wq[0][n] = *reinterpret_cast<const f16x8 *>(wbase_g + n * 1024 + lane16);
@@ -280,95 +283,128 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
         for (int n = 0; n < 3; ++n)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[m][n][i] = p.bias[n * 32 + acc_channel(i, h)];
-    unsigned tl[12][2];  // blended tail (channels 64..66 of this half-lane's own pixel) per tap slot; slots 9..11 stay zero
-#pragma unroll
-    for (int t = 0; t < 12; ++t) tl[t][0] = tl[t][1] = 0u;
     DEFORM_STAMP(ts_offconv);
 
-    // (dy, dx, mask) of this half-lane's row for tap `tap` (wave-uniform): fused, channel c of (row 0 | row 1) of this lane's
-    // pixels is delivered to (half 0 | half 1) by one swap - swap(a, b) -> {(a.lo, b.lo), (a.hi, b.hi)}, the channel lives in
-    // half-lane (c >> 2) & 1, register (c & 3) + 4 * (c >> 3) of the offset_conv's accumulators; else read from p.om
-    auto tap_om = [&](int tap) {
+    // ---- sampling geometry of ALL NINE taps up front (fp32, compare-free clamps: NaN -> -2; positions <= -1 or >= size sample
+    // zeros).  Half-lane h handles the pixel of fragment row h.  Nine independent chains in one block instead of one dependent
+    // chain in front of every tap's steps; the offset_conv's accumulators die here.  Per tap a lane keeps three registers:
+    //   sample inside the staged window:  window byte offset of its top-left corner | (w00, w01) | (w10, w11) as f16 pairs
+    //   sample outside (|offset| > R near the tile edge: rare):  py | px | mask as fp32 bits, bit `tap` of lane_fb set.
+    // Such a sample contributes NOTHING in the tap loop (zero weights, window offset 0); the fix-up loop behind it adds the
+    // missing samples from global memory.  The common path carries no fallback code.
+    constexpr int OFF[4] = {0, C::PSB, C::ROWB, C::ROWB + C::PSB};
+    // (three 16-element register vectors: a wave-uniform runtime index into an ext_vector lowers to an indexed register move,
+    // where a switch over nine scalars was turned into a scratch-memory table by hipcc)
+    typedef unsigned u32x16_t __attribute__((ext_vector_type(9)));
+    u32x16_t gm0 = {}, gm1 = {}, gm2 = {};
+    unsigned lane_fb = 0, fb_taps = 0;   // per-lane / wave-uniform masks over taps
+    unsigned tl[12][2];                  // blended tail (channels 64..66 of this half-lane's own pixel) per tap slot; 9..11 zero
+#pragma unroll
+    for (int t = 9; t < 12; ++t) tl[t][0] = tl[t][1] = 0u;
+    auto geom_tap = [&](auto tc) {
+        constexpr int tap = decltype(tc)::value, ti = tap / 3, tj = tap - 3 * ti;
         OmTap o;
         if constexpr (FUSE_OFF) {
+            // channel c of (row 0 | row 1) of this lane's pixels, delivered to (half 0 | half 1): one swap.
+            // swap(a, b) -> {(a.lo, b.lo), (a.hi, b.hi)}; the channel lives in half-lane (c >> 2) & 1, register (c & 3) + 4 * (c >> 3)
             auto pick = [&](auto cc) {
                 constexpr int c = decltype(cc)::value;
                 constexpr int reg = (c & 3) + 4 * (c >> 3);
                 const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(omr[0][reg]), __float_as_uint(omr[1][reg]), false, false);
                 return __uint_as_float(((c >> 2) & 1) ? sw[1] : sw[0]);
             };
-            auto take = [&](auto kc) {
-                constexpr int k = decltype(kc)::value;
-                o.dy = pick(std::integral_constant<int, 2 * k>{});
-                o.dx = pick(std::integral_constant<int, 2 * k + 1>{});
-                o.mk = pick(std::integral_constant<int, 18 + k>{});
-            };
-            switch (tap) {  // registers cannot be indexed by a loop variable
-            case 0: take(std::integral_constant<int, 0>{}); break;
-            case 1: take(std::integral_constant<int, 1>{}); break;
-            case 2: take(std::integral_constant<int, 2>{}); break;
-            case 3: take(std::integral_constant<int, 3>{}); break;
-            case 4: take(std::integral_constant<int, 4>{}); break;
-            case 5: take(std::integral_constant<int, 5>{}); break;
-            case 6: take(std::integral_constant<int, 6>{}); break;
-            case 7: take(std::integral_constant<int, 7>{}); break;
-            default: take(std::integral_constant<int, 8>{}); break;
-            }
+            o.dy = pick(std::integral_constant<int, 2 * tap>{});
+            o.dx = pick(std::integral_constant<int, 2 * tap + 1>{});
+            o.mk = pick(std::integral_constant<int, 18 + tap>{});
             if (!my_in) o.mk = 0.0f;   // pixels of the tile overhang contribute nothing (and are never stored)
         } else {
             o = load_om(om_my, tap, my_in);
         }
-        return o;
-    };
-    unsigned fb_taps = 0;  // wave-uniform: taps in which some lane's sample left the window
-    OmTap nxt;
-    if (!FUSE_OFF) nxt = load_om(om_my, 0, my_in);   // offsets / masks from memory: one tap ahead
-#pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
-        DEFORM_STAMP(ts_tap);
-        const char *wtap = wbase_g + (size_t)tap * C::DCN_TAP;   // wave-uniform
-        OmTap o;
-        if constexpr (FUSE_OFF) o = tap_om(tap);
-        else {
-            o = nxt;
-            if (tap < 8) nxt = load_om(om_my, tap + 1, my_in);
-        }
-        // ---- sampling geometry (fp32, compare-free clamps: NaN -> -2; positions <= -1 or >= size sample zeros)
-        const int ti = tap / 3, tj = tap - 3 * ti;
         const float py = fminf(fmaxf((fy_base + (float)ti) + o.dy, -2.0f), fy_max);
         const float px = fminf(fmaxf((fx_base + (float)tj) + o.dx, -2.0f), fx_max);
         const float fy = floorf(py), fx = floorf(px);
         const int hl = (int)fy, wl = (int)fx;
         const float lh = py - fy, lw = px - fx, uh = 1.0f - lh, uw = 1.0f - lw;
-        float w4[4] = {o.mk * (uh * uw), o.mk * (uh * lw), o.mk * (lh * uw), o.mk * (lh * lw)};
+        const float w4[4] = {o.mk * (uh * uw), o.mk * (uh * lw), o.mk * (lh * uw), o.mk * (lh * lw)};
+        // window-local top-left corner; all four corners inside the staged window <=> 0 <= ly0 <= TR-2 and 0 <= lx0 <= TC-2
         const int ly0 = hl - ty0, lx0 = wl - tx0;
         const bool inside = (unsigned)ly0 <= (unsigned)(C::TR - 2) && (unsigned)lx0 <= (unsigned)(C::TC - 2);
+        // pixels of the tile overhang (mask forced to 0) read their clamped window position: 0 x finite data
+        const bool need_fb = !EMAVFI_DEFORM_ABL_NO_FALLBACK && !inside && my_in;
         const unsigned mybase = __umul24((unsigned)min(max(ly0, 0), C::TR - 2), (unsigned)C::ROWB) +
                                 __umul24((unsigned)min(max(lx0, 0), C::TC - 2), (unsigned)C::PSB);
-        // pixels of the tile overhang (mask forced to 0) read their clamped window position: 0 x finite data
-        const bool need_fb = !inside && my_in;
-        const bool any_out = !EMAVFI_DEFORM_ABL_NO_FALLBACK && __any(need_fb);   // wave-uniform: both rows
-        // A sample that leaves the window (|offset| > R near the tile edge: rare) contributes NOTHING here - its weights
-        // are zeroed, its reads go to the clamped window position - and the tap is marked: the fix-up loop behind this
-        // one adds the marked taps' missing samples from global memory.  The common path carries no fallback code.
-        if (any_out) fb_taps |= 1u << tap;
-        if (need_fb) { w4[0] = 0.0f; w4[1] = 0.0f; w4[2] = 0.0f; w4[3] = 0.0f; }
-        const unsigned w01h = __builtin_bit_cast(unsigned, f16x2_t{(half_t)w4[0], (half_t)w4[1]});
-        const unsigned w23h = __builtin_bit_cast(unsigned, f16x2_t{(half_t)w4[2], (half_t)w4[3]});
+        // branch-free on purpose (bit masks, not ?: - hipcc turns the selects into EXEC branches that cut the block in nine)
+        const unsigned keep = need_fb ? 0u : 0xffffffffu;
+        const unsigned w01h = __builtin_bit_cast(unsigned, f16x2_t{(half_t)w4[0], (half_t)w4[1]}) & keep;
+        const unsigned w23h = __builtin_bit_cast(unsigned, f16x2_t{(half_t)w4[2], (half_t)w4[3]}) & keep;
+        gm0[tap] = (mybase & keep) | (__float_as_uint(py) & ~keep);
+        gm1[tap] = w01h | (__float_as_uint(px) & ~keep);
+        gm2[tap] = w23h | (__float_as_uint(o.mk) & ~keep);
+        lane_fb |= ~keep & (1u << tap);
+        fb_taps |= __any(need_fb) ? 1u << tap : 0u;
+        // tail of this half-lane's own pixel: four 8-byte corner reads (clamped position: always a valid window address)
+        // (no scheduling fences in this blend: the nine taps' chains are meant to interleave)
+        u32x4_t vt[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const u32x2_t t2 = lds_read8(lds_r + mybase + (unsigned)(128 + OFF[c]));
+            vt[c] = u32x4_t{t2[0], t2[1], 0u, 0u};
+        }
+        const u32x4_t td = __builtin_bit_cast(u32x4_t, blend_corners<2>(vt, w01h, w23h));
+        tl[tap][0] = td[0]; tl[tap][1] = td[1];
+    };
+    geom_tap(std::integral_constant<int, 0>{}); geom_tap(std::integral_constant<int, 1>{}); geom_tap(std::integral_constant<int, 2>{});
+    geom_tap(std::integral_constant<int, 3>{}); geom_tap(std::integral_constant<int, 4>{}); geom_tap(std::integral_constant<int, 5>{});
+    geom_tap(std::integral_constant<int, 6>{}); geom_tap(std::integral_constant<int, 7>{}); geom_tap(std::integral_constant<int, 8>{});
+
+    // ---- the tail channels of all nine taps: three im2col k-groups, contracted first.  Half-lane h holds its OWN row's values;
+    // one swap per dword hands tap slots (4j + 2h, 4j + 2h + 1) of row m to lane (r, h) of fragment m.
+    const char *wtl = wbase_g + C::DCN_TAIL;
+    auto tail_mma = [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        f16x8 wt[3];
+#pragma unroll
+        for (int n = 0; n < 3; ++n) wt[n] = *reinterpret_cast<const f16x8 *>(wtl + (j * 3 + n) * 1024 + lane16);
+        unsigned bm[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(tl[4 * j + u][d], tl[4 * j + 2 + u][d], false, false);
+                bm[0][2 * u + d] = sw[0];
+                bm[1][2 * u + d] = sw[1];
+            }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const f16x8 xf = __builtin_bit_cast(f16x8, u32x4_t{bm[m][0], bm[m][1], bm[m][2], bm[m][3]});
+#pragma unroll
+            for (int n = 0; n < 3; ++n) mma_kg(acc[m][n], wt[n], xf);
+        }
+    };
+    tail_mma(std::integral_constant<int, 0>{}); tail_mma(std::integral_constant<int, 1>{}); tail_mma(std::integral_constant<int, 2>{});
+    DEFORM_STAMP(ts_geom_all);
+
+    // ---- 9 taps x 4 k-groups x 2 rows: two fragments from global weight fragments, the third from the LDS table
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+        DEFORM_STAMP(ts_tap);
+        const char *wtap = wbase_g + (size_t)tap * C::DCN_TAP;   // wave-uniform
+        unsigned g0 = gm0[tap], g1 = gm1[tap], g2 = gm2[tap];   // wave-uniform index: indexed register moves
+        if (__builtin_expect((fb_taps >> tap) & 1u, 0)) {   // wave-uniform, rare: lanes parked for the fix-up loop hold (py, px, mask)
+            if ((lane_fb >> tap) & 1u) { g0 = 0u; g1 = 0u; g2 = 0u; }
+        }
         unsigned base[2], w01[2], w23[2];
         {
             auto both = [&](unsigned x, unsigned (&out)[2]) {
                 const auto sw = __builtin_amdgcn_permlane32_swap(x, x, false, false);
                 out[0] = sw[0]; out[1] = sw[1];
             };
-            both(w01h, w01); both(w23h, w23);
+            both(g1, w01); both(g2, w23);
             // swap(a, b) = {(a.lo, b.lo), (a.hi, b.hi)}: the h = 1 receivers take b = base + 16 (their piece of the pixel)
-            const auto sw = __builtin_amdgcn_permlane32_swap(mybase, mybase + 16u, false, false);
+            const auto sw = __builtin_amdgcn_permlane32_swap(g0, g0 + 16u, false, false);
             base[0] = sw[0]; base[1] = sw[1];
         }
-        DEFORM_STAMP(ts_geom);
         const unsigned w3a = w3lane + (unsigned)(tap * C::W3_TAP);
-        constexpr int OFF[4] = {0, C::PSB, C::ROWB, C::ROWB + C::PSB};
         auto gather = [&](int s, unsigned (&d)[4][4]) {
             const int kg = s >> 1, m = s & 1;
 #pragma unroll
@@ -379,14 +415,6 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
         };
         unsigned vb[2][4][4];
         gather(0, vb[0]);
-        // tail of this half-lane's own pixel: four 8-byte corner reads
-        unsigned vt[4][4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const u32x2_t t2 = lds_read8(lds_r + mybase + (unsigned)(128 + OFF[c]));
-            vt[c][0] = t2[0]; vt[c][1] = t2[1]; vt[c][2] = 0u; vt[c][3] = 0u;
-        }
-        unsigned tval[2];
         f16x8 w3f;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
@@ -408,27 +436,10 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
             mma_kg(acc[m][0], wq[kg & 1][0], xf);
             mma_kg(acc[m][1], wq[kg & 1][1], xf);
             mma_kg(acc[m][2], w3f, xf);
-            if (s == 3) {
-                unsigned td[4];
-                blend_corners_cm<2>(vt, w01h, w23h, td);
-                tval[0] = td[0]; tval[1] = td[1];
-            }
-        }
-        switch (tap) {  // wave-uniform register select
-        case 0: tl[0][0] = tval[0]; tl[0][1] = tval[1]; break;
-        case 1: tl[1][0] = tval[0]; tl[1][1] = tval[1]; break;
-        case 2: tl[2][0] = tval[0]; tl[2][1] = tval[1]; break;
-        case 3: tl[3][0] = tval[0]; tl[3][1] = tval[1]; break;
-        case 4: tl[4][0] = tval[0]; tl[4][1] = tval[1]; break;
-        case 5: tl[5][0] = tval[0]; tl[5][1] = tval[1]; break;
-        case 6: tl[6][0] = tval[0]; tl[6][1] = tval[1]; break;
-        case 7: tl[7][0] = tval[0]; tl[7][1] = tval[1]; break;
-        default: tl[8][0] = tval[0]; tl[8][1] = tval[1]; break;
         }
 #if EMAVFI_DEFORM_STAMPS
         DEFORM_STAMP(ts_end);
-        sum_geom += ts_geom - ts_tap;
-        sum_steps += ts_end - ts_geom;
+        sum_steps += ts_end - ts_tap;
 #endif
     }
 
@@ -443,22 +454,19 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
         for (unsigned left = fb_taps; left != 0; left &= left - 1) {
             const int tap = __builtin_ctz(left);
             const char *wtap = wbase_g + (size_t)tap * C::DCN_TAP;
-            const OmTap o = tap_om(tap);
-            const int ti = tap / 3, tj = tap - 3 * ti;
-            const float py = fminf(fmaxf((fy_base + (float)ti) + o.dy, -2.0f), fy_max);
-            const float px = fminf(fmaxf((fx_base + (float)tj) + o.dx, -2.0f), fx_max);
+            const unsigned g0 = gm0[tap], g1 = gm1[tap], g2 = gm2[tap];
+            const bool need_fb = ((lane_fb >> tap) & 1u) != 0;
+            const float py = need_fb ? __uint_as_float(g0) : 0.0f, px = need_fb ? __uint_as_float(g1) : 0.0f;
+            const float mk = need_fb ? __uint_as_float(g2) : 0.0f;
             const float fy = floorf(py), fx = floorf(px);
             const int hl = (int)fy, wl = (int)fx, hh = hl + 1, wh = wl + 1;
             const float lh = py - fy, lw = px - fx, uh = 1.0f - lh, uw = 1.0f - lw;
-            const int ly0 = hl - ty0, lx0 = wl - tx0;
-            const bool inside = (unsigned)ly0 <= (unsigned)(C::TR - 2) && (unsigned)lx0 <= (unsigned)(C::TC - 2);
-            const bool need_fb = !inside && my_in;
             const int hlc = min(max(hl, 0), H - 1), wlc = min(max(wl, 0), W - 1);
             const int hhc = min(max(hh, 0), H - 1), whc = min(max(wh, 0), W - 1);
             const bool vhl = (unsigned)hl < (unsigned)H, vhh = (unsigned)hh < (unsigned)H;
             const bool vwl = (unsigned)wl < (unsigned)W, vwh = (unsigned)wh < (unsigned)W;
-            const float w4[4] = {need_fb && vhl && vwl ? o.mk * (uh * uw) : 0.0f, need_fb && vhl && vwh ? o.mk * (uh * lw) : 0.0f,
-                                 need_fb && vhh && vwl ? o.mk * (lh * uw) : 0.0f, need_fb && vhh && vwh ? o.mk * (lh * lw) : 0.0f};
+            const float w4[4] = {vhl && vwl ? mk * (uh * uw) : 0.0f, vhl && vwh ? mk * (uh * lw) : 0.0f,
+                                 vhh && vwl ? mk * (lh * uw) : 0.0f, vhh && vwh ? mk * (lh * lw) : 0.0f};
             // top-left pixel index | (x1 - x0) << 24 | (y1 - y0) << 25 (clamped corners) | flag << 26
             const unsigned gpk = (__umul24((unsigned)hlc, (unsigned)W) + (unsigned)wlc) | ((unsigned)(whc - wlc) << 24) |
                                  ((unsigned)(hhc - hlc) << 25) | (need_fb ? 1u << 26 : 0u);
@@ -505,56 +513,43 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
                     mma_kg(acc[m][2], w3f, xf);
                 }
             }
-            if (need_fb) {   // tail of this half-lane's own pixel replaces the zero the tap loop left
-                unsigned pc[4], vt[4][4];
-                corners_of(gpk, pc);
+            // tail channels of the parked lanes' own pixels: one im2col k-group with this tap's slot alone
+            {
+                unsigned vt[4][4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const char *src = tplane ? tplane + (size_t)__umul24(pc[c], tail_bytes) : gplane + (size_t)__umul24(pc[c], ps_bytes) + 128;
-                    const u32x2_t raw = *reinterpret_cast<const u32x2_t *>(src);
-                    const u32x4_t cv = to_f16_piece_rt<TS>(u32x4_t{raw[0], raw[1], 0u, 0u}, p.in_f16);
-                    vt[c][0] = cv[0]; vt[c][1] = cv[1]; vt[c][2] = 0u; vt[c][3] = 0u;
+                for (int c = 0; c < 4; ++c) vt[c][0] = vt[c][1] = vt[c][2] = vt[c][3] = 0u;
+                if (need_fb) {
+                    unsigned pc[4];
+                    corners_of(gpk, pc);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const char *src = tplane ? tplane + (size_t)__umul24(pc[c], tail_bytes) : gplane + (size_t)__umul24(pc[c], ps_bytes) + 128;
+                        const u32x2_t raw = *reinterpret_cast<const u32x2_t *>(src);
+                        const u32x4_t cv = to_f16_piece_rt<TS>(u32x4_t{raw[0], raw[1], 0u, 0u}, p.in_f16);
+                        vt[c][0] = cv[0]; vt[c][1] = cv[1];
+                    }
                 }
                 unsigned td[4];
                 blend_corners_cm<2>(vt, w01h, w23h, td);
-                switch (tap) {
-                case 0: tl[0][0] = td[0]; tl[0][1] = td[1]; break;
-                case 1: tl[1][0] = td[0]; tl[1][1] = td[1]; break;
-                case 2: tl[2][0] = td[0]; tl[2][1] = td[1]; break;
-                case 3: tl[3][0] = td[0]; tl[3][1] = td[1]; break;
-                case 4: tl[4][0] = td[0]; tl[4][1] = td[1]; break;
-                case 5: tl[5][0] = td[0]; tl[5][1] = td[1]; break;
-                case 6: tl[6][0] = td[0]; tl[6][1] = td[1]; break;
-                case 7: tl[7][0] = td[0]; tl[7][1] = td[1]; break;
-                default: tl[8][0] = td[0]; tl[8][1] = td[1]; break;
-                }
-            }
-        }
-    }
-
-    // ---- the tail channels of all nine taps: three im2col k-groups.  Half-lane h holds its OWN row's values; one swap per
-    // dword hands tap slots (4j + 2h, 4j + 2h + 1) of row m to lane (r, h) of fragment m.
-    {
-        const char *wtl = wbase_g + C::DCN_TAIL;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            f16x8 wt[3];
-#pragma unroll
-            for (int n = 0; n < 3; ++n) wt[n] = *reinterpret_cast<const f16x8 *>(wtl + (j * 3 + n) * 1024 + lane16);
-            unsigned bm[2][4];
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
+                // K = 16 j + 8 h' + 4 u + channel with tap = 4 j + 2 h' + u: only lanes of half h' carry it, in dwords (2u, 2u + 1)
+                const int j = tap >> 2, hsel = (tap >> 1) & 1, u = tap & 1;
+                unsigned tm[2][2];
 #pragma unroll
                 for (int d = 0; d < 2; ++d) {
-                    const auto sw = __builtin_amdgcn_permlane32_swap(tl[4 * j + u][d], tl[4 * j + 2 + u][d], false, false);
-                    bm[0][2 * u + d] = sw[0];
-                    bm[1][2 * u + d] = sw[1];
+                    const auto sw = __builtin_amdgcn_permlane32_swap(td[d], td[d], false, false);   // {row 0's, row 1's} in both halves
+                    tm[0][d] = h == hsel ? sw[0] : 0u;
+                    tm[1][d] = h == hsel ? sw[1] : 0u;
                 }
+                f16x8 wt[3];
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const f16x8 xf = __builtin_bit_cast(f16x8, u32x4_t{bm[m][0], bm[m][1], bm[m][2], bm[m][3]});
+                for (int n = 0; n < 3; ++n) wt[n] = *reinterpret_cast<const f16x8 *>(wtl + (j * 3 + n) * 1024 + lane16);
 #pragma unroll
-                for (int n = 0; n < 3; ++n) mma_kg(acc[m][n], wt[n], xf);
+                for (int m = 0; m < 2; ++m) {
+                    const u32x4_t bq = u ? u32x4_t{0u, 0u, tm[m][0], tm[m][1]} : u32x4_t{tm[m][0], tm[m][1], 0u, 0u};
+                    const f16x8 xf = __builtin_bit_cast(f16x8, bq);
+#pragma unroll
+                    for (int n = 0; n < 3; ++n) mma_kg(acc[m][n], wt[n], xf);
+                }
             }
         }
     }
@@ -583,7 +578,7 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
         const unsigned row = (blockIdx.x / DEFORM_STAMP_STRIDE) * C::WAVES + wave;
         if (row < DEFORM_STAMP_ROWS) {
             unsigned long long *o = p.stamps + (size_t)row * 8;
-            o[0] = ts_window - ts_begin; o[1] = ts_offconv - ts_window; o[2] = sum_geom; o[3] = sum_steps;
+            o[0] = ts_window - ts_begin; o[1] = ts_offconv - ts_window; o[2] = ts_geom_all - ts_offconv; o[3] = sum_steps;
             o[4] = (ts_done - ts_loop) | (cnt_out << 32); o[5] = ts_done - ts_begin; o[6] = 1;
             auto q16 = [](unsigned long long v) { v >>= 2; return v > 0xffffull ? 0xffffull : v; };
             o[7] = q16(ts_issued - ts_begin) | (q16(ts_landed - ts_issued) << 16) | (q16(ts_converted - ts_landed) << 32) | (q16(ts_window - ts_converted) << 48);
