@@ -27,6 +27,11 @@
 #pragma once
 #include "deform_pack.inl"
 
+// timing-only ablations (wrong results): bit 0 no weight-fragment loads in the tap loop, 1 undeformed (conflict-free) gathers,
+// 2 no blend, 3 no MFMAs in the tap loop, 4 no window DMA, 5 no offset_conv MFMAs
+#ifndef EMAVFI_P3_ABL
+#define EMAVFI_P3_ABL 0
+#endif
 struct Pack3 {
     static constexpr int R = 2, TROWS = 16, TCOLS = 16, WAVES = 4, THREADS = 256;
     static constexpr int TR = TROWS + 3 + 2 * R, TC = TCOLS + 3 + 2 * R;                 // 23 x 23 window pixels
@@ -73,6 +78,16 @@ template <int NQ> __device__ __forceinline__ void blend_corners_cm(const unsigne
 #pragma unroll
     for (int q = 0; q < NQ; ++q) out[q] = __builtin_bit_cast(unsigned, a[q]);
 }
+
+// Pins a point of the hand-made schedule: an empty volatile asm that "rewrites" the four partial sums (instruction selection
+// otherwise places plain arithmetic anywhere between its operands and its users, on either side of a scheduling fence - half of
+// the steps came out with their blend sunk behind their MFMAs), then the fence for the machine scheduler.  The asm emits no
+// instruction, so the hazard recogniser still sees the real producer of every MFMA operand.
+#define PACK3_PIN(a)                                                                  \
+    do {                                                                              \
+        asm volatile("" : "+v"((a)[0]), "+v"((a)[1]), "+v"((a)[2]), "+v"((a)[3]));    \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+    } while (0)
 
 template <typename TS, bool FUSE_OFF>
 __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams p)
@@ -135,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
         const bool from_tail = tplane != nullptr && dpc == C::SP - 1;   // channels 64..71 from the compact tail buffer
         const char *src = from_tail ? tplane + pix0 * (long long)tail_bytes : gplane + pix0 * (long long)ps_bytes + dpc * 16;
         const unsigned inc = (unsigned)W * (from_tail ? tail_bytes : ps_bytes);
-        if (dact) {
+        if (dact && !(EMAVFI_P3_ABL & 16)) {
 #pragma unroll
             for (int ly = 0; ly < C::TR; ++ly) {
                 const bool ok = dcol && (unsigned)(ty0 + ly) < (unsigned)H;
@@ -227,7 +242,8 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int kg = 0; kg < 4; ++kg) mma_kg(omr[m], ow[tap % 3][kg], __builtin_bit_cast(f16x8, xq[tap & 1][m][kg]));
+                for (int kg = 0; kg < 4; ++kg)
+                    if (!(EMAVFI_P3_ABL & 32) || kg == 0) mma_kg(omr[m], ow[tap % 3][kg], __builtin_bit_cast(f16x8, xq[tap & 1][m][kg]));
             __builtin_amdgcn_sched_barrier(0);
         };
         off_tap(std::integral_constant<int, 0>{}); off_tap(std::integral_constant<int, 1>{}); off_tap(std::integral_constant<int, 2>{});
@@ -385,6 +401,9 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
     DEFORM_STAMP(ts_geom_all);
 
     // ---- 9 taps x 4 k-groups x 2 rows: two fragments from global weight fragments, the third from the LDS table
+    f16x8 xf_prev = {}, w3_prev = {}, w3_cur = {};   // software pipeline: the MFMAs of a step run inside the NEXT step's blend
+#pragma unroll
+    for (int n = 0; n < 2; ++n) wq[1][n] = f16x8{};  // read (against the zero xf_prev) by the first tap's first step
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
         DEFORM_STAMP(ts_tap);
@@ -403,8 +422,16 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
             // swap(a, b) = {(a.lo, b.lo), (a.hi, b.hi)}: the h = 1 receivers take b = base + 16 (their piece of the pixel)
             const auto sw = __builtin_amdgcn_permlane32_swap(g0, g0 + 16u, false, false);
             base[0] = sw[0]; base[1] = sw[1];
+            if (EMAVFI_P3_ABL & 2) { base[0] = xbase[0] + (unsigned)(tap * 16); base[1] = xbase[1] + (unsigned)(tap * 16); }
         }
         const unsigned w3a = w3lane + (unsigned)(tap * C::W3_TAP);
+        // ---- the eight (k-group, row) steps, scheduled by hand.  Left to hipcc the block came out as runs of 4-6 back-to-back
+        // MFMAs (the wave parked behind the matrix pipe, 32 cycles each) between runs of 16-32 blend instructions (the pipe
+        // idle) - and the SIMD's other wave runs the same program.  Here the three MFMAs of step s - 1 are issued between the
+        // thirds of step s's blend (5 / 5 / 6 packed FMAs, corner-major: 8 + ~24 issue cycles per 32-cycle MFMA), the corner
+        // reads of step s + 1 and the next k-group's weight fragments go out at the head of step s, and sched_barrier(0)
+        // pins that order.  The last step's MFMAs are carried into the next tap's first blend (into the final three behind
+        // the loop); the first tap's "previous" B operand is zero.
         auto gather = [&](int s, unsigned (&d)[4][4]) {
             const int kg = s >> 1, m = s & 1;
 #pragma unroll
@@ -415,13 +442,38 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
         };
         unsigned vb[2][4][4];
         gather(0, vb[0]);
-        f16x8 w3f;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const int kg = s >> 1, m = s & 1;
+            const int pm = (s + 7) & 1;              // row of the previous step (step 7 of the previous tap for s = 0)
+            const int pkg = ((s + 7) & 7) >> 1;      // its k-group: weights still in wq[pkg & 1]
             if (s + 1 < 8) gather(s + 1, vb[(s + 1) & 1]);
+            f16x8 w3n;
+            if (m == 0) w3n = __builtin_bit_cast(f16x8, lds_read16(lds_r + w3a + (unsigned)(kg * 128)));
+            __builtin_amdgcn_sched_barrier(0);
+            f16x2_t a[4];
+            const unsigned (&d)[4][4] = vb[s & 1];
+            const unsigned wa = w01[m], wb = w23[m];
+            // ---- MFMA 0 of the previous step | blend ops 0..4
+            mma_kg(acc[pm][0], wq[pkg & 1][0], xf_prev);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = __builtin_bit_cast(f16x2_t, d[0][q]) * bcast_half<0>(wa);
+            a[0] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d[1][0]), bcast_half<1>(wa), a[0]);
+            PACK3_PIN(a);
+            // ---- MFMA 1 | blend ops 5..9
+            mma_kg(acc[pm][1], wq[pkg & 1][1], xf_prev);
+#pragma unroll
+            for (int q = 1; q < 4; ++q) a[q] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d[1][q]), bcast_half<1>(wa), a[q]);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) a[q] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d[2][q]), bcast_half<0>(wb), a[q]);
+            PACK3_PIN(a);
+            // ---- MFMA 2 | blend ops 10..15, then the weight fragments of the next k-group (behind the MFMAs that read wq[(kg+1)&1])
+            mma_kg(acc[pm][2], w3_prev, xf_prev);
+#pragma unroll
+            for (int q = 2; q < 4; ++q) a[q] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d[2][q]), bcast_half<0>(wb), a[q]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d[3][q]), bcast_half<1>(wb), a[q]);
             if (m == 0) {
-                w3f = __builtin_bit_cast(f16x8, lds_read16(lds_r + w3a + (unsigned)(kg * 128)));
                 if (kg + 1 < 4) {
 #pragma unroll
                     for (int n = 0; n < 2; ++n) wq[(kg + 1) & 1][n] = *reinterpret_cast<const f16x8 *>(wtap + ((kg + 1) * 2 + n) * 1024 + lane16);
@@ -429,19 +481,21 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
 #pragma unroll
                     for (int n = 0; n < 2; ++n) wq[0][n] = *reinterpret_cast<const f16x8 *>(wtap + C::DCN_TAP + n * 1024 + lane16);
                 }
+                w3_cur = w3n;
             }
-            unsigned xd[4];
-            blend_corners_cm<4>(vb[s & 1], w01[m], w23[m], xd);
-            const f16x8 xf = __builtin_bit_cast(f16x8, u32x4_t{xd[0], xd[1], xd[2], xd[3]});
-            mma_kg(acc[m][0], wq[kg & 1][0], xf);
-            mma_kg(acc[m][1], wq[kg & 1][1], xf);
-            mma_kg(acc[m][2], w3f, xf);
+            PACK3_PIN(a);
+            xf_prev = f16x8{a[0][0], a[0][1], a[1][0], a[1][1], a[2][0], a[2][1], a[3][0], a[3][1]};
+            w3_prev = w3_cur;
         }
 #if EMAVFI_DEFORM_STAMPS
         DEFORM_STAMP(ts_end);
         sum_steps += ts_end - ts_tap;
 #endif
     }
+    // the last step (k-group 3, row 1) of the last tap
+    mma_kg(acc[1][0], wq[1][0], xf_prev);
+    mma_kg(acc[1][1], wq[1][1], xf_prev);
+    mma_kg(acc[1][2], w3_prev, xf_prev);
 
     // ---- fix-up: the marked taps' samples that left the window, gathered from global memory with clamped corners and
     // validity-masked weights (the value deform_kernel computes); every other lane takes part with zero weights
