@@ -418,7 +418,10 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
     dtype = P.dtype;  // the kernel storage type from here on (EMAVFI_AMP16 -> EMAVFI_F16, with P.amp set)
     if (B < 1 || H < 1 || W < 1) return fail(EMAVFI_E_ARG, "forward: B, H, W must be >= 1 (got %d, %d, %d)", B, H, W);
     if ((size_t)B * H * W >= ((size_t)1 << 31)) return fail(EMAVFI_E_ARG, "forward: B*H*W must be < 2^31");
-    if ((size_t)H * W * P.fpad * P.esize >= ((size_t)1 << 32)) return fail(EMAVFI_E_ARG, "forward: one sample's activation plane must be < 4 GiB");
+    // the kernels' byte offsets inside one sample are 32-bit: guard with the WIDEST element any kernel of the plan reads
+    // (EMAVFI_AMP16 runs the fp32 deformable kernel on an fp32 fusion tensor: 4-byte elements beside P.esize = 2)
+    const size_t widest = P.amp ? sizeof(float) : (size_t)P.esize;
+    if ((size_t)H * W * P.fpad * widest >= ((size_t)1 << 32)) return fail(EMAVFI_E_ARG, "forward: one sample's activation plane must be < 4 GiB");
     if ((size_t)H * W >= ((size_t)1 << 24)) return fail(EMAVFI_E_ARG, "forward: H*W must be < 2^24 (24-bit pixel index arithmetic in the gather kernels)");
     Workspace ws{(char *)workspace, workspace_bytes, 0};
     FwdBuffers f;
