@@ -26,13 +26,23 @@
  *    every convolution with fp32-input MFMA (exact fp32 FMA chains; this is the
  *    parity mode, <= 1e-3 max-abs vs the reference's CPU forward);
  *    EMAVFI_BF16 stores activations and weights in bf16 and accumulates in
- *    fp32 (BASELINE.json configs[2]: "bf16 convs + fp32 warp"); its fused
- *    deformable kernel rounds the four bilinear corner weights to bf16 too.
+ *    fp32 (BASELINE.json configs[2]: "bf16 convs + fp32 warp").  One stage
+ *    leaves bf16: the one-launch ModulatedDeformConvPack kernel (mid_channels
+ *    64) works on the IEEE f16 image of its input window - bf16 values convert
+ *    exactly inside f16's normal range, keep 11 instead of 8 significant bits
+ *    through the bilinear blend, lose trailing bits below 6.1e-5 and SATURATE
+ *    at +-65504 (v_cvt_pkrtz; no infinities are produced) - contracts bf16-
+ *    rounded weights stored as f16, and hands the tensor between two
+ *    consecutive packs on as f16 bit patterns.  Activations beyond +-65504 in
+ *    the fusion stage are therefore clamped there, not propagated
+ *    (tests/test_gpu_parity.py::test_bf16_pack_saturates_at_the_f16_range).
  *    EMAVFI_F16 is the same data flow in IEEE half precision - the arithmetic
  *    torch.cuda.amp.autocast() gives the reference's convolutions on a GPU
  *    (inference.py:159); its fused deformable kernel blends the four corners
  *    in packed f16; values beyond +-65504 overflow to inf exactly as they
- *    would there.  Flow, warp coordinates,
+ *    would there.  A NaN / infinite flow (or one whose `2 * v` overflows)
+ *    warps to NaN in every channel, a finite flow far outside to 0 - what
+ *    the reference's CPU grid_sample returns (ema_vfi.py:169).  Flow, warp coordinates,
  *    deformable offsets / masks / sampling positions, the pooled context
  *    vector and the output are fp32 in every mode.
  *  - The model is identified by the reference constructor's three integers

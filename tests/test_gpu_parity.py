@@ -49,15 +49,26 @@ def test_warp_matches_oracle(B, C, H, W, sigma):
     assert (got - ref).abs().max().item() <= 5e-6 * max(1.0, ref.abs().max().item())
 
 
-def test_warp_far_and_nonfinite_flow_is_zero():
-    f2 = torch.randn(1, 3, 8, 8)
-    flow = torch.zeros(1, 2, 8, 8)
-    flow[0, 0, 4, 4], flow[0, 1, 5, 5] = 1e9, -300.0
-    flow[0, 0, 2, 2], flow[0, 1, 3, 3] = float("nan"), float("inf")
-    got = lib.warp(f2.to(DEV), flow.to(DEV)).cpu()
-    for y, x in ((4, 4), (5, 5), (2, 2), (3, 3)):
-        assert torch.all(got[0, :, y, x] == 0)
-    assert torch.allclose(got[0, :, 0, 0], f2[0, :, 0, 0], atol=1e-5)
+def test_warp_far_and_nonfinite_flow_matches_the_cpu_reference():
+    """ema_vfi.py:169 on the CPU forward (the oracle): a finite flow far outside samples zeros; a NaN / infinite flow - or one
+    so large that the reference's own `2.0 * vgrid` overflows - gives NaN in every channel (ATen's CPU grid_sample: the corner
+    weights are inf - inf there, and 0 * NaN = NaN).  The HIP kernels reproduce both, pixel for pixel, in the NCHW entry and
+    in the tiled kernel the forward uses."""
+    for H, W in ((8, 8), (40, 64)):          # 8x8: per-pixel kernel; 40x64 (W % 4 == 0): the tiled kernel
+        f2 = torch.randn(1, 3, H, W)
+        flow = torch.zeros(1, 2, H, W)
+        flow[0, 0, 4, 4], flow[0, 1, 5, 5] = 1e9, -300.0
+        flow[0, 0, 2, 2], flow[0, 1, 3, 3] = float("nan"), float("inf")
+        flow[0, 0, 6, 6], flow[0, 1, 1, 1] = 3e38, -float("inf")
+        got = lib.warp(f2.to(DEV), flow.to(DEV)).cpu()
+        ref = oracle.warp(f2, flow)
+        for y, x in ((4, 4), (5, 5)):
+            assert torch.all(ref[0, :, y, x] == 0) and torch.all(got[0, :, y, x] == 0)
+        for y, x in ((2, 2), (3, 3), (6, 6), (1, 1)):
+            assert torch.isnan(ref[0, :, y, x]).all() and torch.isnan(got[0, :, y, x]).all(), (H, W, y, x, got[0, :, y, x])
+        assert torch.equal(torch.isnan(got), torch.isnan(ref))
+        fin = ~torch.isnan(ref)
+        assert (got[fin] - ref[fin]).abs().max().item() <= 5e-6 * max(1.0, ref[fin].abs().max().item())
 
 
 def test_model_warp_method_signature():
@@ -139,6 +150,27 @@ def test_deform_bf16_is_deterministic_at_two_workgroups_per_cu():
     for r in runs:
         assert torch.equal(r, runs[0])
         assert (r - ref).abs().max().item() <= 0.05
+
+
+def test_bf16_pack_saturates_at_the_f16_range():
+    """include/emavfi.h: in bf16 mode the LDS-window deformable kernel (reference width) works on the f16 image of its input -
+    |x| > 65504 is CLAMPED to +-65504 (v_cvt_pkrtz saturates; nothing becomes inf), everything else is the bf16 value exactly.
+    Held against the oracle on the clamped, bf16-rounded input; the unclamped oracle differs by far more than the gate."""
+    g = torch.Generator().manual_seed(65504)
+    H, W = 12, 20
+    x = torch.randn(1, 67, H, W, generator=g) * 4e4                      # ~10 % of the values beyond the f16 range
+    off = torch.randn(1, 18, H, W, generator=g) * 1.5
+    msk = torch.rand(1, 9, H, W, generator=g)
+    w = torch.randn(67, 67, 3, 3, generator=g) / math.sqrt(67 * 9) * 1e-3
+    b = torch.randn(67, generator=g) * 0.1
+    assert (x.abs() > 65504).float().mean().item() > 0.05
+    got = lib.deform_conv2d(x.to(DEV), off.to(DEV), msk.to(DEV), w.to(DEV), b.to(DEV), dtype="bf16").cpu()
+    xb, wb = x.bfloat16().float(), w.bfloat16().float()
+    ref_clamped = oracle.deform_conv2d(xb.clamp(-65504.0, 65504.0), off, msk, wb, b)
+    ref_plain = oracle.deform_conv2d(xb, off, msk, wb, b)
+    assert torch.isfinite(got).all()
+    assert rel_err(got, ref_clamped) <= 2e-2
+    assert rel_err(ref_plain, ref_clamped) >= 5e-2                      # the clamp is what the kernel does, not a rounding detail
 
 
 def test_pack_module_matches_oracle_block():
@@ -238,8 +270,15 @@ def test_forward_ragged_sizes_mid64_both_dtypes(H, W):
         b = make_model(sd, dtype="bf16")(f1.to(DEV), f2.to(DEV)).cpu()
         c = make_model(sd, dtype="fp16")(f1.to(DEV), f2.to(DEV)).cpu()
     assert (a - ref).abs().max().item() <= 1e-3
-    assert torch.isfinite(b).all() and (b - ref).abs().max().item() <= 0.15
-    assert torch.isfinite(c).all() and (c - ref).abs().max().item() <= 0.03
+    # 16-bit gates derived from what these shapes measure (worst bf16 4.3e-3 / 60.5 dB, fp16 1.2e-3 / 74.7 dB over the five sizes,
+    # printed below): a factor ~4 of head room, not the 0.15 / 0.03 of round 2 that a 30x regression would have passed; PSNR
+    # on every shape >= 16 px
+    eb, ec = (b - ref).abs().max().item(), (c - ref).abs().max().item()
+    print(f"ragged {H}x{W}: bf16 max-abs {eb:.3e} PSNR {psnr(b, ref):.1f} dB; fp16 max-abs {ec:.3e} PSNR {psnr(c, ref):.1f} dB")
+    assert torch.isfinite(b).all() and eb <= 2e-2
+    assert torch.isfinite(c).all() and ec <= 5e-3
+    if H * W >= 16:
+        assert psnr(b, ref) >= 52.0 and psnr(c, ref) >= 66.0
 
 
 def test_forward_bf16_psnr():
@@ -613,15 +652,22 @@ def test_forward_fuzz_sizes_16bit_against_fp32_path():
     rnd = random.Random(20260101)
     sd = synth.synthetic_state_dict(seed=0)
     m32, mb, mh = make_model(sd, dtype="fp32"), make_model(sd, dtype="bf16"), make_model(sd, dtype="fp16")
-    worst = {"bf16": 0.0, "fp16": 0.0}
+    worst, low = {"bf16": 0.0, "fp16": 0.0}, {"bf16": (1e9,), "fp16": (1e9,)}
     for k in range(30):
         B, H, W = rnd.randint(1, 3), rnd.randint(1, 150), rnd.randint(1, 150)
         f1, f2 = synth.synthetic_frames(1000 + k, B, H, W, "natural" if k % 3 else "stress")
         with torch.no_grad():
             ref = m32(f1.to(DEV), f2.to(DEV))
-            for name, m, tol in (("bf16", mb, 0.2), ("fp16", mh, 0.04)):
+            for name, m, tol in (("bf16", mb, 4e-2), ("fp16", mh, 8e-3)):
                 out = m(f1.to(DEV), f2.to(DEV))
                 err = (out - ref).abs().max().item()
                 assert torch.isfinite(out).all() and err <= tol, (name, B, H, W, err)
+                if H * W >= 16:
+                    ps = psnr(out, ref)
+                    if ps < low[name][0]:
+                        low[name] = (ps, B, H, W, "natural" if k % 3 else "stress")
                 worst[name] = max(worst[name], err)
-    print("worst max-abs vs fp32 path:", worst)
+    print("worst max-abs vs fp32 path:", worst, "lowest PSNR:", low)
+    # measured (deterministic): worst max-abs 3.5e-2 / 6.1e-3 and lowest PSNR 45.0 / 61.2 dB, all on the i.i.d.-byte "stress" frames
+    # (natural frames stay below 1e-2 / 2e-3); round 2 allowed 0.2 / 0.04 and had no PSNR floor
+    assert low["bf16"][0] >= 43.0 and low["fp16"][0] >= 59.0, low

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void aggressor(float *sink, int rounds)
 __device__ __forceinline__ float mk(unsigned s) { return __uint_as_float(0x3f800000u | (s & 0x7fffffu)); }   // [1, 2)
 
 enum { OP_ADD_SWAP1, OP_MUL_SWAP1, OP_FMA_SWAP1, OP_ADD_SWAP0, OP_ADD_LO_CROSS1, OP_ADD_HI_CROSS1, OP_MUL_LO_CROSS0, OP_MUL_HI_BCAST0, OP_FMA_BCAST0, OP_ADD, OP_MUL, OP_FMA,
-       OP_FMA_F16_SWAP1, OP_COUNT };
+       OP_FMA_F16_SWAP1, OP_MUL_F16_BCAST0LO, OP_FMA_F16_BCAST1HI, OP_FMA_F16_BCAST1LO, OP_COUNT };
 static const char *kOp[] = {
     "v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0]          (src1 halves swapped)",
     "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0]          (src1 halves swapped)",
@@ -86,6 +86,10 @@ static const char *kOp[] = {
     "v_pk_mul_f32",
     "v_pk_fma_f32",
     "v_pk_fma_f16 op_sel:[0,1,0] op_sel_hi:[1,0,1]      (src1 halves swapped, f16)",
+    // the three forms deform_pack3.inl's blend emits (a corner weight broadcast to both channels of a dword)
+    "v_pk_mul_f16 op_sel_hi:[0,1]                       (src0.lo to both halves, f16)",
+    "v_pk_fma_f16 op_sel:[0,1,0]                        (src1.hi to both halves, f16)",
+    "v_pk_fma_f16 op_sel_hi:[1,0,1]                     (src1.lo to both halves, f16)",
 };
 
 // EXECMODE: 0 all lanes, 1 a fresh random wave-uniform mask per iteration (random bits, a random subset of the four 16-lane
@@ -131,6 +135,26 @@ __global__ __launch_bounds__(256) void victim(unsigned long long *bad, int iters
         else if (OP == OP_ADD) { PK2("v_pk_add_f32", ""); REF2("v_add_f32", e0, x0, y0); REF2("v_add_f32", e1, x1, y1); }
         else if (OP == OP_MUL) { PK2("v_pk_mul_f32", ""); REF2("v_mul_f32", e0, x0, y0); REF2("v_mul_f32", e1, x1, y1); }
         else if (OP == OP_FMA) { PK3("v_pk_fma_f32", ""); REF3(e0, x0, y0, z0); REF3(e1, x1, y1, z1); }
+        else if (OP == OP_MUL_F16_BCAST0LO || OP == OP_FMA_F16_BCAST1HI || OP == OP_FMA_F16_BCAST1LO) {
+            // f16 operands in [1, 2); expected values from the plain form on an explicitly splatted operand
+            unsigned xi = ((__float_as_uint(x0) >> 13) & 0x03ff03ffu) | 0x3c003c00u, yi = ((__float_as_uint(y0) >> 13) & 0x03ff03ffu) | 0x3c003c00u,
+                     zi = ((__float_as_uint(z0) >> 13) & 0x03ff03ffu) | 0x3c003c00u, ri, ei;
+            if (OP == OP_MUL_F16_BCAST0LO) {
+                const unsigned xs = (xi & 0xffffu) | (xi << 16);
+                asm volatile("v_pk_mul_f16 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(ri) : "v"(xi), "v"(yi));
+                asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(ei) : "v"(xs), "v"(yi));
+            } else if (OP == OP_FMA_F16_BCAST1HI) {
+                const unsigned ys = (yi >> 16) | (yi & 0xffff0000u);
+                asm volatile("v_pk_fma_f16 %0, %1, %2, %3 op_sel:[0,1,0]" : "=v"(ri) : "v"(xi), "v"(yi), "v"(zi));
+                asm volatile("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(ei) : "v"(xi), "v"(ys), "v"(zi));
+            } else {
+                const unsigned ys = (yi & 0xffffu) | (yi << 16);
+                asm volatile("v_pk_fma_f16 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(ri) : "v"(xi), "v"(yi), "v"(zi));
+                asm volatile("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(ei) : "v"(xi), "v"(ys), "v"(zi));
+            }
+            r[0] = __uint_as_float(ri & 0xffffu); e0 = __uint_as_float(ei & 0xffffu);
+            r[1] = __uint_as_float(ri >> 16); e1 = __uint_as_float(ei >> 16);
+        }
         else {   // the 16-bit packed fma the pack kernel's blend uses (regular VALU pipe): one dword = two halves
             unsigned xi = ((__float_as_uint(x0) >> 13) & 0x03ff03ffu) | 0x3c003c00u, yi = ((__float_as_uint(y0) >> 13) & 0x03ff03ffu) | 0x3c003c00u,
                      zi = ((__float_as_uint(z0) >> 13) & 0x03ff03ffu) | 0x3c003c00u, ri, ys = (yi >> 16) | (yi << 16), ei;
@@ -264,6 +288,9 @@ int main(int argc, char **)
         if (run_victim<OP_ADD_HI_CROSS1, 0>(aggr, c) || run_victim<OP_ADD_HI_CROSS1, 2>(aggr, c)) return 1;
         if (run_victim<OP_MUL_LO_CROSS0, 0>(aggr, c) || run_victim<OP_MUL_HI_BCAST0, 0>(aggr, c) || run_victim<OP_FMA_BCAST0, 0>(aggr, c)) return 1;
         if (run_victim<OP_FMA_F16_SWAP1, 0>(aggr, c) || run_victim<OP_FMA_F16_SWAP1, 2>(aggr, c)) return 1;
+        if (run_victim<OP_MUL_F16_BCAST0LO, 0>(aggr, c) || run_victim<OP_MUL_F16_BCAST0LO, 2>(aggr, c)) return 1;
+        if (run_victim<OP_FMA_F16_BCAST1HI, 0>(aggr, c) || run_victim<OP_FMA_F16_BCAST1HI, 2>(aggr, c)) return 1;
+        if (run_victim<OP_FMA_F16_BCAST1LO, 0>(aggr, c) || run_victim<OP_FMA_F16_BCAST1LO, 2>(aggr, c)) return 1;
         if (argc < 2) continue;
         if (run_victim<OP_ADD, 0>(aggr, c) || run_victim<OP_MUL, 0>(aggr, c) || run_victim<OP_FMA, 0>(aggr, c)) return 1;
         if (run_victim<OP_ADD, 1>(aggr, c) || run_victim<OP_MUL, 1>(aggr, c) || run_victim<OP_FMA, 1>(aggr, c)) return 1;

@@ -475,7 +475,11 @@ __device__ __forceinline__ WarpTap warp_tap(int x, int y, float fx, float fy, in
     const float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
     const float xw = floorf(ix), yn = floorf(iy);
     const float w = ix - xw, e = 1.0f - w, n = iy - yn, s = 1.0f - n;
-    // range tests in float: NaN / inf coordinates fail all of them -> 0
+    // range tests in float: a finite coordinate far outside fails all of them -> 0.  A NaN / infinite coordinate (NaN or
+    // infinite flow, or a flow so large that 2 * v overflows: same operation order as the reference, so the same cases)
+    // yields NaN in every channel, as ATen's CPU grid_sample does (its corner weights are NaN - NaN / inf - inf there and
+    // 0 * NaN = NaN): ema_vfi.py:169 on the CPU forward, which is the oracle this path is held to.
+    const bool bad = !(fabsf(ix) <= 3.402823466e38f) || !(fabsf(iy) <= 3.402823466e38f);
     const bool x0 = xw >= 0.0f && xw <= (float)(W - 1), x1 = xw + 1.0f >= 0.0f && xw + 1.0f <= (float)(W - 1);
     const bool y0 = yn >= 0.0f && yn <= (float)(H - 1), y1 = yn + 1.0f >= 0.0f && yn + 1.0f <= (float)(H - 1);
     const int xi = x0 ? (int)xw : (x1 ? (int)xw : 0), yi = y0 ? (int)yn : (y1 ? (int)yn : 0);
@@ -483,10 +487,11 @@ __device__ __forceinline__ WarpTap warp_tap(int x, int y, float fx, float fy, in
     WarpTap t;
     t.o00 = ya * W + xa; t.o01 = ya * W + xb; t.o10 = yb * W + xa; t.o11 = yb * W + xb;
     t.xa = xa; t.xb = xb; t.ya = ya; t.yb = yb;
-    t.nw = (y0 && x0) ? s * e : 0.0f;
-    t.ne = (y0 && x1) ? s * w : 0.0f;
-    t.sw = (y1 && x0) ? n * e : 0.0f;
-    t.se = (y1 && x1) ? n * w : 0.0f;
+    const float qnan = __builtin_nanf("");
+    t.nw = bad ? qnan : ((y0 && x0) ? s * e : 0.0f);
+    t.ne = bad ? qnan : ((y0 && x1) ? s * w : 0.0f);
+    t.sw = bad ? qnan : ((y1 && x0) ? n * e : 0.0f);
+    t.se = bad ? qnan : ((y1 && x1) ? n * w : 0.0f);
     return t;
 }
 __device__ __forceinline__ float warp_sample(const float *__restrict__ p, const WarpTap &t)
