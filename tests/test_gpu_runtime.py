@@ -183,6 +183,12 @@ for dt in ("fp32", "bf16"):
         out = model(f1[lo:hi].to(dev), f2[lo:hi].to(dev)).cpu().numpy()
     np.save(os.path.join(r"%(out)s", f"shard_{dt}_{rank}.npy"), out)
     np.save(os.path.join(r"%(out)s", f"range_{dt}_{rank}.npy"), np.array([lo, hi]))
+    if dt == "bf16":   # segment sharding of a frame STREAM (configs[4] logic): this rank's segment through the harness
+        from emavfi import FrameInterpolator
+        u8, _ = synth.synthetic_frames_u8(78, 1, %(h)d, %(w)d, "natural")
+        stream = [np.roll(u8[0], 5 * i, axis=1) for i in range(6)]
+        seg = list(FrameInterpolator(model, interpolation_factor=3, batch_pairs=2).run(stream, rank=rank, world=world))
+        np.save(os.path.join(r"%(out)s", f"stream_{rank}.npy"), np.stack(seg))
 vdist.barrier()
 torch.distributed.destroy_process_group()
 """
@@ -217,6 +223,14 @@ def test_two_rank_shards_equal_the_single_process_forward(tmp_path):
         assert ranges == [(0, 3), (3, 5)]
         got = np.concatenate([np.load(tmp_path / f"shard_{dt}_{r}.npy") for r in range(2)])
         assert got.shape == whole.shape and np.array_equal(got, whole), dt
+    # the frame stream: rank 0 took pairs 0..2 (frames 0..3), rank 1 pairs 3..4 (frames 3..5: the boundary frame is shared)
+    # and the final frame; concatenated, the two segments are the single-process stream frame for frame
+    from emavfi import FrameInterpolator
+    u8, _ = synth.synthetic_frames_u8(78, 1, h, w, "natural")
+    stream = [np.roll(u8[0], 5 * i, axis=1) for i in range(6)]
+    whole = np.stack(list(FrameInterpolator(make_model(sd, dtype="bf16"), interpolation_factor=3, batch_pairs=2).run(stream)))
+    parts = [np.load(tmp_path / f"stream_{r}.npy") for r in range(2)]
+    assert [len(x) for x in parts] == [12, 9] and np.array_equal(np.concatenate(parts), whole)
 
 
 def test_packed_blob_is_cached_on_disk_by_content(tmp_path, monkeypatch):

@@ -76,6 +76,67 @@ def test_schedule_matches_reference_loop_counts():
     assert FrameInterpolator.schedule(6, 2)[2] is False and FrameInterpolator.schedule(4, 3)[2] is True and FrameInterpolator.schedule(3, 3)[2] is False
 
 
+def test_segments_concatenate_to_the_single_process_stream():
+    """Segment sharding (one process per GPU, BASELINE configs[4]): for n = 0..9 frames, world = 1..4, interval 1..3 and
+    factor 0..3 the ranks' emission plans, concatenated in rank order, ARE the single-process plan; a rank reads a contiguous
+    frame range that covers its pairs, and with interval 1 its last frame is the next non-empty rank's first."""
+    for n in range(0, 10):
+        for interval in (1, 2, 3):
+            for factor in (0, 1, 3):
+                whole = FrameInterpolator.emission_plan(n, factor, interval)
+                pairs, last, _ = FrameInterpolator.schedule(n, interval)
+                assert len(whole) == (0 if last is None else len(pairs) * (factor + 1) + 1)
+                for world in (1, 2, 3, 4):
+                    cat, prev_hi, covered = [], None, []
+                    for rank in range(world):
+                        mine, lo, hi, tail = FrameInterpolator.segment(n, interval, rank, world)
+                        cat += FrameInterpolator.emission_plan(n, factor, interval, rank, world)
+                        covered += mine
+                        assert tail == (last is not None and rank == world - 1)
+                        assert all(lo <= f < hi for p in mine for f in p) and 0 <= lo <= hi <= max(n, 0)
+                        if mine:
+                            assert (lo, hi) == (mine[0][0], max(mine[-1][1], last if tail else 0) + 1)
+                            if interval == 1 and prev_hi is not None:
+                                assert lo == prev_hi - 1          # segment boundaries share exactly one frame
+                            prev_hi = mine[-1][1] + 1
+                    assert cat == whole, (n, interval, factor, world)
+                    assert covered == pairs
+
+
+@pytest.mark.gpu
+def test_sharded_runs_concatenate_bit_exactly():
+    """run(frames, rank, world) for every rank of a 3-way split, one after the other on one device: the concatenation is the
+    single-process output frame for frame (a pair's forward depends on its two frames only; batches are cut differently, and
+    the forward is batch-invariant bit for bit).  A lazy sequence is indexed inside the rank's segment only."""
+    sd = synth.synthetic_state_dict(seed=24, mid_channels=8)
+    base, _ = synth.synthetic_frames_u8(9, 1, 24, 32, "natural")
+    frames = [np.roll(base[0], 3 * i, axis=1) for i in range(8)]
+    model = EMA_VFI(mid_channels=8, compute_dtype="bf16").cuda().eval()
+    model.load_state_dict(sd)
+
+    class Lazy:
+        def __init__(self):
+            self.touched = set()
+        def __len__(self):
+            return len(frames)
+        def __getitem__(self, i):
+            self.touched.add(i)
+            return frames[i]
+
+    for factor, interval, mode in ((3, 1, "reference"), (1, 2, "reference"), (3, 1, "recursive")):
+        fi = FrameInterpolator(model, factor, interval, batch_pairs=2, mode=mode)
+        whole = list(fi.run(frames))
+        cat = []
+        for rank in range(3):
+            lazy = Lazy()
+            cat += list(fi.run(lazy, rank=rank, world=3))
+            _, lo, hi, _ = FrameInterpolator.segment(len(frames), interval, rank, 3)
+            assert lazy.touched <= set(range(lo, hi))
+        assert len(cat) == len(whole) == fi.count_outputs(len(frames))
+        for k, (a, b) in enumerate(zip(cat, whole)):
+            assert np.array_equal(a, b), (factor, interval, mode, k)
+
+
 @pytest.mark.gpu
 def test_preprocess_and_postprocess_bit_exact():
     g = np.random.default_rng(0)

@@ -86,6 +86,41 @@ class FrameInterpolator:
         pairs, last, _ = self.schedule(n_frames, self.interval)
         return 0 if last is None else len(pairs) * (self.factor + 1) + 1
 
+    # ---- segment sharding (BASELINE configs[4]): one process per GPU, each with a contiguous
+    # run of the stream's frame pairs.  No exchange between ranks: a pair's two frames are all a forward needs.
+    @staticmethod
+    def segment(n_frames: int, frame_interval: int, rank: int = 0, world: int = 1):
+        """Rank ``rank``'s share of a stream of ``n_frames`` frames: ``(pairs, lo, hi, tail)``.
+
+        ``pairs``: its contiguous slice of ``schedule()``'s pair list (sizes differ by at most one, earlier ranks take
+        the remainder: ``dist.shard_range``); ``[lo, hi)``: the frame indices it has to read - with ``frame_interval`` 1 its
+        last frame is the next rank's first (segment boundaries share one frame); ``tail``: it writes the stream's final
+        frame (the highest rank does, also when it owns no pair).  Concatenating the ranks' outputs in rank order gives
+        exactly the single-process sequence (``tests/test_stream.py``)."""
+        from .dist import shard_range
+        pairs, last, _ = FrameInterpolator.schedule(n_frames, frame_interval)
+        a, b = shard_range(len(pairs), rank, world)
+        mine = pairs[a:b]
+        tail = last is not None and rank == world - 1
+        need = [f for p in mine for f in p] + ([last] if tail else [])
+        return mine, (min(need) if need else 0), (max(need) + 1 if need else 0), tail
+
+    @staticmethod
+    def emission_plan(n_frames: int, interpolation_factor: int, frame_interval: int, rank: int = 0, world: int = 1,
+                      reference_quirks: bool = True):
+        """What ``run(frames, rank, world)`` yields, symbolically and in order: ("pred", i1, i2, j) - prediction j of the
+        pair (identical for every j in reference mode) -, ("src", i1) - the earlier frame of the pair, round-tripped when
+        ``reference_quirks`` -, ("tail", index, roundtrip).  Pure host logic (no device needed)."""
+        mine, _, _, tail = FrameInterpolator.segment(n_frames, frame_interval, rank, world)
+        _, last, last_roundtrip = FrameInterpolator.schedule(n_frames, frame_interval)
+        plan = []
+        for i1, i2 in mine:
+            plan += [("pred", i1, i2, j) for j in range(interpolation_factor)]
+            plan.append(("src", i1))
+        if tail:
+            plan.append(("tail", last, bool(last_roundtrip and reference_quirks)))
+        return plan
+
     # ---- buffers: two slots of pinned host memory the kernels read / write in place
     def _alloc(self, shape):
         if self._shape == shape:
@@ -152,16 +187,26 @@ class FrameInterpolator:
             levels = (self.factor + 1).bit_length() - 1
             return torch.stack(rec(x1, x2, levels), dim=1)
 
-    def run(self, frames: Iterable[np.ndarray]) -> Iterator[np.ndarray]:
-        """Yields uint8 HWC frames in the order the reference's writer receives them."""
-        frames = [np.ascontiguousarray(f) for f in frames]
-        for f in frames:
-            if f.dtype != np.uint8 or f.ndim != 3 or f.shape != frames[0].shape:
-                raise ValueError("FrameInterpolator.run: same-shape uint8 HWC frames expected")
-        pairs, last, last_roundtrip = self.schedule(len(frames), self.interval)
-        if last is None:
+    def run(self, frames, rank: int = 0, world: int = 1) -> Iterator[np.ndarray]:
+        """Yields uint8 HWC frames in the order the reference's writer receives them.
+
+        ``frames``: the whole stream - an iterable, or (sharded use) any object with ``len()`` and integer indexing, of which
+        only this rank's segment ``[lo, hi)`` (``segment()``) is touched, e.g. a lazy video reader.  ``rank`` / ``world``:
+        this process's share (one process per GPU); the default is the whole stream."""
+        if not (hasattr(frames, "__len__") and hasattr(frames, "__getitem__")):
+            frames = list(frames)
+        n_total = len(frames)
+        mine, lo, hi, tail = self.segment(n_total, self.interval, rank, world)
+        pairs, last, last_roundtrip = self.schedule(n_total, self.interval)
+        if last is None or (not mine and not tail):
             return
-        self._alloc(frames[0].shape)
+        pairs = mine
+        frames = {i: np.ascontiguousarray(frames[i]) for i in range(lo, hi)}   # this rank's segment only
+        first = frames[lo]
+        for f in frames.values():
+            if f.dtype != np.uint8 or f.ndim != 3 or f.shape != first.shape:
+                raise ValueError("FrameInterpolator.run: same-shape uint8 HWC frames expected")
+        self._alloc(first.shape)
         main = torch.cuda.current_stream(self.device)
         chunks = [pairs[i:i + self.batch_pairs] for i in range(0, len(pairs), self.batch_pairs)]
         npred = self.factor if self.mode == "recursive" else 1
@@ -200,6 +245,8 @@ class FrameInterpolator:
             prev = (slot, chunk)
         if prev is not None:
             yield from drain(*prev)
+        if not tail:                         # the stream's final frame belongs to the highest rank
+            return
         if last_roundtrip and self.quirks:   # skip-branch ending: the reference writes the round-tripped frame
             src = torch.from_numpy(frames[last]).unsqueeze(0).to(self.device)
             yield _lib.postprocess_u8(_lib.preprocess_u8(src), denormalize=True).cpu().numpy()[0]
