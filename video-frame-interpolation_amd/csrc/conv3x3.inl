@@ -487,6 +487,27 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_persist_kernel(const ConvP
 // (PackDesc::mfma16).  fp32 accumulation order inside a tap differs from the 32x32x16 kernels (32 channels per MFMA instead
 // of 16), so results agree with them to fp32 rounding, not bit for bit.
 // ------------------------------------------------------------------------------------------
+// Slot permutation of the unpadded 128-byte tile pixels of the two 16x16x32 kernels: the 16-byte piece c of tile pixel q is stored
+// in slot c ^ swz16(q).  A ds_read_b128 is serviced in the lane groups {0-3,12-15,20-27} {4-11,16-19,28-31} (+32), i.e. a group
+// mixes EIGHT pixels that read piece kb with EIGHT that read piece kb ^ 1 (the B-operand layout puts k-block kb = lane >> 4 on
+// 16 lanes).  Round 2's permutation c ^ ((q >> 1) & 7) touches bit 0 of c, so for half of the tile alignments (odd q >> 1 at the
+// group's first pixel: every tap with dx = 1 and every odd tile row) two lane pairs of a group met in one bank quad: exactly the
+// 25.0 % SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE the round-2 counters showed.  This one only permutes bits
+// 1-2 of the piece index: bit 0 keeps the two halves of a group apart, and the eight pixels of a half have eight different
+// (q & 1, (q >> 1) & 3) = (bank-row half, permutation) pairs for EVERY alignment.  +16 pixels keeps the permutation; the second
+// 32-channel step still flips bit 2 of the piece = byte 64 of the address.
+#ifndef EMAVFI_CONV_SWZ_NEW
+#define EMAVFI_CONV_SWZ_NEW 1
+#endif
+#ifndef EMAVFI_CONV_FASTDMA
+#define EMAVFI_CONV_FASTDMA 1
+#endif
+#ifndef EMAVFI_CONV_PKRELU
+#define EMAVFI_CONV_PKRELU 0   // ReLU as v_pk_max_i16 on the rounded pairs: half the instructions, and measured SLOWER (64 -> 64: 570 vs 532 us,
+#endif                         // same box): VOP3P instructions beside the other group's MFMAs cost more than two plain v_max_f32
+
+__device__ __forceinline__ int swz16(int q) { return EMAVFI_CONV_SWZ_NEW ? ((q >> 1) & 3) << 1 : (q >> 1) & 7; }
+
 // NF = 32-channel fragments the layer is packed for (2 NF blocks of 16 in the packed weights); NB = blocks of 16 output channels
 // the kernel computes: 2 NF, or 1 for the planar heads (flow: 2 channels), which then do half the MFMAs of a 32-wide fragment.
 template <typename T, int CK, int NF, int NB> struct ConvP16Cfg {
@@ -537,7 +558,7 @@ __global__ __launch_bounds__(512) void conv3x3_persist16_kernel(const ConvParams
             const int jn = i * C::WAVES + wave;
             if (jn < C::NINST) {
                 const int sl = jn * 64 + lane;
-                const int pix = sl >> 3, pc = (sl & 7) ^ ((pix >> 1) & 7);   // slot -> the piece stored there
+                const int pix = sl >> 3, pc = (sl & 7) ^ swz16(pix);   // slot -> the piece stored there
                 const int ly = pix / IW, lx = pix - ly * IW;
                 const int gy = iy0 + ly, gx = ix0 + lx;
                 const char *src = conv_dma_src(gin, zeros, gy, gx, pc, p.Hin, p.Win, pixbytes, sl < C::NSLOT && pc < npieces);
@@ -571,7 +592,7 @@ __global__ __launch_bounds__(512) void conv3x3_persist16_kernel(const ConvParams
 #pragma unroll
                 for (int m = 0; m < MF; ++m) {   // see conv3x3_pingpong16_kernel: +16 pixels keeps the slot permutation, k32 flips byte 64
                     const int q = ((wave * MF + m) + dy) * IW + j + dx;
-                    const int off = (q * PSTR + ((kb ^ ((q >> 1) & 7)) << 4)) ^ (k32 * 64);
+                    const int off = (q * PSTR + ((kb ^ swz16(q)) << 4)) ^ (k32 * 64);
                     xd[2 * m] = *reinterpret_cast<const vec *>(lds_in + off);
                     xd[2 * m + 1] = *reinterpret_cast<const vec *>(lds_in + off + 2048);
                 }
@@ -690,17 +711,40 @@ __global__ __launch_bounds__(512) void conv3x3_pingpong16_kernel(const ConvParam
     const int rounds = ((int)blockIdx.x * 2 < ntiles) ? (ntiles - (int)blockIdx.x * 2 + stride - 1) / stride : 0;
     const int coutpad = NF * 32;
 
+    // A DMA instruction's lanes -> (tile pixel, piece) never change, so for a tile that lies inside the image with its halo
+    // (all but the border tiles) the source is  tile origin (wave-uniform) + a per-lane byte offset computed ONCE per kernel:
+    // no address arithmetic at all beside the other group's MFMAs (the staging wave shares its SIMD's issue port with a
+    // contracting wave: every VALU instruction here delays an MFMA there; the generic path costs ~15 per DMA instruction).
+    constexpr int NDMA = (NINST + GW - 1) / GW;
+    unsigned dma_off[NDMA];
+    const bool fast_ok = EMAVFI_CONV_FASTDMA && npieces >= 8;
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+        const int jn = i * GW + wq, sl = jn * 64 + lane;
+        const int pix = sl >> 3, pc = (sl & 7) ^ swz16(pix);
+        const int ly = pix / IW, lx = pix - ly * IW;
+        dma_off[i] = sl < NSLOT ? (unsigned)(ly * p.Win + lx) * pixbytes + (unsigned)pc * 16u : 0u;   // (slots past the tile: any valid address)
+    }
     auto stage = [&](int tile) {
         const int b = tile / (ntx * nty), trem = tile - b * (ntx * nty);
         const int ty = trem / ntx, tx = trem - ty * ntx;
         const int iy0 = ty * TH - 1, ix0 = tx * 32 - 1;
         const char *gin = (const char *)p.in + (size_t)b * p.Hin * p.Win * p.in_ps * sizeof(T);
+        if (fast_ok && iy0 >= 0 && ix0 >= 0 && iy0 + IH <= p.Hin && ix0 + IW <= p.Win) {   // wave-uniform
+            const char *origin = gin + ((size_t)iy0 * p.Win + ix0) * pixbytes;
 #pragma unroll
-        for (int i = 0; i < (NINST + GW - 1) / GW; ++i) {
+            for (int i = 0; i < NDMA; ++i) {
+                const int jn = i * GW + wq;
+                if (jn < NINST) __builtin_amdgcn_global_load_lds((gptr_t *)(origin + dma_off[i]), (lptr_t *)(lds_in + jn * 1024), 16, 0, 0);
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
             const int jn = i * GW + wq;
             if (jn < NINST) {
                 const int sl = jn * 64 + lane;
-                const int pix = sl >> 3, pc = (sl & 7) ^ ((pix >> 1) & 7);
+                const int pix = sl >> 3, pc = (sl & 7) ^ swz16(pix);
                 const int ly = pix / IW, lx = pix - ly * IW;
                 const int gy = iy0 + ly, gx = ix0 + lx;
                 const char *src = conv_dma_src(gin, zeros, gy, gx, pc, p.Hin, p.Win, pixbytes, sl < NSLOT && pc < npieces);
@@ -736,7 +780,7 @@ __global__ __launch_bounds__(512) void conv3x3_pingpong16_kernel(const ConvParam
 #pragma unroll
             for (int m = 0; m < MF; ++m) {
                 const int q = ((wq * MF + m) + dy) * IW + j + dx;
-                const int off = (q * PSTR + ((kb ^ ((q >> 1) & 7)) << 4)) ^ (k32 * 64);   // bit 6 lies inside the 128-byte pixel
+                const int off = (q * PSTR + ((kb ^ swz16(q)) << 4)) ^ (k32 * 64);   // bit 6 lies inside the 128-byte pixel
                 xd[2 * m] = *reinterpret_cast<const vec *>(lds_in + off);
                 xd[2 * m + 1] = *reinterpret_cast<const vec *>(lds_in + off + 2048);
             }
@@ -769,7 +813,10 @@ __global__ __launch_bounds__(512) void conv3x3_pingpong16_kernel(const ConvParam
         const int b = tile / (ntx * nty), trem = tile - b * (ntx * nty);
         const int ty = trem / ntx, tx = trem - ty * ntx;
         typedef __attribute__((ext_vector_type(2))) T pair_t;
+        typedef __attribute__((ext_vector_type(2))) short s16x2_t;
         const bool relu = p.epi == EPI_RELU;
+        // (EMAVFI_CONV_PKRELU = 1, an experiment that lost: ReLU on the ROUNDED pair as a packed signed-16-bit max with 0)
+        const s16x2_t floor16 = (relu && EMAVFI_CONV_PKRELU) ? s16x2_t{0, 0} : s16x2_t{(short)-32768, (short)-32768};
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) {
             const int y = ty * TH + wq * MF + (pb >> 1), x = tx * 32 + (pb & 1) * 16 + j;
@@ -781,9 +828,11 @@ __global__ __launch_bounds__(512) void conv3x3_pingpong16_kernel(const ConvParam
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     float v0 = acc[pb][2 * t][2 * i], v1 = acc[pb][2 * t][2 * i + 1], u0 = acc[pb][2 * t + 1][2 * i], u1 = acc[pb][2 * t + 1][2 * i + 1];
-                    if (relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); u0 = fmaxf(u0, 0.0f); u1 = fmaxf(u1, 0.0f); }
+                    if (relu && !EMAVFI_CONV_PKRELU) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); u0 = fmaxf(u0, 0.0f); u1 = fmaxf(u1, 0.0f); }
                     const pair_t pa = {(T)v0, (T)v1}, pc2 = {(T)u0, (T)u1};
-                    const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, pa), __builtin_bit_cast(unsigned, pc2), false, false);
+                    const s16x2_t ra = __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, pa), floor16);
+                    const s16x2_t rc = __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, pc2), floor16);
+                    const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, ra), __builtin_bit_cast(unsigned, rc), false, false);
                     a[i] = sw[0];
                     c2[i] = sw[1];
                 }
