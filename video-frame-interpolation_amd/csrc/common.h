@@ -197,7 +197,8 @@ struct DeformParams {
     int cin_real;  // real (unpadded) input channels
     int cout_real; // real output channels (0 = unknown: nf * 32)
     int ck, nf;    // host-side template selectors
-    int pack3;     // weights are in the deform_pack3.inl layout (K = 64 per tap + im2col tail, third fragment as an LDS table)
+    int pack3;     // weights are in the deform_pack3.inl layout (K = 64 per tap + im2col tail, third fragment as an LDS table);
+                   // 3: fp32, the deform_f32w.inl layout
     int in_f16, out_f16;  // bf16 storage only: x (and x_tail) / out hold IEEE f16 bit patterns (tensors handed between consecutive packs)
     unsigned long long *stamps;  // diagnostic build (-DEMAVFI_DEFORM_STAMPS=1) only, else null
 };
@@ -223,5 +224,13 @@ int launch_deform_f16(const DeformParams &p, hipStream_t s);
 static inline bool deform_pack3_shape(int ck, int nf, int cin_real, int cout_real)
 {
     return EMAVFI_PACK3 && ck == 80 && nf == 3 && cin_real > 64 && cin_real <= 67 && cout_real > 64 && cout_real <= 67;
+}
+// shape served by deform_f32w_kernel (fp32, LDS window): the reference width, input channels in (64, 72], outputs <= 80
+#ifndef EMAVFI_F32W
+#define EMAVFI_F32W 1   // 0: deform_kernel<float, 80, 3> (global gathers, 32x32x2 MFMAs) and its weight layout (A/B builds)
+#endif
+static inline bool deform_f32w_shape(int ck, int nf, int cin_real, int cout_real)
+{
+    return EMAVFI_F32W && ck == 80 && nf == 3 && cin_real > 64 && cin_real <= 72 && cout_real > 64 && cout_real <= 80;
 }
 bool deform16_can_fuse_offset_conv(int ck, int nf, int cin_real, int off_ck, int off_nf);

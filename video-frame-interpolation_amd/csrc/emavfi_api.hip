@@ -220,6 +220,12 @@ bool build_plan(Plan &P, int in_ch, int mid, int nb, int dtype)
         }
         if (!ok) { P.why = "no fp32 deformable-conv instantiation for these channel widths"; return false; }
     }
+    if (ok && dtype == EMAVFI_F32)
+        for (int i = 0; i < nb; ++i)
+            if (deform_f32w_shape(P.dcn[i].ck, P.dcn[i].nf, P.dcn[i].cin_take, P.dcn[i].cout)) P.dcn[i].pack3 = 3;
+    if (ok && P.amp)
+        for (int i = 0; i < nb; ++i)
+            if (deform_f32w_shape(P.dcn32[i].ck, P.dcn32[i].nf, P.dcn32[i].cin_take, P.dcn32[i].cout)) P.dcn32[i].pack3 = 3;
     P.has_offh = false;
     const bool p3 = ok && !P.amp && dtype != EMAVFI_F32 && nb > 0 && deform_pack3_shape(P.dcn[0].ck, P.dcn[0].nf, P.dcn[0].cin_take, P.dcn[0].cout) &&
                     P.off[0].nchunk == 1 && P.off[0].npass == 1 && P.off[0].ck == 80 && P.off[0].nf == 1;
@@ -877,6 +883,7 @@ int emavfi_deform_conv2d(const float *x, const float *offset, const float *mask,
     // the 16-bit LDS-window kernel contracts in f16 on chip: a bf16 call packs its bf16-rounded weights as f16 fragments
     const bool h_of_b = dtype == EMAVFI_BF16 && deform16_lds_shape_host(L.ck, L.nf, L.cin_take);
     if (dtype != EMAVFI_F32 && deform_pack3_shape(L.ck, L.nf, L.cin_take, L.cout)) L.pack3 = 1;
+    if (dtype == EMAVFI_F32 && deform_f32w_shape(L.ck, L.nf, L.cin_take, L.cout)) L.pack3 = 3;
     PackDesc d{L.cout, L.cin_raw, 0, L.cin_take, L.ck, 1, L.nf, 1, 0, h_of_b ? 1 : 0};
     d.pack3 = L.pack3;
     if (hipMemsetAsync(zpage, 0, 256, s) != hipSuccess) return fail(EMAVFI_E_LAUNCH, "deform_conv2d: zero page memset failed");

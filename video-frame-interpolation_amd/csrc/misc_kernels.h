@@ -12,7 +12,8 @@ struct PackDesc {
                                            // (f16 fragments holding the bf16 model's weights exactly: deform_pack.inl)
     int bias_f16;                          // 1 = the fp32 bias table holds fp16-rounded values (autocast casts the bias too)
     int mfma16;                            // 1 = fragments for v_mfma_f32_16x16x32: [tap][k32][cout16 block][lane (i, kb)][8 elements]
-    int pack3;                             // deform_pack3.inl layouts (f16 elements, cin_take = 67): 1 = DCN 67 -> <= 67, 2 = offset_conv 67 -> 27
+    int pack3;                             // deform_pack3.inl layouts (f16 elements, cin_take = 67): 1 = DCN 67 -> <= 67, 2 = offset_conv 67 -> 27;
+                                           // 3 = deform_f32w.inl (fp32 elements, the fp32 DCN on an LDS window)
 };
 
 int launch_pack_conv(const float *w, const float *bias, void *wp, float *bp, const PackDesc &d, int dtype, hipStream_t s);

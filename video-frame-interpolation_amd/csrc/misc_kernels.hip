@@ -137,8 +137,35 @@ __global__ void pack_deform3_kernel(const float *__restrict__ w, const float *__
     }
 }
 
+// deform_f32w.inl layout (fp32, 67 -> <= 80 channels): [tap][half 2][cout block 5]{ group 0: [lane][4] | group 1: [lane][4] |
+// leftover: [lane][1] }; lane (i = lane & 15, kb = lane >> 4) of a group holds W[16 c + i][36 half + 16 G + 4 kb + t] for the
+// group's four MFMA steps t = 0..3 (step t contracts the channel set {16 G + 4 kb' + t}: the order in which a lane's 16-byte
+// gather piece feeds the steps), the leftover step W[16 c + i][36 half + 32 + kb].
+__global__ void pack_deform_f32w_kernel(const float *__restrict__ w, const float *__restrict__ bias, float *__restrict__ wp,
+                                        float *__restrict__ bp, PackDesc d)
+{
+    constexpr int CB = 64 * 4 * 2 + 64, HALF = 5 * CB, TAP = 2 * HALF;   // floats
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < 9 * TAP; idx += gridDim.x * blockDim.x) {
+        int t = idx;
+        const int tap = t / TAP; t -= tap * TAP;
+        const int half = t / HALF; t -= half * HALF;
+        const int c = t / CB; t -= c * CB;
+        int lane, ci;
+        if (t < 512) { const int G = t / 256, r = t - G * 256; lane = r >> 2; ci = 36 * half + 16 * G + 4 * (lane >> 4) + (r & 3); }
+        else { lane = t - 512; ci = 36 * half + 32 + (lane >> 4); }
+        const int co = 16 * c + (lane & 15);
+        wp[idx] = (co < d.cout && ci < d.cin_take) ? w[((size_t)co * d.cin_raw + d.cin_off + ci) * 9 + tap] : 0.0f;
+    }
+    const int coutpad = d.npass * d.nf * 32;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < coutpad; i += gridDim.x * blockDim.x) bp[i] = (i < d.cout && bias) ? bias[i] : 0.0f;
+}
+
 int launch_pack_conv(const float *w, const float *bias, void *wp, float *bp, const PackDesc &d, int dtype, hipStream_t s)
 {
+    if (d.pack3 == 3) {
+        pack_deform_f32w_kernel<<<64, 256, 0, s>>>(w, bias, (float *)wp, bp, d);
+        return (int)hipGetLastError();
+    }
     if (d.pack3) {
         pack_deform3_kernel<<<64, 256, 0, s>>>(w, bias, (half_t *)wp, bp, d);
         return (int)hipGetLastError();
