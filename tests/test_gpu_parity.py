@@ -577,6 +577,28 @@ def test_fused_tail_equals_two_launches(dtype, shape, monkeypatch):
     assert torch.equal(one, two), f"{int((one != two).sum())} of {one.numel()} elements differ, max {(one - two).abs().max().item():.3e}"
 
 
+def test_fused_first_layer_equals_pack_input_plus_conv(monkeypatch):
+    """16-bit modes at mid_channels 64 compute cat(frame1, frame2) + feat_ext_conv1 + ReLU in ONE launch straight from the NCHW
+    fp32 frames (csrc/conv_first.inl); EMAVFI_CONV_FIRST=0 runs pack_input + conv3x3.  Same rounded inputs, weights and products;
+    the fp32 accumulation groups two taps per MFMA instead of one, so conv1's stored output may differ by one unit in the last place
+    of the storage type in a few elements; three more layers later (the `feat` tap) and at the frame the two paths must still
+    agree to a few such units.  Ragged size on purpose (tile remainders)."""
+    sd = synth.synthetic_state_dict(seed=0)
+    f1, f2 = (t.to(DEV) for t in synth.synthetic_frames(41, 2, 45, 77, "natural"))
+    for dt, step, tol in (("bf16", 2.0 ** -7, 1.5e-2), ("fp16", 2.0 ** -10, 3e-3)):
+        feats, outs = [], []
+        for flag in ("1", "0"):
+            monkeypatch.setenv("EMAVFI_CONV_FIRST", flag)
+            m = make_model(sd, dtype=dt)
+            with torch.no_grad():
+                out, taps = m(f1, f2, return_taps=True)
+            feats.append(taps["feat"].clone()); outs.append(out.clone())
+        rel = ((feats[0] - feats[1]).abs() / feats[1].abs().clamp_min(1.0)).max().item()
+        frac = (feats[0] != feats[1]).float().mean().item()
+        print(f"{dt}: feat max rel diff {rel:.3e} ({100 * frac:.2f} % of the elements differ), frame max-abs {(outs[0] - outs[1]).abs().max().item():.3e}")
+        assert rel <= 8 * step and (outs[0] - outs[1]).abs().max().item() <= tol
+
+
 def test_fused_pack_equals_the_two_launch_path(tmp_path):
     """bf16 / fp16 at the reference width run offset_conv inside the deform kernel (one launch per
     ModulatedDeformConvPack, csrc/deform_pack.inl); EMAVFI_NO_FUSED_OFFSET=1 runs conv3x3(EPI_OM) + the deform kernel

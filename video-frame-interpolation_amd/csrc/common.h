@@ -208,6 +208,10 @@ struct DeformParams {
 // compute units of the CURRENT device (persistent kernels size their grid by it); cached per device, thread-safe
 int device_cu_count();
 
+// feat_ext_conv1 fused with cat(frame1, frame2) (conv_first.inl; 16-bit types, mid_channels 64)
+struct FirstParams;
+int launch_conv_first_bf16(const FirstParams &p, hipStream_t s);
+int launch_conv_first_f16(const FirstParams &p, hipStream_t s);
 int launch_conv3x3_f32(const ConvParams &p, hipStream_t s);
 int launch_conv3x3_bf16(const ConvParams &p, hipStream_t s);
 int launch_conv3x3_f16(const ConvParams &p, hipStream_t s);

@@ -1,4 +1,5 @@
 #include "conv3x3.inl"
+#include "conv_first.inl"
 #include <cstdlib>
 int launch_conv3x3_bf16(const ConvParams &p, hipStream_t s)
 {
@@ -16,3 +17,5 @@ extern "C" int emavfi_debug_conv_stamps(unsigned long long *out, int reset)
     return 0;
 }
 #endif
+
+int launch_conv_first_bf16(const FirstParams &p, hipStream_t s) { return launch_conv_first_t<bf16_t>(p, s); }

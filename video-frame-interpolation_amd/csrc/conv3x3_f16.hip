@@ -1,4 +1,5 @@
 #include "conv3x3.inl"
+#include "conv_first.inl"
 #include <cstdlib>
 int launch_conv3x3_f16(const ConvParams &p, hipStream_t s)
 {
@@ -6,3 +7,5 @@ int launch_conv3x3_f16(const ConvParams &p, hipStream_t s)
     return launch_conv16<half_t>(p, s, off);
 }
 int launch_conv_tail_f16(const TailParams &p, hipStream_t s) { return launch_conv_tail<half_t>(p, s); }
+
+int launch_conv_first_f16(const FirstParams &p, hipStream_t s) { return launch_conv_first_t<half_t>(p, s); }

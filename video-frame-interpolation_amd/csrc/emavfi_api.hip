@@ -4,6 +4,7 @@
 #include "../../include/emavfi.h"
 #include "common.h"
 #include "misc_kernels.h"
+#include "conv_first.inl"
 
 #include <cstdarg>
 #include <cstdlib>
@@ -56,6 +57,7 @@ struct Layer {
     bool f16_of_bf16 = false;  // bf16 model, layer consumed by deform_pack_kernel: bf16-rounded weights stored as f16
     bool mfma16 = false;       // packed for and run by conv3x3_persist16_kernel (v_mfma_f32_16x16x32): 16-bit full-resolution 64 -> (1..64) layers
     int pack3 = 0;             // deform_pack3.inl layouts: 1 = DCN, 2 = offset_conv (f16 elements)
+    bool first6 = false;       // feat_ext_conv1 at mid_channels 64, 16-bit: a second copy of the weights in conv_first.inl's layout (10 KiB)
 };
 
 bool conv_geometry(Layer &L, int esize)
@@ -200,7 +202,14 @@ bool build_plan(Plan &P, int in_ch, int mid, int nb, int dtype)
         L.b_off = o; o = rup256(o + (size_t)L.coutpad * sizeof(float));
         return true;
     };
-    bool ok = place(P.conv1, false);
+    // 16-bit, 6 -> 64: the fused cat + conv kernel (conv_first.inl) reads its own 10 KiB fragment copy behind the regular one
+    // (the blob always carries both layouts: EMAVFI_CONV_FIRST=0, read per forward, runs pack_input + conv3x3<16,2,1> - A/B, parity test)
+    bool ok = conv_geometry(P.conv1, P.esize);
+    if (ok) {
+        P.conv1.first6 = P.esize == 2 && P.conv1.cout == 64 && P.conv1.cin_take == 6;
+        P.conv1.w_off = o; o = rup256(o + P.conv1.w_bytes + (P.conv1.first6 ? 10240 : 0));
+        P.conv1.b_off = o; o = rup256(o + (size_t)P.conv1.coutpad * sizeof(float));
+    }
     for (int i = 0; i < nb && ok; ++i) ok = place(P.blk[i], false);
     ok = ok && place(P.c0, false) && place(P.c1, false) && place(P.c2, false);
     ok = ok && place(P.m0, false) && place(P.m1, false) && place(P.m2, false);
@@ -318,6 +327,7 @@ int pack_layer(const Layer &L, const void *const *params, void *packed, int dtyp
 {
     PackDesc d{L.cout, L.cin_raw, L.cin_off, L.cin_take, L.ck, L.nchunk, L.nf, L.npass, L.perm, L.f16_of_bf16 ? 1 : 0, bias_f16 ? 1 : 0};
     d.mfma16 = L.mfma16 ? 1 : 0;
+    d.first6 = L.first6 ? 1 : 0;
     d.pack3 = L.pack3;
     return launch_pack_conv((const float *)params[L.param], (const float *)params[L.param + 1], (char *)packed + L.w_off,
                             (float *)((char *)packed + L.b_off), d, L.f16_of_bf16 ? (int)EMAVFI_F16 : dtype, s);
@@ -445,10 +455,21 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
     double fl, by;
 
     // --- feature extraction: cat + conv + ReLU, then num_blocks x (conv + ReLU)  (ema_vfi.py:112-116)
-    EMAVFI_STEP(rec, "pack_input", 0, px * (8.0 * C + 2.0 * C * e), launch_pack_input(frame1, frame2, f.in16, B, C, H, W, 16, dtype, s));
     conv_work(P, P.conv1, B, H, W, e, fl, by);
-    EMAVFI_STEP(rec, conv_name(P, P.conv1) + " feat_ext_conv1", fl, by,
-                run_conv(P, P.conv1, packed, f.in16, 16, H, W, f.fA, P.p_mid, 0, P.p_mid, EPI_RELU, B, s));
+    {
+        const char *cf = getenv("EMAVFI_CONV_FIRST");   // read per call: the parity test flips it inside one process (the blob carries both layouts)
+        if (P.conv1.first6 && !(cf && cf[0] == '0')) {
+            // cat(frame1, frame2) + conv + ReLU in one launch, straight from the NCHW fp32 frames (ema_vfi.py:112-113)
+            FirstParams fp{frame1, frame2, f.fA, (const char *)packed + P.conv1.w_off + P.conv1.w_bytes,
+                           (const float *)((const char *)packed + P.conv1.b_off), P.p_mid, H, W, B, 1};
+            EMAVFI_STEP(rec, std::string("conv_first<") + dtype_name(dtype) + ",6->64> cat+feat_ext_conv1", fl, px * (8.0 * C + mid * e) + 9.0 * 2 * C * mid * e,
+                        dtype == EMAVFI_F16 ? launch_conv_first_f16(fp, s) : launch_conv_first_bf16(fp, s));
+        } else {
+            EMAVFI_STEP(rec, "pack_input", 0, px * (8.0 * C + 2.0 * C * e), launch_pack_input(frame1, frame2, f.in16, B, C, H, W, 16, dtype, s));
+            EMAVFI_STEP(rec, conv_name(P, P.conv1) + " feat_ext_conv1", fl, by,
+                        run_conv(P, P.conv1, packed, f.in16, 16, H, W, f.fA, P.p_mid, 0, P.p_mid, EPI_RELU, B, s));
+        }
+    }
     void *cur = f.fA, *nxt = f.fB;
     for (int i = 0; i < P.nb; ++i) {
         const bool last = i == P.nb - 1;  // the last block writes feat straight into the fusion buffer

@@ -66,6 +66,19 @@ __global__ void pack_conv_kernel(const float *__restrict__ w, const float *__res
         if (d.via_bf16) v = (float)(bf16_t)v;
         wp[idx] = (T)v;
     }
+    if (d.first6 && EPV == 8) {   // a second copy behind the regular fragments: conv_first.inl's ten tap slots of 8
+        for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (size_t)5 * 2 * 64 * 8; idx += (size_t)gridDim.x * blockDim.x) {
+            size_t t = idx;
+            const int e = t % 8; t /= 8;
+            const int lane = t % 64; t /= 64;
+            const int n = t % 2; t /= 2;
+            const int kg = (int)t;
+            const int tap = 2 * kg + (lane >> 5), co = n * 32 + (lane & 31);
+            float v = 0.0f;
+            if (tap < 9 && e < d.cin_take && co < d.cout) v = w[((size_t)co * d.cin_raw + d.cin_off + e) * 9 + tap];
+            wp[total + idx] = (T)v;
+        }
+    }
     const int coutpad = d.npass * d.nf * 32;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < coutpad; i += gridDim.x * blockDim.x) {
         const int co = route_cout(i, d.perm);
