@@ -66,6 +66,9 @@ __device__ __forceinline__ const char *conv_dma_src(const char *gin, const char 
 #ifndef EMAVFI_CONV_INTERLEAVE
 #define EMAVFI_CONV_INTERLEAVE 1
 #endif
+#ifndef EMAVFI_CONV_STAGED_STORE
+#define EMAVFI_CONV_STAGED_STORE 1   // tile-per-workgroup kernel: 16-bit channels-last outputs are transposed through LDS (0: direct 32-byte stores)
+#endif
 #ifndef EMAVFI_CONV_PIPELINE
 #define EMAVFI_CONV_PIPELINE 1   // persistent kernel: operands one step ahead of their MFMAs (0 = the compiler's own order)
 #endif
@@ -282,6 +285,52 @@ __global__ __launch_bounds__(256, (conv_wg_per_cu<T, CK, NF, S>())) void conv3x3
         }
     }
 
+    // 16-bit channels-last outputs: through LDS, so that a store instruction writes whole pixels of consecutive addresses instead
+    // of 32 bytes of 64 different pixels (conv_first.inl measured 25 % on this store pattern).  The tile and the weight ring are dead.
+    constexpr int STG_PX = NF * 64 + 16, STG_WAVE = MF * 32 * STG_PX;
+    if constexpr (sizeof(T) == 2 && EMAVFI_CONV_STAGED_STORE && 4 * STG_WAVE <= C::LDS_BYTES) {
+        if (p.epi == EPI_NONE || p.epi == EPI_RELU) {   // wave-uniform
+            typedef __attribute__((ext_vector_type(2))) T pair_t;
+            typedef __attribute__((ext_vector_type(4))) unsigned u4_t;
+            typedef __attribute__((address_space(3))) char lchar_t;
+            __syncthreads();
+            lchar_t *stg = (lchar_t *)smem + wave * STG_WAVE;
+            const bool relu = p.epi == EPI_RELU;
+            const int limit = p.cstore - pass * NF * 32;   // channels of this pass that exist in the output (multiple of 8)
+#pragma unroll
+            for (int m = 0; m < MF; ++m)
+#pragma unroll
+                for (int n = 0; n < NF; ++n)
+#pragma unroll
+                    for (int g = 0; g < 4; g += 2) {
+                        unsigned a[2], c[2];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            float v0 = acc[m][n][4 * g + 2 * q], v1 = acc[m][n][4 * g + 2 * q + 1], u0 = acc[m][n][4 * (g + 1) + 2 * q], u1 = acc[m][n][4 * (g + 1) + 2 * q + 1];
+                            if (relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); u0 = fmaxf(u0, 0.0f); u1 = fmaxf(u1, 0.0f); }
+                            const pair_t pa = {(T)v0, (T)v1}, pb = {(T)u0, (T)u1};
+                            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, pa), __builtin_bit_cast(unsigned, pb), false, false);
+                            a[q] = sw[0]; c[q] = sw[1];
+                        }
+                        *reinterpret_cast<__attribute__((address_space(3))) u4_t *>(stg + (m * 32 + r) * STG_PX + (n * 32 + 8 * (g + h)) * 2) = u4_t{a[0], a[1], c[0], c[1]};
+                    }
+            constexpr int NCH = NF * 4;   // 16-byte chunks per staged pixel
+#pragma unroll
+            for (int m = 0; m < MF; ++m) {
+                const int y = ty * C::TH + wave * MF + m;
+                if (y >= p.Hout) continue;
+                char *orow = reinterpret_cast<char *>(p.out) + ((((size_t)b * p.Hout + y) * p.Wout + (size_t)tx * 32) * p.out_ps + p.out_coff + pass * NF * 32) * sizeof(T);
+#pragma unroll
+                for (int i = 0; i < NCH / 2; ++i) {
+                    const int q = i * 64 + lane, px = q / NCH, ch = q - px * NCH;
+                    if (tx * 32 + px < p.Wout && ch * 8 < limit)
+                        *reinterpret_cast<u4_t *>(orow + (size_t)px * p.out_ps * sizeof(T) + ch * 16) =
+                            *reinterpret_cast<const __attribute__((address_space(3))) u4_t *>(stg + (m * 32 + px) * STG_PX + ch * 16);
+                }
+            }
+            return;
+        }
+    }
     conv_epilogue<T, MF, NF>(acc, p, b, pass, ty * C::TH + wave * MF, tx * 32 + r, h);
 }
 
