@@ -534,49 +534,6 @@ def test_mfma16_conv_agrees_with_the_32x32_kernels(dtype, cout, act, shape, monk
     assert (err > 0).float().mean().item() < 0.02, "the two kernels should differ in rare last-place roundings only"
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("cout", [64, 32, 2])
-@pytest.mark.parametrize("shape", [(2, 75, 131), (1, 8, 32), (1, 17, 33), (2, 40, 64), (1, 360, 640)])
-def test_pingpong_conv_equals_the_persistent_kernel(dtype, cout, shape, monkeypatch):
-    """conv3x3_pingpong_kernel (opt-in, EMAVFI_CONV_PINGPONG=1: two four-wave groups half a tile out of phase; 64 -> 64 on
-    unpadded XOR-swizzled tiles) against the product's persistent kernel: same tap / k-group order, so bit-identical.  Sizes
-    with one tile, odd tile counts per group and tiles hanging over every edge."""
-    B, H, W = shape
-    g = torch.Generator().manual_seed(7)
-    x = torch.randn(B, 64, H, W, generator=g).to(DEV)
-    w = (torch.randn(cout, 64, 3, 3, generator=g) * 0.05).to(DEV)
-    b = torch.randn(cout, generator=g).to(DEV)
-    monkeypatch.setenv("EMAVFI_CONV_MFMA16", "0")      # compare against the 32x32x16 persistent kernel, not the 16x16x32 one
-    monkeypatch.setenv("EMAVFI_CONV_PINGPONG", "0")
-    ref = lib.conv3x3(x, w, b, dtype=dtype).clone()
-    monkeypatch.setenv("EMAVFI_CONV_PINGPONG", "1")
-    got = lib.conv3x3(x, w, b, dtype=dtype).clone()
-    assert torch.isfinite(got).all()
-    assert torch.equal(got, ref), f"{int((got != ref).sum())} of {got.numel()} elements differ, max {(got - ref).abs().max().item():.3e}"
-
-
-@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("shape", [(2, 75, 131), (1, 8, 32), (1, 9, 33), (3, 40, 64), (1, 360, 640)])
-def test_fused_tail_equals_two_launches(dtype, shape, monkeypatch):
-    """reconstruction.1 + .2 as one launch (conv3x3_tail_kernel, opt-in with EMAVFI_FUSED_TAIL=1 because it measured slower:
-    the 32-channel intermediate stays in the LDS, halo recomputed, out-of-image positions zeroed) must equal the two
-    stand-alone launches bit for bit: same tap / k-group order, same rounding of the intermediate.  Ragged sizes exercise
-    tiles that hang over the image on every side."""
-    B, H, W = shape
-    monkeypatch.setenv("EMAVFI_CONV_MFMA16", "0")    # the tail kernel reads reconstruction.1's weights in the 32x32x16 packing
-    sd = synth.synthetic_state_dict(seed=2)
-    m = EMA_VFI(compute_dtype=dtype).to(DEV).eval()
-    m.load_state_dict(sd)
-    f1, f2 = (t.to(DEV) for t in synth.synthetic_frames(31, B, H, W, "natural"))
-    with torch.no_grad():
-        monkeypatch.setenv("EMAVFI_FUSED_TAIL", "0")
-        two = m(f1, f2).clone()
-        monkeypatch.setenv("EMAVFI_FUSED_TAIL", "1")
-        one = m(f1, f2).clone()
-    assert torch.isfinite(one).all()
-    assert torch.equal(one, two), f"{int((one != two).sum())} of {one.numel()} elements differ, max {(one - two).abs().max().item():.3e}"
-
-
 def test_fused_first_layer_equals_pack_input_plus_conv(monkeypatch):
     """16-bit modes at mid_channels 64 compute cat(frame1, frame2) + feat_ext_conv1 + ReLU in ONE launch straight from the NCHW
     fp32 frames (csrc/conv_first.inl); EMAVFI_CONV_FIRST=0 runs pack_input + conv3x3.  Same rounded inputs, weights and products;

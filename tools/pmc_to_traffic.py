@@ -22,6 +22,19 @@ def label(k):
     m = re.match(r"_Z18deform_pack_kernelI(DF16b|DF16_)Li(\d+)ELi(\d+)ELb1", k)
     if m:  # the LDS-window kernel, one launch per ModulatedDeformConvPack (csrc/deform_pack.inl)
         return f"deform<{'bf16' if m.group(1) == 'DF16b' else 'f16'},ck=80,nf=3>"
+    if "deform_pack3_kernel" in k:   # rocprofv3 prints the template demangled without its arguments: the bench runs the bf16 fused instance
+        return "deform<bf16,ck=80,nf=3>"
+    if "deform_f32w_kernel" in k:
+        return "deform<f32,ck=80,nf=3>"
+    m = re.match(r"_Z17conv_first_kernelI(DF16b|DF16_)", k)
+    if m:
+        return f"conv_first<{'bf16' if m.group(1) == 'DF16b' else 'f16'},6->64>"
+    m = re.match(r"_Z25conv3x3_pingpong16_kernelI(DF16b|DF16_)Li64ELi2", k)
+    if m:
+        return f"conv3x3<{'bf16' if m.group(1) == 'DF16b' else 'f16'},ck=64,nf=2,s=1>"
+    m = re.match(r"_Z24conv3x3_persist16_kernelI(DF16b|DF16_)Li64ELi1", k)
+    if m:
+        return f"conv3x3<{'bf16' if m.group(1) == 'DF16b' else 'f16'},ck=64,nf=1,s=1>"
     m = re.match(r"_Z14conv3x3_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)EEv", k)
     if m:
         return f"conv3x3<{'bf16' if m.group(1) == 'DF16b' else 'f32'},ck={m.group(2)},nf={m.group(3)},s={m.group(4)}>"

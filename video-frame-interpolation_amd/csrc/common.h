@@ -164,17 +164,6 @@ struct ConvParams {
                          // Pieces beyond read as zeros: the 72-channel fusion buffers feed CK = 80 layers this way.
 };
 
-// reconstruction.1 + reconstruction.2 in one launch (conv3x3.inl, conv3x3_tail_kernel): conv 64 -> 32 + ReLU whose result never
-// leaves the LDS, then conv 32 -> <= 4 planes with the frame epilogue
-struct TailParams {
-    const void *in;        // channels-last T, in_ps elements per pixel (64 used)
-    const void *w1, *w2;   // packed weights of the two layers (same packing as ConvParams::w)
-    const float *bias1, *bias2;
-    float *out_planar;     // NCHW fp32, nplanes planes
-    const void *zeros;
-    int in_ps, H, W, B, nplanes, epi2, round16;
-};
-
 struct DeformParams {
     const void *x;     // channels-last T, CK channels used
     float *om;         // [px][32] fp32: 18 offsets (dy,dx per tap), 9 masks, 5 pad (read; written first when fused)
@@ -215,8 +204,6 @@ int launch_conv_first_f16(const FirstParams &p, hipStream_t s);
 int launch_conv3x3_f32(const ConvParams &p, hipStream_t s);
 int launch_conv3x3_bf16(const ConvParams &p, hipStream_t s);
 int launch_conv3x3_f16(const ConvParams &p, hipStream_t s);
-int launch_conv_tail_bf16(const TailParams &p, hipStream_t s);
-int launch_conv_tail_f16(const TailParams &p, hipStream_t s);
 int launch_deform_f32(const DeformParams &p, hipStream_t s);
 int launch_deform_bf16(const DeformParams &p, hipStream_t s);
 int launch_deform_f16(const DeformParams &p, hipStream_t s);

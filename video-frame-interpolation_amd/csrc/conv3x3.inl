@@ -27,8 +27,8 @@
 //   conv3x3_persist_kernel    persistent, nine taps' weights resident, 16 x 32 tiles, 8 waves in lock step (32x32x16 MFMAs)
 //   conv3x3_persist16_kernel  the same on v_mfma_f32_16x16x32 with an unpadded XOR-swizzled tile: 64 -> 32 and 64 -> planes
 //   conv3x3_pingpong16_kernel two four-wave groups half a tile out of phase on that shape: the 64 -> 64 layers (product)
-//   conv3x3_pingpong_kernel   the ping-pong schedule on 32x32x16 MFMAs (opt-in, measurement)
-//   conv3x3_tail_kernel       reconstruction.1 + .2 through the LDS (opt-in: bit-identical, slower)
+//   (round 2's conv3x3_pingpong_kernel - the schedule on 32x32x16 MFMAs - and conv3x3_tail_kernel - reconstruction.1 + .2 through
+//    the LDS - were measurement-only experiments that lost and were removed in round 3)
 #include "common.h"
 #include <cstdlib>
 #include <mutex>
@@ -728,7 +728,7 @@ template <typename T, int CK, int NF, int NB> static int launch_conv_persist16(c
     return (int)hipGetLastError();
 }
 
-// The 16x16x32 kernel with the ping-pong schedule (see conv3x3_pingpong_kernel below): two groups of four waves, each with
+// The 16x16x32 kernel with the ping-pong schedule (first built on 32x32x16 MFMAs in round 2: DESIGN.md section 4.2): two groups of four waves, each with
 // its own 8-row tile buffer (unpadded + XOR swizzle: 72 KiB of weights + 2 x 44 KiB fit), one group in its MFMA loop while the
 // other stores its previous tile and DMAs its next.  Channels-last epilogue only (64 -> 64).  The product's kernel for these
 // layers; bit-identical to conv3x3_persist16_kernel (EMAVFI_CONV_PINGPONG=0).
@@ -967,169 +967,6 @@ template <typename T> static int launch_conv_mfma16(const ConvParams &p, hipStre
     return -2;
 }
 
-// ------------------------------------------------------------------------------------------
-// Ping-pong variant of the persistent kernel (16-bit, stride 1, one chunk, one pass).  In the kernel above all eight waves
-// of the workgroup walk through a tile's phases together - DMA in, contract, store out - so the matrix pipe idles during two
-// of the three (3.8 us of MFMA time in an 11.4 us tile).  Here the workgroup is two groups of four
-// waves (one per SIMD each) with their OWN 8-row tile buffers and tile sequences, half a tile out of phase: in every slot one
-// group contracts while the other stores its previous tile and DMAs its next one, and a workgroup barrier ends the slot
-//     slot A:  group 0  MFMA(k)                       | group 1  store(k-1), DMA(k), wait
-//     slot B:  group 0  store(k), DMA(k+1), wait      | group 1  MFMA(k)
-// Same tap / k-group order per pixel as the other kernels: bit-identical results.  The weights stay resident and shared.
-// Measured: 64 -> 64 gets 7.6 % faster, 64 -> 32 / 64 -> 2 do not change, and the board lowers the clock so
-// that the whole step gains 0.2 % - opt-in (EMAVFI_CONV_PINGPONG=1), the product keeps the kernel above.
-// ------------------------------------------------------------------------------------------
-// SWZ (chosen when the padded tiles do not fit beside the weights: 64 -> 64): pixels are stored UNPADDED (128 bytes) and the
-// 16-byte piece c of tile pixel q sits in slot c ^ ((q >> 1) & 7) of that pixel - the DMA permutes via its per-lane source
-// address, the reader XORs; the 16 lanes of a ds_read_b128 group (16 consecutive-modulo-16 pixels, one piece index) then hit 16
-// different slots of the 256-byte bank row, as with the odd padded stride.
-template <typename T, int CK, int NF> struct ConvPingCfg {
-    using D = DT<T>;
-    static constexpr int GW = 4, MF = 2, TH = GW * MF, TW = 32, IH = TH + 2, IW = TW + 2;
-    static constexpr int PIECES = CK * (int)sizeof(T) / 16;
-    static constexpr int PAD_BYTES = 9 * (CK / D::CHKG) * NF * 1024 + 2 * (((IH * IW * (LdsPix<T, CK>::BYTES / 16)) + 63) / 64) * 1024;
-    static constexpr bool SWZ = PAD_BYTES > 160 * 1024 && PIECES == 8;
-    static constexpr int PSTR = SWZ ? PIECES * 16 : LdsPix<T, CK>::BYTES;
-    static constexpr int KG = CK / D::CHKG;
-    static constexpr int WTAP = KG * NF * 1024, WINST = 9 * KG * NF;
-    static constexpr int SP = PSTR / 16, NSLOT = IH * IW * SP, NINST = (NSLOT + 63) / 64;
-    static constexpr int LDS_W = 9 * WTAP, LDS_IN = NINST * 1024, LDS_BYTES = LDS_W + 2 * LDS_IN;
-    static constexpr bool FITS = LDS_BYTES <= 160 * 1024;
-};
-
-template <typename T, int CK, int NF>
-__global__ __launch_bounds__(512) void conv3x3_pingpong_kernel(const ConvParams p)
-{
-    using C = ConvPingCfg<T, CK, NF>;
-    using vec = typename DT<T>::vec;
-    constexpr int MF = C::MF, IW = C::IW, PSTR = C::PSTR;
-    static_assert(C::FITS, "resident weights + two tile buffers do not fit the 160 KiB LDS");
-    typedef __attribute__((address_space(1))) const void gptr_t;
-    typedef __attribute__((address_space(3))) void lptr_t;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *lds_w = smem;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = wave >> 2, wq = wave & 3;   // group, wave inside the group
-    char *lds_in = smem + C::LDS_W + g * C::LDS_IN;
-    const int r = lane & 31, h = lane >> 5;
-    const char *zeros = (const char *)p.zeros;
-    const int npieces = p.in_pieces > 0 ? p.in_pieces : C::PIECES;
-
-#pragma unroll 1
-    for (int j = wave; j < C::WINST; j += 8)
-        __builtin_amdgcn_global_load_lds((gptr_t *)((const char *)p.w + j * 1024 + lane * 16), (lptr_t *)(lds_w + j * 1024), 16, 0, 0);
-
-    const int ntx = (p.Wout + 31) / 32, nty = (p.Hout + C::TH - 1) / C::TH;
-    const int ntiles = ntx * nty * p.B;
-    const int first = (int)blockIdx.x * 2 + g, stride = (int)gridDim.x * 2;
-    // rounds: group 0 never has fewer tiles than group 1
-    const int rounds = ((int)blockIdx.x * 2 < ntiles) ? (ntiles - (int)blockIdx.x * 2 + stride - 1) / stride : 0;
-
-    auto stage = [&](int tile) {   // DMA `tile`'s input (+halo) into this group's buffer
-        const int b = tile / (ntx * nty), trem = tile - b * (ntx * nty);
-        const int ty = trem / ntx, tx = trem - ty * ntx;
-        const int iy0 = ty * C::TH - 1, ix0 = tx * 32 - 1;
-        const char *gin = (const char *)p.in + (size_t)b * p.Hin * p.Win * p.in_ps * sizeof(T);
-#pragma unroll
-        for (int i = 0; i < (C::NINST + C::GW - 1) / C::GW; ++i) {
-            const int j = i * C::GW + wq;
-            if (j < C::NINST) {
-                const int sl = j * 64 + lane;
-                const int pix = sl / C::SP, ps_ = sl - pix * C::SP;
-                const int pc = C::SWZ ? (ps_ ^ ((pix >> 1) & 7)) : ps_;
-                const int ly = pix / IW, lx = pix - ly * IW;
-                const int gy = iy0 + ly, gx = ix0 + lx;
-                const bool ok = sl < C::NSLOT && pc < npieces && gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
-                const char *src = ok ? gin + ((size_t)gy * p.Win + gx) * p.in_ps * sizeof(T) + pc * 16 : zeros;
-                __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)(lds_in + j * 1024), 16, 0, 0);
-            }
-        }
-    };
-    f32x16 acc[MF][NF];
-    auto contract = [&](int tile) {
-        const int b = tile / (ntx * nty), trem = tile - b * (ntx * nty);
-        const int ty = trem / ntx, tx = trem - ty * ntx;
-        conv_init_acc<MF, NF>(acc, p, b, 0, ty * C::TH + wq * MF, tx * 32 + r, h);
-        constexpr int KGS = (C::KG % 2 == 0) ? 2 : 1;
-        constexpr int SPT = C::KG / KGS, NSTEP = 9 * SPT;
-        vec xq[2][MF][KGS], wv[2][KGS][NF];
-        auto load_step = [&](int s, vec (&xd)[MF][KGS], vec (&wd)[KGS][NF]) {
-            const int tap = s / SPT, kg0 = (s - tap * SPT) * KGS;
-            const int dy = tap / 3, dx = tap - 3 * dy;
-#pragma unroll
-            for (int m = 0; m < MF; ++m) {
-                const int q = ((wq * MF + m) + dy) * IW + r + dx;
-                if constexpr (C::SWZ) {
-                    const int fq = (q >> 1) & 7;
-#pragma unroll
-                    for (int k = 0; k < KGS; ++k) xd[m][k] = *reinterpret_cast<const vec *>(lds_in + q * PSTR + (((2 * (kg0 + k) + h) ^ fq) << 4));
-                } else {
-                    const char *xb = lds_in + q * PSTR + h * 16;
-#pragma unroll
-                    for (int k = 0; k < KGS; ++k) xd[m][k] = *reinterpret_cast<const vec *>(xb + (kg0 + k) * 32);
-                }
-            }
-            const char *wb = lds_w + tap * C::WTAP + lane * 16;
-#pragma unroll
-            for (int k = 0; k < KGS; ++k)
-#pragma unroll
-                for (int n = 0; n < NF; ++n) wd[k][n] = *reinterpret_cast<const vec *>(wb + ((kg0 + k) * NF + n) * 1024);
-        };
-        load_step(0, xq[0], wv[0]);
-#pragma unroll
-        for (int s = 0; s < NSTEP; ++s) {
-            if (s + 1 < NSTEP) load_step(s + 1, xq[(s + 1) & 1], wv[(s + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 0; k < KGS; ++k)
-#pragma unroll
-                for (int n = 0; n < NF; ++n)
-#pragma unroll
-                    for (int m = 0; m < MF; ++m) mma_kg(acc[m][n], wv[s & 1][k][n], xq[s & 1][m][k]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    auto store = [&](int tile) {
-        const int b = tile / (ntx * nty), trem = tile - b * (ntx * nty);
-        const int ty = trem / ntx, tx = trem - ty * ntx;
-        conv_epilogue<T, MF, NF>(acc, p, b, 0, ty * C::TH + wq * MF, tx * 32 + r, h);
-    };
-
-    if (g == 0 && first < ntiles) stage(first);
-    __syncthreads();   // weights and group 0's first tile have landed (hipcc drains vmcnt(0) ahead of the barrier)
-    // slot s: the group with (s + g) even contracts its tile number (s - g) / 2; the other one stores the tile it contracted in
-    // the previous slot and stages the one it will contract in the next.  2 * rounds + 1 slots: the last one only stores.
-#pragma unroll 1
-    for (int sl = 0; sl <= 2 * rounds; ++sl) {
-        if (((sl + g) & 1) == 0) {
-            const int t = first + ((sl - g) >> 1) * stride;
-            if (sl < 2 * rounds && t < ntiles) contract(t);
-        } else {
-            const int tp = first + ((sl - 1 - g) >> 1) * stride, tn = first + ((sl + 1 - g) >> 1) * stride;
-            if (sl - 1 - g >= 0 && tp < ntiles) store(tp);
-            if (sl + 1 < 2 * rounds + 1 && tn < ntiles) stage(tn);
-        }
-        __syncthreads();
-    }
-}
-
-template <typename T, int CK, int NF> static int launch_conv_pingpong(const ConvParams &p, hipStream_t s)
-{
-    using C = ConvPingCfg<T, CK, NF>;
-    static std::once_flag once;
-    static hipError_t init_err = hipSuccess;
-    std::call_once(once, [] {
-        init_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_pingpong_kernel<T, CK, NF>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-    });
-    if (init_err != hipSuccess) return (int)init_err;
-    const int ncu = device_cu_count();
-    if (ncu <= 0) return (int)hipErrorInvalidDevice;
-    const int ntiles = ((p.Wout + 31) / 32) * ((p.Hout + C::TH - 1) / C::TH) * p.B;
-    const int wgs = (ntiles + 1) / 2;
-    conv3x3_pingpong_kernel<T, CK, NF><<<wgs < ncu ? wgs : ncu, 512, C::LDS_BYTES, s>>>(p);
-    return (int)hipGetLastError();
-}
-
 template <typename T, int CK, int NF, int WAVES> static int launch_conv_persist(const ConvParams &p, hipStream_t s)
 {
     using C = ConvPersistCfg<T, CK, NF, WAVES>;
@@ -1156,158 +993,7 @@ template <typename T, int CK, int NF, int WAVES> static int launch_conv_persist(
     return (int)hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------------------
-// reconstruction.1 + reconstruction.2 (ema_vfi.py:103-107: conv_block(64, 32), conv(32, 3), then tanh and (t + 1) / 2 at
-// :146) as ONE persistent launch for the 16-bit types at mid_channels = 64.  Per 8 x 32 output tile:
-//   stage 1  the 64-channel input tile with a 2-pixel halo (12 x 36 pixels) is DMA-staged; conv 64 -> 32 + bias + ReLU is
-//            evaluated on the 10 x 34 positions stage 2 needs (halo recompute: 340 instead of 256 pixels, 11 fragments of 32
-//            spread over the 8 waves), rounded to T exactly as the stand-alone layer stores it, positions outside the image
-//            forced to zero (they are stage 2's zero padding), and written to an LDS tile - it never reaches HBM;
-//   stage 2  conv 32 -> nplanes on that tile, one output row per wave, with the stand-alone layer's epilogue.
-// Same tap / k-group order as the stand-alone kernels, so the result is bit-identical to the two-launch path
-// (tests/test_gpu_parity.py::test_fused_tail_equals_two_launches).  LDS: 36 + 18 KiB of weights (resident), 61 KiB input
-// tile, 27 KiB intermediate = 142 KiB, one 8-wave workgroup per CU.
-// ------------------------------------------------------------------------------------------
-template <typename T> struct TailCfg {
-    using D = DT<T>;
-    static constexpr int WAVES = 8, TH = 8, TW = 32;
-    static constexpr int CK1 = 64, KG1 = CK1 / D::CHKG, PSTR1 = LdsPix<T, CK1>::BYTES, SP1 = PSTR1 / 16, PIECES1 = CK1 * (int)sizeof(T) / 16;
-    static constexpr int CK2 = 32, KG2 = CK2 / D::CHKG, PSTR2 = LdsPix<T, CK2>::BYTES;
-    static constexpr int IH = TH + 4, IW = TW + 4, MH = TH + 2, MW = TW + 2, NMID = MH * MW, NFRAG1 = (NMID + 31) / 32;
-    static constexpr int W1TAP = KG1 * 1024, W2TAP = KG2 * 1024, LDS_W1 = 9 * W1TAP, LDS_W2 = 9 * W2TAP;
-    static constexpr int NSLOT = IH * IW * SP1, NINST = (NSLOT + 63) / 64, LDS_IN = NINST * 1024;
-    static constexpr int LDS_MID = (NMID * PSTR2 + 15) / 16 * 16;
-    static constexpr int LDS_BYTES = LDS_W1 + LDS_W2 + LDS_IN + LDS_MID;
-    static_assert(sizeof(T) == 2, "16-bit storage types only");
-    static_assert(LDS_BYTES <= 160 * 1024, "fused tail does not fit the 160 KiB LDS");
-};
-
-template <typename T>
-__global__ __launch_bounds__(512) void conv3x3_tail_kernel(const TailParams p)
-{
-    using C = TailCfg<T>;
-    using vec = typename DT<T>::vec;
-    typedef __attribute__((address_space(1))) const void gptr_t;
-    typedef __attribute__((address_space(3))) void lptr_t;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *lds_w1 = smem, *lds_w2 = smem + C::LDS_W1, *lds_in = lds_w2 + C::LDS_W2, *lds_mid = lds_in + C::LDS_IN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const char *zeros = (const char *)p.zeros;
-    const int npieces = p.in_ps * (int)sizeof(T) / 16 < C::PIECES1 ? p.in_ps * (int)sizeof(T) / 16 : C::PIECES1;
-
-    // both layers' packed weights, once per workgroup
-#pragma unroll 1
-    for (int j = wave; j < 9 * C::KG1; j += C::WAVES)
-        __builtin_amdgcn_global_load_lds((gptr_t *)((const char *)p.w1 + j * 1024 + lane * 16), (lptr_t *)(lds_w1 + j * 1024), 16, 0, 0);
-#pragma unroll 1
-    for (int j = wave; j < 9 * C::KG2; j += C::WAVES)
-        __builtin_amdgcn_global_load_lds((gptr_t *)((const char *)p.w2 + j * 1024 + lane * 16), (lptr_t *)(lds_w2 + j * 1024), 16, 0, 0);
-
-    // the second layer's parameters in the shape the shared epilogue takes
-    ConvParams p2{};
-    p2.out_planar = p.out_planar; p2.bias = p.bias2; p2.Hout = p.H; p2.Wout = p.W; p2.B = p.B; p2.npass = 1;
-    p2.epi = p.epi2; p2.nplanes = p.nplanes; p2.round16 = p.round16;
-
-    const int ntx = (p.W + C::TW - 1) / C::TW, nty = (p.H + C::TH - 1) / C::TH;
-    const int ntiles = ntx * nty * p.B;
-    // input tile of `t` -> LDS (the caller has made sure nobody still reads the previous one)
-    auto stage_input = [&](int t) {
-        const int b = t / (ntx * nty), trem = t - b * (ntx * nty);
-        const int ty = trem / ntx, tx = trem - ty * ntx;
-        const int iy0 = ty * C::TH - 2, ix0 = tx * C::TW - 2;
-        const char *gin = (const char *)p.in + (size_t)b * p.H * p.W * p.in_ps * sizeof(T);
-#pragma unroll
-        for (int i = 0; i < (C::NINST + C::WAVES - 1) / C::WAVES; ++i) {
-            const int j = i * C::WAVES + wave;
-            if (j < C::NINST) {
-                const int sl = j * 64 + lane;
-                const int pix = sl / C::SP1, pc = sl - pix * C::SP1;
-                const int ly = pix / C::IW, lx = pix - ly * C::IW;
-                const int gy = iy0 + ly, gx = ix0 + lx;
-                const bool ok = sl < C::NSLOT && pc < npieces && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-                const char *src = ok ? gin + ((size_t)gy * p.W + gx) * p.in_ps * sizeof(T) + pc * 16 : zeros;
-                __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)(lds_in + j * 1024), 16, 0, 0);
-            }
-        }
-    };
-    if ((int)blockIdx.x < ntiles) stage_input(blockIdx.x);
-#pragma unroll 1
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int b = tile / (ntx * nty), trem = tile - b * (ntx * nty);
-        const int ty = trem / ntx, tx = trem - ty * ntx;
-        // the tile's DMA (issued behind the previous tile's stage 1) has landed; the previous stage 2 has finished with the
-        // intermediate image (hipcc drains vmcnt(0) ahead of the barrier)
-        __syncthreads();
-
-        // ---- stage 1: conv 64 -> 32 + ReLU on the 10 x 34 intermediate positions, 32 of them per fragment
-#pragma unroll 1
-        for (int f = wave; f < C::NFRAG1; f += C::WAVES) {
-            const int q = f * 32 + r, qq = q < C::NMID ? q : C::NMID - 1;   // lanes past the end recompute the last position
-            const int my = qq / C::MW, mx = qq - my * C::MW;
-            f32x16 acc;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = p.bias1[acc_channel(i, h)];
-            const char *xb = lds_in + (my * C::IW + mx) * C::PSTR1 + h * 16;
-            const char *wb = lds_w1 + lane * 16;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int dy = tap / 3, dx = tap - 3 * dy;
-#pragma unroll
-                for (int kg = 0; kg < C::KG1; ++kg) {
-                    const vec xv = *reinterpret_cast<const vec *>(xb + (dy * C::IW + dx) * C::PSTR1 + kg * 32);
-                    const vec wv = *reinterpret_cast<const vec *>(wb + (tap * C::KG1 + kg) * 1024);
-                    mma_kg(acc, wv, xv);
-                }
-            }
-            // the stand-alone layer's rounding (store_frag, EPI_RELU); zero outside the image = stage 2's padding
-            const int gy = ty * C::TH - 1 + my, gx = tx * C::TW - 1 + mx;
-            const float keep = (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? 1.0f : 0.0f;
-            // (lanes past the last position store nothing but still take part in store_frag's lane swaps)
-            store_frag(reinterpret_cast<T *>(lds_mid + qq * C::PSTR2), acc, h, q < C::NMID ? 32 : 0, [keep](float v, int) { return fmaxf(v, 0.0f) * keep; });
-        }
-        __syncthreads();
-        // every wave is done with the input tile: fetch the next one under stage 2
-        if (tile + (int)gridDim.x < ntiles) stage_input(tile + gridDim.x);
-
-        // ---- stage 2: conv 32 -> nplanes, output row `wave` of the tile
-        {
-            f32x16 acc2[1][1];
-            conv_init_acc<1, 1>(acc2, p2, b, 0, ty * C::TH + wave, tx * C::TW + r, h);
-            const char *xb = lds_mid + (wave * C::MW + r) * C::PSTR2 + h * 16;
-            const char *wb = lds_w2 + lane * 16;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int dy = tap / 3, dx = tap - 3 * dy;
-#pragma unroll
-                for (int kg = 0; kg < C::KG2; ++kg) {
-                    const vec xv = *reinterpret_cast<const vec *>(xb + (dy * C::MW + dx) * C::PSTR2 + kg * 32);
-                    const vec wv = *reinterpret_cast<const vec *>(wb + (tap * C::KG2 + kg) * 1024);
-                    mma_kg(acc2[0][0], wv, xv);
-                }
-            }
-            conv_epilogue<T, 1, 1>(acc2, p2, b, 0, ty * C::TH + wave, tx * C::TW + r, h);
-        }
-    }
-}
-
-template <typename T> static int launch_conv_tail(const TailParams &p, hipStream_t s)
-{
-    using C = TailCfg<T>;
-    static std::once_flag once;
-    static hipError_t init_err = hipSuccess;
-    std::call_once(once, [] {
-        init_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_tail_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-    });
-    if (init_err != hipSuccess) return (int)init_err;
-    const int ncu = device_cu_count();
-    if (ncu <= 0) return (int)hipErrorInvalidDevice;
-    const int ntiles = ((p.W + C::TW - 1) / C::TW) * ((p.H + C::TH - 1) / C::TH) * p.B;
-    conv3x3_tail_kernel<T><<<ntiles < ncu ? ntiles : ncu, 512, C::LDS_BYTES, s>>>(p);
-    return (int)hipGetLastError();
-}
-
-// (CK, NF, stride) instantiations: what mid_channels in {8, 16, 32, 64} need (see plan.cpp).
+// (CK, NF, stride) instantiations of the tile-per-workgroup kernel (keep in sync with kConvInst in emavfi_api.hip)
 #define EMAVFI_CONV_INSTANCES(X) \
     X(16, 1, 1) X(16, 2, 1) X(32, 1, 1) X(48, 1, 1) X(64, 1, 1) X(64, 2, 1) X(64, 4, 1) X(80, 1, 1) X(80, 2, 1) \
     X(16, 1, 2) X(32, 2, 2) X(32, 4, 2)
@@ -1333,10 +1019,6 @@ template <typename T> static int launch_conv16(const ConvParams &p, hipStream_t 
         // measured at B=8 x 720p in bf16 (us per launch, tile-per-workgroup -> persistent): 64->64 670 -> 644,
         // 64->32 / 64->2 414 -> 370, 67->27 685 -> 557.  NOT used where it loses: 67->64 with 4 waves
         // (771 -> 915: one 4-wave workgroup per CU cannot overlap its own phases), 6->64, 32->3 (no gain).
-        const char *pp_ = getenv("EMAVFI_CONV_PINGPONG");   // read per call: the parity test flips it inside one process
-        const bool pingpong = pp_ != nullptr && pp_[0] == '1';
-        if (pingpong && p.ck == 64 && p.nf == 1) return launch_conv_pingpong<T, 64, 1>(p, s);
-        if (pingpong && p.ck == 64 && p.nf == 2) return launch_conv_pingpong<T, 64, 2>(p, s);
         if (p.ck == 64 && p.nf == 2) return launch_conv_persist<T, 64, 2, 8>(p, s);
         if (p.ck == 64 && p.nf == 1) return launch_conv_persist<T, 64, 1, 8>(p, s);
         if (p.ck == 80 && p.nf == 1) return launch_conv_persist<T, 80, 1, 8>(p, s);

@@ -6,6 +6,5 @@ int launch_conv3x3_f16(const ConvParams &p, hipStream_t s)
     static const bool off = getenv("EMAVFI_NO_PERSISTENT_CONV") != nullptr;  // A/B switch for measurements
     return launch_conv16<half_t>(p, s, off);
 }
-int launch_conv_tail_f16(const TailParams &p, hipStream_t s) { return launch_conv_tail<half_t>(p, s); }
 
 int launch_conv_first_f16(const FirstParams &p, hipStream_t s) { return launch_conv_first_t<half_t>(p, s); }

@@ -20,10 +20,6 @@
 #pragma once
 #include "deform.inl"
 
-#ifndef EMAVFI_DEFORM_XCD_ORDER
-#define EMAVFI_DEFORM_XCD_ORDER 1
-#endif
-
 struct F32W {
     static constexpr int R = 2, TROWS = 16, TCOLS = 16, WAVES = 4, THREADS = 256;
     static constexpr int TR = TROWS + 3 + 2 * R, TC = TCOLS + 3 + 2 * R;                  // 23 x 23 window pixels

@@ -123,8 +123,6 @@ bool deform_geometry(Layer &L, int esize)
     return false;
 }
 
-// shape served by deform_pack_kernel (keep in sync with deform16_lds_shape in deform_pack.inl)
-bool deform16_lds_shape_host(int ck, int nf, int cin_real) { return ck == 80 && nf == 3 && cin_real <= 72; }
 // bf16 model: consecutive one-launch packs hand each other f16 bit patterns (the window is f16 on chip anyway; the
 // receiving pack skips its in-LDS conversion pass).  EMAVFI_PACK_F16_CHAIN=0 keeps bf16 between them (A/B switch).
 bool pack_f16_chain()
@@ -219,7 +217,7 @@ bool build_plan(Plan &P, int in_ch, int mid, int nb, int dtype)
     // model its two weight sets are the bf16-rounded values stored as f16.  The stand-alone offset_conv (conv3x3, used
     // when the pack is not fused) still reads the bf16 copy.
     P.fps = P.fpad;
-    if (ok && !P.amp && dtype != EMAVFI_F32 && nb > 0 && deform16_lds_shape_host(P.dcn[0].ck, P.dcn[0].nf, P.dcn[0].cin_take)) P.fps = 72;
+    if (ok && !P.amp && dtype != EMAVFI_F32 && nb > 0 && deform_pack3_shape(P.dcn[0].ck, P.dcn[0].nf, P.dcn[0].cin_take, P.dcn[0].cout)) P.fps = 72;
     if (ok && P.amp) {
         for (int i = 0; i < nb && ok; ++i) {
             P.dcn32[i] = mk(P.dcn[i].param, f, f);
@@ -238,7 +236,7 @@ bool build_plan(Plan &P, int in_ch, int mid, int nb, int dtype)
     P.has_offh = false;
     const bool p3 = ok && !P.amp && dtype != EMAVFI_F32 && nb > 0 && deform_pack3_shape(P.dcn[0].ck, P.dcn[0].nf, P.dcn[0].cin_take, P.dcn[0].cout) &&
                     P.off[0].nchunk == 1 && P.off[0].npass == 1 && P.off[0].ck == 80 && P.off[0].nf == 1;
-    if (p3 || (ok && dtype == EMAVFI_BF16 && nb > 0 && deform16_lds_shape_host(P.dcn[0].ck, P.dcn[0].nf, P.dcn[0].cin_take))) {
+    if (p3) {
         // a second copy of offset_conv for the one-launch pack: f16 fragments (bf16 model: the bf16-rounded values), and in
         // the deform_pack3.inl layout where that kernel serves the shape (both 16-bit models); off[i] keeps the conv3x3 layout
         P.has_offh = true;
@@ -595,27 +593,7 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
     conv_work(P, P.r0, B, H, W, e, fl, by);
     EMAVFI_STEP(rec, conv_name(P, P.r0) + " reconstruction.0", fl, by,
                 run_conv(P, P.r0, packed, x, P.fps, H, W, f.fA, P.p_mid, 0, P.p_mid, EPI_RELU, B, s));
-    // 16-bit types at mid_channels = 64: reconstruction.1 and .2 can run as one launch whose 32-channel intermediate stays in
-    // the LDS (conv3x3.inl, conv3x3_tail_kernel; bit-identical to the two launches).  Built for VERDICT r1 item 4 and measured
-    // SLOWER (677 vs 362 + 232 us at B=8 x 720p: +33 % recomputed positions, one fragment per wave = no operand reuse, one
-    // workgroup per CU), so it is opt-in: EMAVFI_FUSED_TAIL=1 together with EMAVFI_CONV_MFMA16=0 (the tail kernel reads
-    // reconstruction.1's weights in the 32x32x16 packing).  Read per call: the parity test flips it inside one process.
-    const char *ft_ = getenv("EMAVFI_FUSED_TAIL");
-    const bool fused_tail_off = !(ft_ != nullptr && ft_[0] == '1');
-    if (P.esize == 2 && !fused_tail_off && !P.r1.mfma16 && P.r1.ck == 64 && P.r1.nf == 1 && P.r1.nchunk == 1 && P.r2.ck == 32 && P.r2.nf == 1 && P.r2.nchunk == 1) {
-        double fl2 = 0.0, by2 = 0.0;
-        conv_work(P, P.r1, B, H, W, e, fl, by);
-        conv_work(P, P.r2, B, H, W, 4.0, fl2, by2);
-        fl += fl2;
-        by += by2 - 2.0 * (double)B * H * W * f.p_half * e;   // the intermediate is neither written nor read
-        TailParams t{};
-        t.in = f.fA; t.in_ps = P.p_mid; t.H = H; t.W = W; t.B = B; t.nplanes = C; t.epi2 = EPI_PLANAR_TANH01; t.round16 = P.amp ? 1 : 0;
-        t.w1 = (const char *)packed + P.r1.w_off; t.bias1 = (const float *)((const char *)packed + P.r1.b_off);
-        t.w2 = (const char *)packed + P.r2.w_off; t.bias2 = (const float *)((const char *)packed + P.r2.b_off);
-        t.out_planar = out; t.zeros = (const char *)packed + P.zero_off;
-        EMAVFI_STEP(rec, std::string(P.dtype == EMAVFI_F16 ? "tail<f16" : "tail<bf16") + ",64-32-planes> reconstruction.1+.2(tanh)", fl, by,
-                    P.dtype == EMAVFI_F16 ? launch_conv_tail_f16(t, s) : launch_conv_tail_bf16(t, s));
-    } else {
+    {
         conv_work(P, P.r1, B, H, W, e, fl, by);
         EMAVFI_STEP(rec, conv_name(P, P.r1) + " reconstruction.1", fl, by,
                     run_conv(P, P.r1, packed, f.fA, P.p_mid, H, W, f.fB, f.p_half, 0, f.p_half, EPI_RELU, B, s));
@@ -902,8 +880,8 @@ int emavfi_deform_conv2d(const float *x, const float *offset, const float *mask,
     L.w_off = (char *)wp - (char *)workspace;
     L.b_off = (char *)bp - (char *)workspace;
     // the 16-bit LDS-window kernel contracts in f16 on chip: a bf16 call packs its bf16-rounded weights as f16 fragments
-    const bool h_of_b = dtype == EMAVFI_BF16 && deform16_lds_shape_host(L.ck, L.nf, L.cin_take);
     if (dtype != EMAVFI_F32 && deform_pack3_shape(L.ck, L.nf, L.cin_take, L.cout)) L.pack3 = 1;
+    const bool h_of_b = dtype == EMAVFI_BF16 && L.pack3 == 1;   // the LDS-window kernel contracts bf16-rounded weights stored as f16
     if (dtype == EMAVFI_F32 && deform_f32w_shape(L.ck, L.nf, L.cin_take, L.cout)) L.pack3 = 3;
     PackDesc d{L.cout, L.cin_raw, 0, L.cin_take, L.ck, 1, L.nf, 1, 0, h_of_b ? 1 : 0};
     d.pack3 = L.pack3;
