@@ -57,7 +57,7 @@
 extern "C" {
 #endif
 
-#define EMAVFI_VERSION 200 /* 0.2.0: EMAVFI_AMP16, 72-channel fusion pixels in the packed layout (round 2) */
+#define EMAVFI_VERSION 300 /* 0.3.0: packed-blob layout of the deformable packs, the fp32 DCN and feat_ext_conv1 changed (round 3): re-pack */
 
 #define EMAVFI_F32 0
 #define EMAVFI_BF16 1
