@@ -951,11 +951,14 @@ template <typename T, int CK, int NF> static int launch_conv_pingpong16(const Co
     return (int)hipGetLastError();
 }
 
-// weights packed for the 16x16x32 shape (ConvParams::mfma16): 64 -> 64 (four blocks), 64 -> 32 (two), 64 -> planes (one)
+#include "conv_light.inl"
+
+// weights packed for the 16x16x32 shape (ConvParams::mfma16): 64 -> 64 (four blocks), 64 -> 32 (two), 64 / 32 -> planes (one)
 template <typename T> static int launch_conv_mfma16(const ConvParams &p, hipStream_t s)
 {
-    if (p.ck != 64 || p.stride != 1 || p.nchunk != 1 || p.npass != 1) return -2;
     const bool planar = p.epi == EPI_PLANAR || p.epi == EPI_PLANAR_TANH01;
+    if (p.ck == 32 && p.stride == 1 && p.nchunk == 1 && p.npass == 1 && p.nf == 1 && planar && p.nplanes <= 4) return launch_conv_light<T, 32>(p, s);
+    if (p.ck != 64 || p.stride != 1 || p.nchunk != 1 || p.npass != 1) return -2;
     if (!planar && p.epi != EPI_NONE && p.epi != EPI_RELU) return -2;
     // 64 -> 64: the ping-pong schedule is the default here (530 vs 612 us; the step keeps 1.7 % of it after the board's clock
     // response); EMAVFI_CONV_PINGPONG=0 selects the lock-step kernel (read per call: parity test)
@@ -963,7 +966,11 @@ template <typename T> static int launch_conv_mfma16(const ConvParams &p, hipStre
     if (p.nf == 2 && !planar && !(pp_ != nullptr && pp_[0] == '0')) return launch_conv_pingpong16<T, 64, 2>(p, s);
     if (p.nf == 2 && !planar) return launch_conv_persist16<T, 64, 2, 4>(p, s);
     if (p.nf == 1 && !planar) return launch_conv_persist16<T, 64, 1, 2>(p, s);
-    if (p.nf == 1 && planar && p.nplanes <= 4) return launch_conv_persist16<T, 64, 1, 1>(p, s);
+    if (p.nf == 1 && planar && p.nplanes <= 4) {
+        const char *cl_ = getenv("EMAVFI_CONV_LIGHT");   // 0: the lock-step persistent kernel (A/B; read per call)
+        if (!(cl_ != nullptr && cl_[0] == '0')) return launch_conv_light<T, 64>(p, s);
+        return launch_conv_persist16<T, 64, 1, 1>(p, s);
+    }
     return -2;
 }
 

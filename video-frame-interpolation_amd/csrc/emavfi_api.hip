@@ -103,6 +103,8 @@ bool conv_geometry(Layer &L, int esize)
     // EMAVFI_CONV_MFMA16=0 keeps the 32x32x16 kernels (read per call: tests compare the two inside one process).
     const char *m16 = getenv("EMAVFI_CONV_MFMA16");
     L.mfma16 = esize == 2 && L.stride == 1 && L.ck == 64 && (L.nf == 2 || L.nf == 1) && L.nchunk == 1 && L.npass == 1 && !(m16 && m16[0] == '0');
+    // 32 -> <= 4 channels (reconstruction.2): the planar-head kernel on 16x16x32 (conv_light.inl) reads the same regrouped packing
+    if (esize == 2 && L.stride == 1 && L.ck == 32 && L.nf == 1 && L.nchunk == 1 && L.npass == 1 && L.cout <= 4 && !(m16 && m16[0] == '0')) L.mfma16 = true;
     return true;
 }
 
