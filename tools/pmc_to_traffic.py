@@ -35,8 +35,8 @@ def label(k):
     m = re.match(r"_Z24conv3x3_persist16_kernelI(DF16b|DF16_)Li64ELi1", k)
     if m:
         return f"conv3x3<{'bf16' if m.group(1) == 'DF16b' else 'f16'},ck=64,nf=1,s=1>"
-    m = re.match(r"_Z18conv3x3_s2w_kernelI(DF16b|DF16_)", k)
-    if m:  # context_encoding.0: one 64-channel chunk, waves split the output fragments (csrc/conv3x3.inl)
+    m = re.match(r"_Z21conv3x3_s2ring_kernelI(DF16b|DF16_)", k)
+    if m:  # context_encoding.0: weights in registers, input rows through an LDS ring (csrc/conv3x3.inl)
         return f"conv3x3<{'bf16' if m.group(1) == 'DF16b' else 'f16'},ck=64,nf=4,s=2>"
     m = re.match(r"_Z14conv3x3_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)EEv", k)
     if m:

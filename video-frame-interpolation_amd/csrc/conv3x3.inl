@@ -23,7 +23,8 @@
 // fetches of 32 consecutive pixels are bank-conflict free for stride 1.
 //
 // Kernels in this file (which layer runs where: launch_conv16 / launch_conv_mfma16 at the end):
-//   conv3x3_kernel            the tile-per-workgroup kernel described above (every shape; the only one for fp32, stride 2, chunked K)
+//   conv3x3_kernel            the tile-per-workgroup kernel described above (every shape; the only one for fp32, chunked K)
+//   conv3x3_s2ring_kernel     64 -> 128 at stride 2: weights in registers, input rows through an LDS ring (one strip per workgroup)
 //   conv3x3_persist_kernel    persistent, nine taps' weights resident, 16 x 32 tiles, 8 waves in lock step (32x32x16 MFMAs)
 //   conv3x3_persist16_kernel  the same on v_mfma_f32_16x16x32 with an unpadded XOR-swizzled tile: 64 -> 32 and 64 -> planes
 //   conv3x3_pingpong16_kernel two four-wave groups half a tile out of phase on that shape: the 64 -> 64 layers (product)
@@ -1002,142 +1003,167 @@ template <typename T, int CK, int NF, int WAVES> static int launch_conv_persist(
 
 
 // ------------------------------------------------------------------------------------------
-// context_encoding.0 (64 -> 128, stride 2: ema_vfi.py:80) without reading its input twice.  The tile-per-workgroup kernel takes
-// stride-2 layers in 32-channel chunks (a 64-channel 4 x 32 tile + weights would leave one workgroup per CU, which measured
-// slower), i.e. it DMAs 64 bytes of every 144-byte fusion pixel per chunk - and each chunk fetches every 128-byte line (PMC:
-// 2.75 GB for 1.42 GB algorithmic; the XCD's L2 does not hold the lines for the ~9 us between the two chunk passes: 64
-// workgroups x 47 KiB in flight per XCD are most of its 4 MiB).  Here the workgroup's four waves split the OUTPUT CHANNELS
-// instead of the rows: wave w owns tile row (w & 1) and fragments 2 (w >> 1), 2 (w >> 1) + 1 of the four; the tile is 2 x 32
-// outputs = 5 x 65 input pixels with all 64 channels (46 KiB, as before), weights 16 KiB per tap in a 2-slot ring: 79 KiB, two
-// workgroups per CU, every input line fetched once (vertical halo 5 / 4 instead of 9 / 8).
+// context_encoding.0 (64 -> 128, stride 2: ema_vfi.py:80): weights stationary in registers, input rows through an LDS ring.
+//
+// The tile-per-workgroup kernel takes stride-2 layers in 32-channel chunks (a 64-channel 4 x 32 tile + weights would leave one
+// workgroup per CU), i.e. it DMAs 64 bytes of every 144-byte fusion pixel per chunk - and each chunk fetches every 128-byte line
+// (PMC: 2.75 GB for 1.42 GB algorithmic; an XCD's L2 does not hold the lines for the ~9 us between the two chunk passes), and it
+// streams 144 KiB of weights through LDS per tile.  Here a workgroup walks DOWN a strip of 32 output columns:
+//   * wave w owns output fragment w (channels 32 w .. 32 w + 31) and keeps that fragment's 64 x 9 x 32 weights in 144 VGPRs for
+//     the whole walk: no weights in LDS, no per-tap barrier, one ds_read_b128 per MFMA;
+//   * input rows live in a ring of five (output row y reads input rows 2y-1, 2y, 2y+1; rows 2y+2, 2y+3 are in flight for y+1):
+//     every input row is DMA'd once per strip - no vertical halo at all, 65 / 64 horizontally;
+//   * a row's even and odd pixels are stored apart (pixel p -> slot (p >> 1) + 33 (p & 1)): lane r reads pixel 2r + dx, i.e.
+//     slot r + const at 144-byte pitch = 36 r dwords, distinct 4-bank groups for any 16 lanes a ds_read_b128 serves together
+//     (the interleaved order reads at 72 r dwords: two-way conflicts);
+//   * outputs go through a double-buffered LDS row (32 pixels x 256 bytes) so that a store instruction writes whole lines.
+// One barrier per output row.  A strip is cut into `nseg` vertical segments so that ~2 workgroups per CU exist.
 // ------------------------------------------------------------------------------------------
-template <typename T> struct ConvS2WCfg {
-    static constexpr int CK = 64, NF = 4, NFW = 2, S = 2, TH = 2, TW = 32, IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
-    static constexpr int PSTR = LdsPix<T, CK>::BYTES, PIECES = CK * (int)sizeof(T) / 16, SP = PSTR / 16, KG = CK / DT<T>::CHKG;
-    static constexpr int WTAP = KG * NF * 1024, WINST = KG * NF;
-    static constexpr int NSLOT = IH * IW * SP, NINST = (NSLOT + 63) / 64, LDS_IN = NINST * 1024, LDS_BYTES = LDS_IN + 2 * WTAP;
+template <typename T> struct ConvS2RCfg {
+    static constexpr int CK = 64, NFRAG = 4, PSTR = 144, IW = 65, SP = 9, ROWSLOT = IW * SP, ROWINST = (ROWSLOT + 63) / 64, ROWB = ROWINST * 1024;
+    static constexpr int RING = 5, STG_PX = NFRAG * 64 + 16, STG = 32 * STG_PX, LDS_BYTES = RING * ROWB + 2 * STG;
     static_assert(sizeof(T) == 2 && 2 * LDS_BYTES <= 160 * 1024, "16-bit types; two workgroups per CU");
 };
 
 template <typename T>
-__global__ __launch_bounds__(256, 2) void conv3x3_s2w_kernel(const ConvParams p)
+__global__ __launch_bounds__(256, 2) void conv3x3_s2ring_kernel(const ConvParams p, const int nseg, const int seg_rows)
 {
-    using C = ConvS2WCfg<T>;
+    using C = ConvS2RCfg<T>;
     using vec = typename DT<T>::vec;
-    constexpr int IW = C::IW, PSTR = C::PSTR, NFW = C::NFW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *lds_in = smem;
-    char *lds_w = smem + C::LDS_IN;
+    char *ring = smem;
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
+    typedef __attribute__((address_space(3))) char lchar_t;
+    typedef __attribute__((ext_vector_type(4))) unsigned u4_t;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int wrow = wave & 1, wfg = wave >> 1;
-    const int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
-    const int y = ty * C::TH + wrow, x = tx * 32 + r;
+    const int ntx = (p.Wout + 31) / 32, nstrip = ntx * p.B;
+    const int strip = (int)blockIdx.x % nstrip, seg = (int)blockIdx.x / nstrip;
+    const int b = strip / ntx, tx = strip - b * ntx;
+    const int ys = seg * seg_rows, ye = min(ys + seg_rows, p.Hout);
+    if (ys >= ye) return;   // workgroup-uniform
     const char *zeros = (const char *)p.zeros;
-    const int npieces = p.in_pieces > 0 ? p.in_pieces : C::PIECES;
-
-    f32x16 acc[NFW];
-#pragma unroll
-    for (int n = 0; n < NFW; ++n)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[n][i] = p.bias[(wfg * NFW + n) * 32 + acc_channel(i, h)];
-
-    const int iy0 = ty * C::TH * 2 - 1, ix0 = tx * 32 * 2 - 1;
+    const int npieces = p.in_pieces > 0 ? p.in_pieces : 8;
+    const unsigned pixbytes = (unsigned)p.in_ps * (unsigned)sizeof(T);
     const char *gin = (const char *)p.in + (size_t)b * p.Hin * p.Win * p.in_ps * sizeof(T);
+    const int ix0 = tx * 64 - 1;
+
+    // ---- this wave's fragment of the weights: 9 taps x 4 k-groups x (32 channels x 16 k), packed [tap][kg][fragment][lane][8]
+    vec wf[9][4];
+    {
+        const char *wb = (const char *)p.w + wave * 1024 + lane * 16;
 #pragma unroll
-    for (int i = 0; i < (C::NINST + 3) / 4; ++i) {
-        const int jn = i * 4 + wave;
-        if (jn < C::NINST) {
-            const int sl = jn * 64 + lane;
-            const int pix = sl / C::SP, pc = sl - pix * C::SP;
-            const int ly = pix / IW, lx = pix - ly * IW;
-            const char *src = conv_dma_src(gin, zeros, iy0 + ly, ix0 + lx, pc, p.Hin, p.Win, (unsigned)p.in_ps * (unsigned)sizeof(T), sl < C::NSLOT && pc < npieces && pc < C::PIECES);
-            __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)(lds_in + jn * 1024), 16, 0, 0);
-        }
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) wf[t][kg] = *reinterpret_cast<const vec *>(wb + (t * 4 + kg) * (C::NFRAG * 1024));
     }
-    const char *wc = (const char *)p.w;
-    auto issue_w = [&](int t) {   // this wave's four of the tap's sixteen 1-KiB fragments
+    // ---- DMA of one input row into one ring slot: ROWINST instructions, instruction jn covers 16-byte slots [64 jn, 64 jn + 64)
+    auto dma = [&](int gy, int slot, int jn) {
+        const int q = jn * 64 + lane;
+        const int ps = q / C::SP, pc = q - ps * C::SP;
+        const int px = ps < 33 ? 2 * ps : 2 * (ps - 33) + 1;   // even pixels first, then the odd ones
+        const char *src = conv_dma_src(gin, zeros, gy, ix0 + px, pc, p.Hin, p.Win, pixbytes, q < C::ROWSLOT && pc < npieces && pc < 8);
+        __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)(ring + slot * C::ROWB + jn * 1024), 16, 0, 0);
+    };
+    // rows 2 ys - 1 .. 2 ys + 1 -> slots (row + 1) % 5
+    int s0 = (2 * ys) % C::RING;   // slot of input row 2y - 1
+    for (int u = wave; u < 3 * C::ROWINST; u += 4) {
+        const int k = u / C::ROWINST, jn = u - k * C::ROWINST;
+        int sl = s0 + k; sl = sl >= C::RING ? sl - C::RING : sl;
+        dma(2 * ys - 1 + k, sl, jn);
+    }
+    float bias[16];
 #pragma unroll
-        for (int i = 0; i < C::WINST / 4; ++i) {
-            const int jn = i * 4 + wave;
-            __builtin_amdgcn_global_load_lds((gptr_t *)(wc + (size_t)t * C::WTAP + jn * 1024 + lane * 16), (lptr_t *)(lds_w + (t & 1) * C::WTAP + jn * 1024), 16, 0, 0);
+    for (int i = 0; i < 16; ++i) bias[i] = p.bias[wave * 32 + acc_channel(i, h)];
+    const bool relu = p.epi == EPI_RELU;
+    char *obase = reinterpret_cast<char *>(p.out) + (((size_t)b * p.Hout * p.Wout + (size_t)tx * 32) * p.out_ps + p.out_coff) * sizeof(T);
+    auto store_row = [&](int y) {
+        lchar_t *stg = (lchar_t *)smem + C::RING * C::ROWB + (y & 1) * C::STG;
+        char *orow = obase + (size_t)y * p.Wout * p.out_ps * sizeof(T);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = i * 256 + tid, px = q >> 4, ch = q & 15;
+            if (tx * 32 + px < p.Wout && ch * 8 < p.cstore)
+                *reinterpret_cast<u4_t *>(orow + (size_t)px * p.out_ps * sizeof(T) + ch * 16) =
+                    *reinterpret_cast<const __attribute__((address_space(3))) u4_t *>(stg + px * C::STG_PX + ch * 16);
         }
     };
-    issue_w(0);
-    __syncthreads();  // hipcc drains the DMA (vmcnt(0)) ahead of the barrier
 #pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
-        if (tap + 1 < 9) issue_w(tap + 1);   // the other ring slot was last read one barrier ago
-        const int dy = tap / 3, dx = tap - 3 * dy;
-        const char *xb = lds_in + ((wrow * 2 + dy) * IW + r * 2 + dx) * PSTR + h * 16;
-        const char *wb = lds_w + (tap & 1) * C::WTAP + lane * 16;
-#pragma unroll
-        for (int kg = 0; kg < C::KG; ++kg) {
-            const vec xv = *reinterpret_cast<const vec *>(xb + kg * 32);
-#pragma unroll
-            for (int n = 0; n < NFW; ++n) mma_kg(acc[n], *reinterpret_cast<const vec *>(wb + (kg * C::NF + wfg * NFW + n) * 1024), xv);
-        }
-        if (tap < 8) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-    }
-    // ---- epilogue: bias is in, optional ReLU; through LDS so that a store instruction writes whole 128-byte halves of pixels
-    {
-        typedef __attribute__((ext_vector_type(2))) T pair_t;
-        typedef __attribute__((ext_vector_type(4))) unsigned u4_t;
-        typedef __attribute__((address_space(3))) char lchar_t;
-        constexpr int STG_PX = NFW * 64 + 16;
+    for (int y = ys; y < ye; ++y) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the rows for y (and its stores of row y - 2)
         __syncthreads();
-        lchar_t *stg = (lchar_t *)smem + wave * (32 * STG_PX);
-        const bool relu = p.epi == EPI_RELU;
+        if (y > ys) store_row(y - 1);
+        if (y + 1 < ye) {   // rows 2y + 2, 2y + 3 -> slots s0 + 3, s0 + 4
 #pragma unroll
-        for (int n = 0; n < NFW; ++n)
+            for (int i = 0; i < (2 * C::ROWINST + 3) / 4; ++i) {
+                const int u = i * 4 + wave;
+                if (u < 2 * C::ROWINST) {
+                    const int k = u / C::ROWINST, jn = u - k * C::ROWINST;
+                    int sl = s0 + 3 + k; sl = sl >= C::RING ? sl - C::RING : sl;
+                    dma(2 * y + 2 + k, sl, jn);
+                }
+            }
+        }
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc[0][i] = bias[i]; acc[1][i] = 0.0f; }
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            int sl = s0 + dy; sl = sl >= C::RING ? sl - C::RING : sl;
+            const char *xb = ring + sl * C::ROWB + r * C::PSTR + h * 16;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                // pixel 2r + dx: even -> slot r + dx / 2, odd -> slot 33 + r
+                const char *xp = xb + (dx == 1 ? 33 : (dx >> 1)) * C::PSTR;
+#pragma unroll
+                for (int kg = 0; kg < 4; ++kg) mma_kg(acc[kg & 1], wf[dy * 3 + dx][kg], *reinterpret_cast<const vec *>(xp + kg * 32));
+            }
+        }
+        // ---- bias is in; optional ReLU; this wave's 32 channels of the row's 32 pixels into the row's staging buffer
+        {
+            typedef __attribute__((ext_vector_type(2))) T pair_t;
+            lchar_t *stg = (lchar_t *)smem + C::RING * C::ROWB + (y & 1) * C::STG + r * C::STG_PX + wave * 64;
 #pragma unroll
             for (int g = 0; g < 4; g += 2) {
                 unsigned a[2], c[2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    float v0 = acc[n][4 * g + 2 * q], v1 = acc[n][4 * g + 2 * q + 1], u0 = acc[n][4 * (g + 1) + 2 * q], u1 = acc[n][4 * (g + 1) + 2 * q + 1];
+                    float v0 = acc[0][4 * g + 2 * q] + acc[1][4 * g + 2 * q], v1 = acc[0][4 * g + 2 * q + 1] + acc[1][4 * g + 2 * q + 1];
+                    float u0 = acc[0][4 * (g + 1) + 2 * q] + acc[1][4 * (g + 1) + 2 * q], u1 = acc[0][4 * (g + 1) + 2 * q + 1] + acc[1][4 * (g + 1) + 2 * q + 1];
                     if (relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); u0 = fmaxf(u0, 0.0f); u1 = fmaxf(u1, 0.0f); }
                     const pair_t pa = {(T)v0, (T)v1}, pb = {(T)u0, (T)u1};
                     const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, pa), __builtin_bit_cast(unsigned, pb), false, false);
                     a[q] = sw[0]; c[q] = sw[1];
                 }
-                *reinterpret_cast<__attribute__((address_space(3))) u4_t *>(stg + r * STG_PX + (n * 32 + 8 * (g + h)) * 2) = u4_t{a[0], a[1], c[0], c[1]};
-            }
-        if (y < p.Hout) {
-            char *orow = reinterpret_cast<char *>(p.out) + ((((size_t)b * p.Hout + y) * p.Wout + (size_t)tx * 32) * p.out_ps + p.out_coff + wfg * NFW * 32) * sizeof(T);
-            const int limit = p.cstore - wfg * NFW * 32;
-            constexpr int NCH = NFW * 4;
-#pragma unroll
-            for (int i = 0; i < NCH / 2; ++i) {
-                const int q = i * 64 + lane, px = q / NCH, ch = q - px * NCH;
-                if (tx * 32 + px < p.Wout && ch * 8 < limit)
-                    *reinterpret_cast<u4_t *>(orow + (size_t)px * p.out_ps * sizeof(T) + ch * 16) =
-                        *reinterpret_cast<const __attribute__((address_space(3))) u4_t *>(stg + px * STG_PX + ch * 16);
+                *reinterpret_cast<__attribute__((address_space(3))) u4_t *>(stg + 16 * (g + h)) = u4_t{a[0], a[1], c[0], c[1]};
             }
         }
+        s0 += 2; s0 = s0 >= C::RING ? s0 - C::RING : s0;
     }
-    (void)x;
+    __syncthreads();
+    store_row(ye - 1);
 }
 
-template <typename T> static int launch_conv_s2w(const ConvParams &p, hipStream_t s)
+template <typename T> static int launch_conv_s2ring(const ConvParams &p, hipStream_t s)
 {
-    using C = ConvS2WCfg<T>;
+    using C = ConvS2RCfg<T>;
     if (p.ck != 64 || p.nf != 4 || p.stride != 2 || p.nchunk != 1 || p.npass != 1 || p.bias_mode != 0 || (p.epi != EPI_NONE && p.epi != EPI_RELU)) return -2;
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_s2w_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_s2ring_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     });
     if (attr_err != hipSuccess) return (int)attr_err;
-    dim3 grid((p.Wout + 31) / 32, (p.Hout + C::TH - 1) / C::TH, p.B);
-    conv3x3_s2w_kernel<T><<<grid, 256, C::LDS_BYTES, s>>>(p);
+    const int ncu = device_cu_count();
+    if (ncu <= 0) return (int)hipErrorInvalidDevice;
+    const int nstrip = ((p.Wout + 31) / 32) * p.B;
+    int nseg = (2 * ncu) / nstrip;   // two workgroups per CU in one round
+    nseg = nseg < 1 ? 1 : (nseg > p.Hout ? p.Hout : nseg);
+    const int seg_rows = (p.Hout + nseg - 1) / nseg;
+    nseg = (p.Hout + seg_rows - 1) / seg_rows;
+    conv3x3_s2ring_kernel<T><<<nstrip * nseg, 256, C::LDS_BYTES, s>>>(p, nseg, seg_rows);
     return (int)hipGetLastError();
 }
 
@@ -1163,7 +1189,7 @@ template <typename T> static int launch_conv_any(const ConvParams &p, hipStream_
 template <typename T> static int launch_conv16(const ConvParams &p, hipStream_t s, bool no_persistent)
 {
     if (p.mfma16) return launch_conv_mfma16<T>(p, s);
-    if (p.s2w) return launch_conv_s2w<T>(p, s);
+    if (p.s2ring) return launch_conv_s2ring<T>(p, s);
     if (!no_persistent && p.stride == 1 && p.nchunk == 1 && p.npass == 1) {
         // measured at B=8 x 720p in bf16 (us per launch, tile-per-workgroup -> persistent): 64->64 670 -> 644,
         // 64->32 / 64->2 414 -> 370, 67->27 685 -> 557.  NOT used where it loses: 67->64 with 4 waves

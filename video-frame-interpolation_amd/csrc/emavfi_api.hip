@@ -57,7 +57,7 @@ struct Layer {
     bool f16_of_bf16 = false;  // bf16 model, layer consumed by deform_pack_kernel: bf16-rounded weights stored as f16
     bool mfma16 = false;       // packed for and run by conv3x3_persist16_kernel (v_mfma_f32_16x16x32): 16-bit full-resolution 64 -> (1..64) layers
     int pack3 = 0;             // deform_pack3.inl layouts: 1 = DCN, 2 = offset_conv (f16 elements)
-    bool s2w = false;          // stride 2, 64 -> 128: conv3x3_s2w_kernel (packing = the regular one for ck 64, nf 4)
+    bool s2ring = false;          // stride 2, 64 -> 128: conv3x3_s2ring_kernel (packing = the regular one for ck 64, nf 4)
     bool first6 = false;       // feat_ext_conv1 at mid_channels 64, 16-bit: a second copy of the weights in conv_first.inl's layout (10 KiB)
 };
 
@@ -72,11 +72,11 @@ bool conv_geometry(Layer &L, int esize)
     // these layers are not bound by the over-fetch but by how little of a tile's DMA / MFMA / store phases one
     // workgroup per CU can overlap.  Kept as an experiment switch, not the default.
     static const bool s2_ck64 = getenv("EMAVFI_CONV_S2_CK64") != nullptr;
-    // 64 -> 128 at stride 2 (context_encoding.0): one 64-channel chunk, the four waves split the four output fragments
-    // (conv3x3.inl, conv3x3_s2w_kernel); EMAVFI_CONV_S2W=0 keeps the 32-channel-chunk plan (changes the packing: set before packing)
-    static const bool s2w_off = [] { const char *e = getenv("EMAVFI_CONV_S2W"); return e && e[0] == '0'; }();
-    L.s2w = L.stride == 2 && esize == 2 && L.cin_pad == 64 && (L.cout + 31) / 32 == 4 && !s2w_off;
-    if (L.s2w) {
+    // 64 -> 128 at stride 2 (context_encoding.0): one 64-channel chunk, each wave keeps one output fragment's weights in registers
+    // (conv3x3.inl, conv3x3_s2ring_kernel); EMAVFI_CONV_S2RING=0 keeps the 32-channel-chunk plan (changes the packing: set before packing)
+    static const bool s2r_off = [] { const char *e = getenv("EMAVFI_CONV_S2RING"); return e && e[0] == '0'; }();
+    L.s2ring = L.stride == 2 && esize == 2 && L.cin_pad == 64 && (L.cout + 31) / 32 == 4 && !s2r_off;
+    if (L.s2ring) {
         L.ck = 64; L.nchunk = 1; L.nf = 4; L.npass = 1; L.coutpad = 128;
         L.w_bytes = (size_t)9 * 4 * 4 * 1024;
         L.mfma16 = false;
@@ -290,7 +290,7 @@ int run_conv(const Plan &P, const Layer &L, const void *packed, const void *in, 
     c.Hout = (Hin + L.stride - 1) / L.stride; c.Wout = (Win + L.stride - 1) / L.stride;
     c.B = B; c.nchunk = L.nchunk; c.npass = L.npass; c.cstore = cstore;
     c.epi = epi; c.nplanes = nplanes; c.bias_mode = bias_table ? 1 : 0;
-    c.ck = L.ck; c.nf = L.nf; c.stride = L.stride; c.mfma16 = L.mfma16 ? 1 : 0; c.s2w = L.s2w ? 1 : 0;
+    c.ck = L.ck; c.nf = L.nf; c.stride = L.stride; c.mfma16 = L.mfma16 ? 1 : 0; c.s2ring = L.s2ring ? 1 : 0;
     return P.dtype == EMAVFI_F32 ? launch_conv3x3_f32(c, s) : P.dtype == EMAVFI_F16 ? launch_conv3x3_f16(c, s) : launch_conv3x3_bf16(c, s);
 }
 
