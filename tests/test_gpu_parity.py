@@ -488,9 +488,10 @@ for dt in ("bf16", "fp16", "fp32"):
 @pytest.mark.parametrize("cout,act", [(64, "relu"), (48, "none")])
 @pytest.mark.parametrize("shape", [(2, 75, 131), (1, 8, 32), (1, 17, 33), (2, 40, 64), (1, 360, 640)])
 def test_pingpong16_equals_the_lockstep_16x16x32_kernel(dtype, cout, act, shape, monkeypatch):
-    """The product kernel of the 64 -> 64 layers (conv3x3_pingpong16_kernel) against conv3x3_persist16_kernel
+    """Round 2's kernel of the 64 -> 64 layers (conv3x3_pingpong16_kernel, EMAVFI_CONV_RING=0) against conv3x3_persist16_kernel
     (EMAVFI_CONV_PINGPONG=0): same MFMA shape, same accumulation order - bit-identical; one tile, odd tile counts per group,
     tiles hanging over every edge."""
+    monkeypatch.setenv("EMAVFI_CONV_RING", "0")
     B, H, W = shape
     g = torch.Generator().manual_seed(13)
     x = torch.randn(B, 64, H, W, generator=g).to(DEV)
@@ -512,7 +513,9 @@ def test_mfma16_conv_agrees_with_the_32x32_kernels(dtype, cout, act, shape, monk
     """conv3x3_persist16_kernel (v_mfma_f32_16x16x32, the product path for 16-bit 64 -> 33..64 layers) against the 32x32x16
     kernels it replaces (EMAVFI_CONV_MFMA16=0): the fp32 accumulation groups 32 instead of 16 channels per MFMA, so the two
     agree to fp32 rounding - after rounding to the storage type at most one unit in the last place, and almost everywhere
-    exactly.  (Accuracy against ATen is gated by test_conv3x3_matches_aten for both.)"""
+    exactly.  (Accuracy against ATen is gated by test_conv3x3_matches_aten for both.)  EMAVFI_CONV_RING=0: the 33..64-channel
+    outputs are the ring kernel's in the product (next test)."""
+    monkeypatch.setenv("EMAVFI_CONV_RING", "0")
     B, H, W = shape
     g = torch.Generator().manual_seed(11)
     x = torch.randn(B, 64, H, W, generator=g).to(DEV)
@@ -531,6 +534,35 @@ def test_mfma16_conv_agrees_with_the_32x32_kernels(dtype, cout, act, shape, monk
     assert (err <= ulp * ref.abs().clamp_min(2.0 ** -6)).all(), f"max {err.max().item():.3e}"
     if act == "tanh01":
         return
+    assert (err > 0).float().mean().item() < 0.02, "the two kernels should differ in rare last-place roundings only"
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("cin,cout,act", [(64, 64, "relu"), (64, 48, "none"), (64, 33, "relu"), (67, 64, "relu"), (67, 40, "none"), (65, 64, "none")])
+@pytest.mark.parametrize("shape", [(2, 75, 131), (1, 1, 5), (1, 2, 64), (1, 17, 65), (3, 40, 128), (1, 360, 640)])
+def test_ring_conv_agrees_with_the_tile_kernels(dtype, cin, cout, act, shape, monkeypatch):
+    """conv3x3_ring_kernel (weights in registers, input rows through an LDS ring, the im2col tail for channels 64..66: the product
+    path of the 16-bit 64..67 -> 33..64 layers) against round 2's plans (EMAVFI_CONV_RING=0, EMAVFI_CONV_MFMA16=0: the 32x32x16
+    tile / persistent kernels at CK = 64 or 80).  Same rounded operands and products; the ring kernel accumulates even and odd
+    k-groups in two chains (and the tail first), so the two agree to fp32 rounding - after rounding to the storage type at most
+    one unit in the last place, and almost everywhere exactly.  Shapes: one row, one strip, a strip of one column, several
+    segments per strip (360 rows), several samples."""
+    B, H, W = shape
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(B, cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV)
+    kw = dict(dtype=dtype, act=lib.ACT_RELU if act == "relu" else lib.ACT_NONE)
+    monkeypatch.setenv("EMAVFI_CONV_RING", "0")
+    monkeypatch.setenv("EMAVFI_CONV_MFMA16", "0")
+    ref = lib.conv3x3(x, w, b, **kw).clone()
+    monkeypatch.delenv("EMAVFI_CONV_RING")
+    monkeypatch.delenv("EMAVFI_CONV_MFMA16")
+    got = lib.conv3x3(x, w, b, **kw).clone()
+    assert torch.isfinite(got).all() and got.shape == ref.shape
+    ulp = 2.0 ** (-7 if dtype == "bf16" else -10)
+    err = (got - ref).abs()
+    assert (err <= ulp * ref.abs().clamp_min(2.0 ** -6)).all(), f"max {err.max().item():.3e}"
     assert (err > 0).float().mean().item() < 0.02, "the two kernels should differ in rare last-place roundings only"
 
 

@@ -160,7 +160,8 @@ struct ConvParams {
     int round16;         // EMAVFI_AMP16: fp32-stored results (flow, offsets / masks, the frame) hold fp16-rounded values and
                          // sigmoid / tanh / (t+1)/2 round after every op, as fp16 tensors do under autocast
     int mfma16;          // weights packed for v_mfma_f32_16x16x32 (conv3x3_persist16_kernel): [tap][k32][cout16 block][lane][16 B]
-    int s2ring;             // stride 2, 64 -> 128 (context_encoding.0): conv3x3_s2ring_kernel (weights in registers, input rows through an LDS ring)
+    int ring;            // weights in registers, input rows through an LDS ring: 1 = conv3x3_s2ring_kernel (64 -> 128 at stride 2, context_encoding.0),
+                         // 2 = conv3x3_ring_kernel (64 -> 64), 3 = the same with the im2col tail (65..67 -> 64: reconstruction.0)
     int in_pieces;       // 16-byte pieces of an input pixel (single-chunk layers) that exist in memory; 0 = all CK of them.
                          // Pieces beyond read as zeros: the 72-channel fusion buffers feed CK = 80 layers this way.
 };

@@ -25,9 +25,10 @@
 // Kernels in this file (which layer runs where: launch_conv16 / launch_conv_mfma16 at the end):
 //   conv3x3_kernel            the tile-per-workgroup kernel described above (every shape; the only one for fp32, chunked K)
 //   conv3x3_s2ring_kernel     64 -> 128 at stride 2: weights in registers, input rows through an LDS ring (one strip per workgroup)
+//   conv3x3_ring_kernel       (conv_ring.inl) that structure at stride 1: the 64 -> 64 layers and reconstruction.0 (67 -> 64) (product)
 //   conv3x3_persist_kernel    persistent, nine taps' weights resident, 16 x 32 tiles, 8 waves in lock step (32x32x16 MFMAs)
 //   conv3x3_persist16_kernel  the same on v_mfma_f32_16x16x32 with an unpadded XOR-swizzled tile: 64 -> 32 and 64 -> planes
-//   conv3x3_pingpong16_kernel two four-wave groups half a tile out of phase on that shape: the 64 -> 64 layers (product)
+//   conv3x3_pingpong16_kernel two four-wave groups half a tile out of phase on that shape: the 64 -> 64 layers (EMAVFI_CONV_RING=0)
 //   (round 2's conv3x3_pingpong_kernel - the schedule on 32x32x16 MFMAs - and conv3x3_tail_kernel - reconstruction.1 + .2 through
 //    the LDS - were measurement-only experiments that lost and were removed in round 3)
 #include "common.h"
@@ -953,6 +954,7 @@ template <typename T, int CK, int NF> static int launch_conv_pingpong16(const Co
 }
 
 #include "conv_light.inl"
+#include "conv_ring.inl"
 
 // weights packed for the 16x16x32 shape (ConvParams::mfma16): 64 -> 64 (four blocks), 64 -> 32 (two), 64 / 32 -> planes (one)
 template <typename T> static int launch_conv_mfma16(const ConvParams &p, hipStream_t s)
@@ -1109,16 +1111,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2ring_kernel(const ConvParams
         f32x16 acc[2];
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc[0][i] = bias[i]; acc[1][i] = 0.0f; }
+        {
+            // operands three k-groups ahead of their MFMAs (fenced: the scheduler otherwise sinks every read to just above its MFMA)
+            constexpr int AH = 3;
+            const char *xb[3];
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            int sl = s0 + dy; sl = sl >= C::RING ? sl - C::RING : sl;
-            const char *xb = ring + sl * C::ROWB + r * C::PSTR + h * 16;
+            for (int dy = 0; dy < 3; ++dy) {
+                int sl = s0 + dy; sl = sl >= C::RING ? sl - C::RING : sl;
+                xb[dy] = ring + sl * C::ROWB + r * C::PSTR + h * 16;
+            }
+            // pixel 2r + dx: even -> slot r + dx / 2, odd -> slot 33 + r
+            auto xptr = [&](int n) { const int dx = (n / 4) % 3; return xb[n / 12] + (dx == 1 ? 33 : (dx >> 1)) * C::PSTR + (n & 3) * 32; };
+            vec xq[AH + 1];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                // pixel 2r + dx: even -> slot r + dx / 2, odd -> slot 33 + r
-                const char *xp = xb + (dx == 1 ? 33 : (dx >> 1)) * C::PSTR;
+            for (int s = 0; s < AH; ++s) xq[s] = *reinterpret_cast<const vec *>(xptr(s));
 #pragma unroll
-                for (int kg = 0; kg < 4; ++kg) mma_kg(acc[kg & 1], wf[dy * 3 + dx][kg], *reinterpret_cast<const vec *>(xp + kg * 32));
+            for (int s = 0; s < 36; ++s) {
+                if (s + AH < 36) xq[(s + AH) % (AH + 1)] = *reinterpret_cast<const vec *>(xptr(s + AH));
+                mma_kg(acc[s & 1], wf[s >> 2][s & 3], xq[s % (AH + 1)]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // ---- bias is in; optional ReLU; this wave's 32 channels of the row's 32 pixels into the row's staging buffer
@@ -1189,7 +1201,8 @@ template <typename T> static int launch_conv_any(const ConvParams &p, hipStream_
 template <typename T> static int launch_conv16(const ConvParams &p, hipStream_t s, bool no_persistent)
 {
     if (p.mfma16) return launch_conv_mfma16<T>(p, s);
-    if (p.s2ring) return launch_conv_s2ring<T>(p, s);
+    if (p.ring == 1) return launch_conv_s2ring<T>(p, s);
+    if (p.ring >= 2) return launch_conv_ring<T>(p, s);
     if (!no_persistent && p.stride == 1 && p.nchunk == 1 && p.npass == 1) {
         // measured at B=8 x 720p in bf16 (us per launch, tile-per-workgroup -> persistent): 64->64 670 -> 644,
         // 64->32 / 64->2 414 -> 370, 67->27 685 -> 557.  NOT used where it loses: 67->64 with 4 waves

@@ -1,0 +1,285 @@
+// conv_ring.inl - the 64 -> 64 layers (feat_ext_blocks, motion_estimation.0 / .1: ema_vfi.py:74-76, 90-91) and reconstruction.0
+// (67 -> 64: ema_vfi.py:103) with the weights stationary in registers and the input rows in an LDS ring.  Included by conv3x3.inl.
+//
+// The structure of conv3x3_s2ring_kernel at stride 1 (measured there: 543 -> 343 us against a tile kernel that streamed weights
+// through LDS), for the layers conv3x3_pingpong16_kernel served at 533 us = 4.15 TB/s of real HBM traffic, 17 % of it vertical halo:
+//   * a workgroup of four waves walks DOWN a strip of 64 output columns, one output row per step, one barrier per step;
+//   * wave w owns output fragment (w & 1) (channels 32 (w & 1) .. + 31) of column block (w >> 1) (32 pixels) and keeps the
+//     fragment's 64 x 9 x 32 weights in 144 VGPRs for the whole kernel: no weights in LDS, one ds_read_b128 per MFMA;
+//   * input rows live in a ring of D + 2 (output row y reads rows y-1, y, y+1; rows y+2 .. y+D are in flight, D = 3: an HBM
+//     round trip under load is several steps long): every input row is DMA'd once per strip segment - no vertical halo,
+//     66 / 64 horizontally.  The DMA is issued from inline asm and drained by a COUNTED s_waitcnt: hipcc drains every
+//     __builtin_amdgcn_global_load_lds it knows of (vmcnt(0)) in front of the next ds_read and of __syncthreads(), which made the
+//     prefetch one step deep at best.  Every wave therefore issues exactly 3 DMA + 2 store instructions per step (dummy DMA
+//     into a scratch KiB, stores as buffer stores whose out-of-range lanes are dropped instead of branched over), so that "all
+//     but the youngest 2 + 5 (D - 2)" retires exactly the row the step needs;  Pixels keep the 144-byte pitch of the fusion tensors
+//     (36 dwords: conflict-free for the 16 lanes a ds_read_b128 serves together); 128-byte inputs get a zero ninth piece;
+//   * TAIL (reconstruction.0): channels 64..66 of the nine taps are three more k-groups, K = 16 j + 8 h + e <-> tap slot
+//     4 j + 2 h + (e >> 2), channel 64 + (e & 3) (deform_pack3.inl's im2col tail): 39 MFMAs per row instead of the 45 of CK = 80,
+//     operands straight from the ninth piece of the ring pixels (two ds_read_b64);
+//   * outputs go through a double-buffered LDS row (64 pixels x 128 bytes) so that a store instruction writes whole lines;
+//   * work items = (strip, vertical segment), dealt round-robin to 2 workgroups per CU; the host picks the segment height so
+//     that the item count fills whole rounds (launch_conv_ring).
+#ifndef EMAVFI_RING_DEPTH
+#define EMAVFI_RING_DEPTH 3
+#endif
+#ifndef EMAVFI_RING_AHEAD
+#define EMAVFI_RING_AHEAD 4
+#endif
+template <typename T, bool TAIL> struct ConvRingCfg {
+    static constexpr int PSTR = 144, SP = 9, TW = 64, IW = TW + 2, ROWSLOT = IW * SP, ROWINST = (ROWSLOT + 63) / 64, ROWB = ROWINST * 1024;
+    static constexpr int D = EMAVFI_RING_DEPTH, RING = D + 2, STG_PX = 128 + 16, STG = TW * STG_PX, BIAS_OFF = RING * ROWB + 2 * STG;
+    static constexpr int SCRATCH_OFF = BIAS_OFF + 16 * 64 * 4, LDS_BYTES = SCRATCH_OFF + 1024;
+    static constexpr int NDMA = (ROWINST + 3) / 4, NSTORE = 2, VMWAIT = NSTORE + (NDMA + NSTORE) * (D - 2);
+    static constexpr int WMAIN = 9 * 4 * 2 * 1024;   // bytes of [tap][kg][fragment][lane][8]; the tail [j 3][fragment][lane][8] follows
+    static_assert(sizeof(T) == 2 && 2 * LDS_BYTES <= 160 * 1024, "16-bit types; two workgroups per CU");
+};
+
+template <typename T, bool TAIL>
+__global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p, const int nseg, const int seg_rows)
+{
+    using C = ConvRingCfg<T, TAIL>;
+    using vec = typename DT<T>::vec;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *ring = smem;
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    typedef __attribute__((address_space(3))) char lchar_t;
+    typedef __attribute__((ext_vector_type(4))) unsigned u4_t;
+    typedef __attribute__((ext_vector_type(2))) unsigned u2_t;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned lds0 = (unsigned)(size_t)(lchar_t *)smem;
+    const int r = lane & 31, h = lane >> 5;
+    const int frag = wave & 1, cb = wave >> 1;
+    const int ntx = (p.Wout + C::TW - 1) / C::TW, nstrip = ntx * p.B, nitems = nstrip * nseg;
+    const char *zeros = (const char *)p.zeros;
+    const int npieces = TAIL ? 9 : 8;   // pieces of an input pixel that are read (a 64-channel layer never reads the ninth)
+    const unsigned pixbytes = (unsigned)p.in_ps * (unsigned)sizeof(T);
+    const unsigned rowbytes = (unsigned)p.Win * pixbytes;
+    const bool relu = p.epi == EPI_RELU;
+
+    // ---- this wave's fragment of the weights
+    vec wf[9][4], wt[TAIL ? 3 : 1];
+    {
+        const char *wb = (const char *)p.w + frag * 1024 + lane * 16;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) wf[t][kg] = *reinterpret_cast<const vec *>(wb + (t * 4 + kg) * 2048);
+        if (TAIL) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) wt[j] = *reinterpret_cast<const vec *>(wb + C::WMAIN + j * 2048);
+        }
+    }
+    // ---- lane constants of the row DMA: instruction jn covers 16-byte slots [64 jn, 64 jn + 64) of a ring row
+    unsigned xoff[C::NDMA];
+    unsigned xcol[C::NDMA];
+#pragma unroll
+    for (int i = 0; i < C::NDMA; ++i) {
+        const int q = (i * 4 + wave) * 64 + lane;
+        const int px = q / C::SP, pc = q - px * C::SP;
+        xoff[i] = (unsigned)px * pixbytes + (unsigned)pc * 16u;
+        xcol[i] = (q < C::ROWSLOT && pc < npieces) ? (unsigned)px : 0x40000000u;   // far outside any image: the zero page
+    }
+    // the tail's two 8-byte reads per k-group: this lane half's tap slots 4 j + 2 h, 4 j + 2 h + 1
+    int tdy[6], tdx[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int ts = 4 * (k >> 1) + 2 * h + (k & 1), tap = ts < 9 ? ts : 8;
+        tdy[k] = tap / 3;
+        tdx[k] = tap - 3 * tdy[k];
+    }
+
+#pragma unroll 1
+    for (int item = (int)blockIdx.x; item < nitems; item += (int)gridDim.x) {
+        const int strip = item % nstrip, seg = item / nstrip;
+        const int b = strip / ntx, tx = strip - b * ntx;
+        const int ys = seg * seg_rows, ye = min(ys + seg_rows, p.Hout);
+        const char *gin = (const char *)p.in + (size_t)b * p.Hin * p.Win * p.in_ps * sizeof(T);
+        const int ix0 = tx * C::TW - 1;
+        // exactly NDMA instructions per wave (instruction slots past the row land in a scratch KiB; rows outside the image, or
+        // not needed by this segment, read the zero page)
+        auto dma_row = [&](int gy, int slot, bool live) {
+            const bool rowok = live && (unsigned)gy < (unsigned)p.Hin;   // wave-uniform
+            const char *rowp = gin + (size_t)(rowok ? gy : 0) * rowbytes + (ptrdiff_t)ix0 * (ptrdiff_t)pixbytes;
+#pragma unroll
+            for (int i = 0; i < C::NDMA; ++i) {
+                const int jn = i * 4 + wave_u;
+                const bool ok = rowok && (unsigned)(ix0 + (int)xcol[i]) < (unsigned)p.Win;
+                const char *src = ok ? rowp + xoff[i] : zeros;
+                const unsigned dst = lds0 + (jn < C::ROWINST ? (unsigned)(slot * C::ROWB + jn * 1024) : (unsigned)C::SCRATCH_OFF);
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory");
+            }
+        };
+        // the bias table in LDS: [border class 0..15][64] floats (bias_mode 0: one class) - no global loads inside the row loop
+        // (hipcc would wait for them with vmcnt(0), i.e. for the whole DMA ring)
+        {
+            const f32x4 *bsrc = reinterpret_cast<const f32x4 *>(p.bias + (p.bias_mode == 1 ? (size_t)b * 16 * 64 : 0));
+            if (tid < (p.bias_mode == 1 ? 256 : 16)) reinterpret_cast<f32x4 *>(smem + C::BIAS_OFF)[tid] = bsrc[tid];
+        }
+        const int xg = tx * C::TW + cb * 32 + r;   // this lane's output column
+        const int xm = (xg >= 1 ? 1 : 0) | (xg <= p.Wout - 2 ? 2 : 0);
+
+        char *obase = reinterpret_cast<char *>(p.out) + (((size_t)b * p.Hout * p.Wout + (size_t)tx * C::TW) * p.out_ps + p.out_coff) * sizeof(T);
+        const int npx = min(C::TW, p.Wout - tx * C::TW);
+        unsigned soff[C::NSTORE];
+#pragma unroll
+        for (int i = 0; i < C::NSTORE; ++i) {
+            const int q = i * 256 + tid, px = q >> 3, ch = q & 7;
+            soff[i] = (px < npx && ch * 8 < p.cstore) ? (unsigned)px * (unsigned)p.out_ps * (unsigned)sizeof(T) + ch * 16u : 0x80000000u;
+        }
+        auto store_row = [&](int y, bool real) {   // exactly NSTORE instructions; lanes outside the image (or !real) are dropped by the range check
+            lchar_t *stg = (lchar_t *)smem + C::RING * C::ROWB + (y & 1) * C::STG;
+            char *orow = obase + (size_t)(real ? y : ys) * p.Wout * p.out_ps * sizeof(T);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(orow, 0, real ? 0x7ffffff0 : 0, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < C::NSTORE; ++i) {
+                const int q = i * 256 + tid, px = q >> 3, ch = q & 7;
+                const u4_t v = *reinterpret_cast<const __attribute__((address_space(3))) u4_t *>(stg + px * C::STG_PX + ch * 16);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs, soff[i], 0, 0);
+            }
+        };
+        // rows ys - 1 .. ys + D - 1 -> slots 0 .. D, each followed by NSTORE dropped stores: the steady state's instruction pattern
+#pragma unroll 1
+        for (int k = 0; k <= C::D; ++k) {
+            dma_row(ys - 1 + k, k, ys - 1 + k <= ye);
+            store_row(ys, false);
+        }
+        int s0 = 0;   // ring slot of input row y - 1
+#pragma unroll 1
+        for (int y = ys; y < ye; ++y) {
+            // this wave's part of input row y + 1 (all but the youngest VMWAIT instructions) and its LDS writes of row y - 1
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C::VMWAIT) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            {
+                int sl = s0 + C::D + 1; sl = sl >= C::RING ? sl - C::RING : sl;
+                dma_row(y + C::D, sl, y + C::D <= ye);
+            }
+            store_row(y - 1, y > ys);
+            f32x16 acc[2];
+            {
+                // motion_estimation.0 (bias_mode 1): the folded context half depends on the pixel's border class
+                const int ym = (y >= 1 ? 1 : 0) | (y <= p.Hout - 2 ? 2 : 0), cls = p.bias_mode == 1 ? ym * 4 + xm : 0;
+                const f32x4 *lb = reinterpret_cast<const f32x4 *>(smem + C::BIAS_OFF + (cls * 64 + frag * 32 + 4 * h) * 4);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = lb[2 * g];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[0][4 * g + e] = v[e];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[1][i] = 0.0f;
+            const char *xl = ring + (cb * 32 + r) * C::PSTR + h * 16;
+            if (TAIL) {
+                const char *tl = ring + (cb * 32 + r) * C::PSTR + 128;
+                int toff[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    int sl = s0 + tdy[k]; sl = sl >= C::RING ? sl - C::RING : sl;
+                    toff[k] = sl * C::ROWB + tdx[k] * C::PSTR;
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    u2_t lo = *reinterpret_cast<const u2_t *>(tl + toff[2 * j]);
+                    u2_t hi = *reinterpret_cast<const u2_t *>(tl + toff[2 * j + 1]);
+                    if (j == 2) {   // tap slots 9..11 do not exist: zero operand (their weights are zero, but 0 x Inf is not)
+                        const unsigned keep0 = h ? 0u : ~0u;
+                        lo[0] &= keep0; lo[1] &= keep0; hi[0] = 0u; hi[1] = 0u;
+                    }
+                    const u4_t xv = {lo[0], lo[1], hi[0], hi[1]};
+                    mma_kg(acc[j & 1], wt[j], __builtin_bit_cast(vec, xv));
+                }
+            }
+            {
+                // operands EMAVFI_RING_AHEAD k-groups ahead of their MFMAs: one wave's read -> MFMA chain must not expose the LDS latency
+                constexpr int AH = TAIL ? EMAVFI_RING_AHEAD - 1 : EMAVFI_RING_AHEAD;   // (TAIL: 12 more weight registers)
+                const char *xb[3];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    int sl = s0 + dy; sl = sl >= C::RING ? sl - C::RING : sl;
+                    xb[dy] = xl + sl * C::ROWB;
+                }
+                vec xq[AH + 1];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < AH; ++s) xq[s] = *reinterpret_cast<const vec *>(xb[s / 12] + ((s / 4) % 3) * C::PSTR + (s & 3) * 32);
+#pragma unroll
+                for (int s = 0; s < 36; ++s) {
+                    if (s + AH < 36) {
+                        const int n = s + AH;
+                        xq[n % (AH + 1)] = *reinterpret_cast<const vec *>(xb[n / 12] + ((n / 4) % 3) * C::PSTR + (n & 3) * 32);
+                    }
+                    mma_kg(acc[s & 1], wf[s >> 2][s & 3], xq[s % (AH + 1)]);
+                    __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks every read to just above its MFMA)
+                }
+            }
+            // ---- optional ReLU; this wave's 32 channels of its 32 pixels into the row's staging buffer
+            {
+                typedef __attribute__((ext_vector_type(2))) T pair_t;
+                lchar_t *stg = (lchar_t *)smem + C::RING * C::ROWB + (y & 1) * C::STG + (cb * 32 + r) * C::STG_PX + frag * 64;
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    unsigned a[2], c[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        float v0 = acc[0][4 * g + 2 * q] + acc[1][4 * g + 2 * q], v1 = acc[0][4 * g + 2 * q + 1] + acc[1][4 * g + 2 * q + 1];
+                        float u0 = acc[0][4 * (g + 1) + 2 * q] + acc[1][4 * (g + 1) + 2 * q], u1 = acc[0][4 * (g + 1) + 2 * q + 1] + acc[1][4 * (g + 1) + 2 * q + 1];
+                        if (relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); u0 = fmaxf(u0, 0.0f); u1 = fmaxf(u1, 0.0f); }
+                        const pair_t pa = {(T)v0, (T)v1}, pb = {(T)u0, (T)u1};
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, pa), __builtin_bit_cast(unsigned, pb), false, false);
+                        a[q] = sw[0]; c[q] = sw[1];
+                    }
+                    *reinterpret_cast<__attribute__((address_space(3))) u4_t *>(stg + 16 * (g + h)) = u4_t{a[0], a[1], c[0], c[1]};
+                }
+            }
+            s0 = s0 + 1 >= C::RING ? 0 : s0 + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the next item primes the same slots)
+        __syncthreads();
+        store_row(ye - 1, true);
+    }
+}
+
+// Segment height: the item count should fill whole rounds of the 2-per-CU grid (a strip's segment re-reads two halo rows).
+static void conv_ring_segments(int nstrip, int Hout, int grid, int *nseg_out, int *seg_rows_out)
+{
+    double best = -1.0;
+    int bn = 1, br = Hout;
+    for (int nseg = 1; nseg <= (Hout + 7) / 8; ++nseg) {
+        const int rows = (Hout + nseg - 1) / nseg, ns = (Hout + rows - 1) / rows;
+        const long items = (long)nstrip * ns, rounds = (items + grid - 1) / grid;
+        const double eff = (double)items / (double)(rounds * grid) * (double)rows / (double)(rows + 2);
+        if (eff > best + 1e-9) { best = eff; bn = ns; br = rows; }
+    }
+    *nseg_out = bn;
+    *seg_rows_out = br;
+}
+
+template <typename T, bool TAIL> static int launch_conv_ring_t(const ConvParams &p, hipStream_t s)
+{
+    using C = ConvRingCfg<T, TAIL>;
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_ring_kernel<T, TAIL>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    });
+    if (attr_err != hipSuccess) return (int)attr_err;
+    const int ncu = device_cu_count();
+    if (ncu <= 0) return (int)hipErrorInvalidDevice;
+    const int nstrip = ((p.Wout + C::TW - 1) / C::TW) * p.B, grid = 2 * ncu;
+    int nseg, seg_rows;
+    conv_ring_segments(nstrip, p.Hout, grid, &nseg, &seg_rows);
+    const int nitems = nstrip * nseg;
+    conv3x3_ring_kernel<T, TAIL><<<nitems < grid ? nitems : grid, 256, C::LDS_BYTES, s>>>(p, nseg, seg_rows);
+    return (int)hipGetLastError();
+}
+
+template <typename T> static int launch_conv_ring(const ConvParams &p, hipStream_t s)
+{
+    if (p.stride != 1 || p.nchunk != 1 || p.npass != 1 || p.nf != 2 || p.bias_mode > 1 || (p.epi != EPI_NONE && p.epi != EPI_RELU)) return -2;
+    return p.ring == 3 ? launch_conv_ring_t<T, true>(p, s) : launch_conv_ring_t<T, false>(p, s);
+}

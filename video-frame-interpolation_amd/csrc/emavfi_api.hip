@@ -57,7 +57,8 @@ struct Layer {
     bool f16_of_bf16 = false;  // bf16 model, layer consumed by deform_pack_kernel: bf16-rounded weights stored as f16
     bool mfma16 = false;       // packed for and run by conv3x3_persist16_kernel (v_mfma_f32_16x16x32): 16-bit full-resolution 64 -> (1..64) layers
     int pack3 = 0;             // deform_pack3.inl layouts: 1 = DCN, 2 = offset_conv (f16 elements)
-    bool s2ring = false;          // stride 2, 64 -> 128: conv3x3_s2ring_kernel (packing = the regular one for ck 64, nf 4)
+    int ring = 0;              // ConvParams::ring: 1 = stride 2, 64 -> 128 (regular packing for ck 64, nf 4); 2 = 64 -> 64 (regular packing for
+                               // ck 64, nf 2); 3 = 65..67 -> 64 (that + the im2col tail of channels 64..66, 6 KiB)
     bool first6 = false;       // feat_ext_conv1 at mid_channels 64, 16-bit: a second copy of the weights in conv_first.inl's layout (10 KiB)
 };
 
@@ -75,10 +76,22 @@ bool conv_geometry(Layer &L, int esize)
     // 64 -> 128 at stride 2 (context_encoding.0): one 64-channel chunk, each wave keeps one output fragment's weights in registers
     // (conv3x3.inl, conv3x3_s2ring_kernel); EMAVFI_CONV_S2RING=0 keeps the 32-channel-chunk plan (changes the packing: set before packing)
     static const bool s2r_off = [] { const char *e = getenv("EMAVFI_CONV_S2RING"); return e && e[0] == '0'; }();
-    L.s2ring = L.stride == 2 && esize == 2 && L.cin_pad == 64 && (L.cout + 31) / 32 == 4 && !s2r_off;
-    if (L.s2ring) {
+    L.ring = (L.stride == 2 && esize == 2 && L.cin_pad == 64 && (L.cout + 31) / 32 == 4 && !s2r_off) ? 1 : 0;
+    if (L.ring) {
         L.ck = 64; L.nchunk = 1; L.nf = 4; L.npass = 1; L.coutpad = 128;
         L.w_bytes = (size_t)9 * 4 * 4 * 1024;
+        L.mfma16 = false;
+        return true;
+    }
+    // 64 -> 64 and 65..67 -> 64 at stride 1 (feat_ext_blocks, motion_estimation.0 / .1, reconstruction.0): conv_ring.inl.
+    // EMAVFI_CONV_RING=0 keeps round 2's plans (conv3x3_pingpong16_kernel / the CK = 80 tile kernel; changes the packing: set before packing)
+    // (read per call, like EMAVFI_CONV_MFMA16 below: tests compare the plans inside one process)
+    const char *ring_env = getenv("EMAVFI_CONV_RING");
+    const bool ring_off = ring_env && ring_env[0] == '0';
+    if (L.stride == 1 && esize == 2 && L.cout > 32 && L.cout <= 64 && L.cin_take >= 64 && L.cin_take <= 67 && !ring_off) {
+        L.ring = L.cin_take == 64 ? 2 : 3;
+        L.ck = L.cin_pad; L.nchunk = 1; L.nf = 2; L.npass = 1; L.coutpad = 64;
+        L.w_bytes = (size_t)9 * 4 * 2 * 1024 + (L.ring == 3 ? 3 * 2 * 1024 : 0);
         L.mfma16 = false;
         return true;
     }
@@ -290,7 +303,7 @@ int run_conv(const Plan &P, const Layer &L, const void *packed, const void *in, 
     c.Hout = (Hin + L.stride - 1) / L.stride; c.Wout = (Win + L.stride - 1) / L.stride;
     c.B = B; c.nchunk = L.nchunk; c.npass = L.npass; c.cstore = cstore;
     c.epi = epi; c.nplanes = nplanes; c.bias_mode = bias_table ? 1 : 0;
-    c.ck = L.ck; c.nf = L.nf; c.stride = L.stride; c.mfma16 = L.mfma16 ? 1 : 0; c.s2ring = L.s2ring ? 1 : 0;
+    c.ck = L.ck; c.nf = L.nf; c.stride = L.stride; c.mfma16 = L.mfma16 ? 1 : 0; c.ring = L.ring;
     return P.dtype == EMAVFI_F32 ? launch_conv3x3_f32(c, s) : P.dtype == EMAVFI_F16 ? launch_conv3x3_f16(c, s) : launch_conv3x3_bf16(c, s);
 }
 
@@ -338,6 +351,7 @@ int pack_layer(const Layer &L, const void *const *params, void *packed, int dtyp
 {
     PackDesc d{L.cout, L.cin_raw, L.cin_off, L.cin_take, L.ck, L.nchunk, L.nf, L.npass, L.perm, L.f16_of_bf16 ? 1 : 0, bias_f16 ? 1 : 0};
     d.mfma16 = L.mfma16 ? 1 : 0;
+    d.ring = L.ring;
     d.first6 = L.first6 ? 1 : 0;
     d.pack3 = L.pack3;
     return launch_pack_conv((const float *)params[L.param], (const float *)params[L.param + 1], (char *)packed + L.w_off,
@@ -834,6 +848,7 @@ int emavfi_conv3x3(const float *x, const float *weight, const float *bias, float
     L.b_off = (char *)bp - (char *)workspace;
     PackDesc d{L.cout, L.cin_raw, 0, L.cin_take, L.ck, L.nchunk, L.nf, L.npass, 0, 0};
     d.mfma16 = L.mfma16 ? 1 : 0;
+    d.ring = L.ring;
     if (hipMemsetAsync(zpage, 0, 256, s) != hipSuccess) return fail(EMAVFI_E_LAUNCH, "conv3x3: zero page memset failed");
     EMAVFI_TRY(launch_pack_conv(weight, bias, wp, bp, d, dtype, s), "conv3x3 pack");
     EMAVFI_TRY(launch_nchw_to_cl(x, xcl, B, Cin, H, W, L.cin_pad, dtype, s), "conv3x3 layout in");

@@ -12,6 +12,8 @@ struct PackDesc {
                                            // (f16 fragments holding the bf16 model's weights exactly: deform_pack.inl)
     int bias_f16;                          // 1 = the fp32 bias table holds fp16-rounded values (autocast casts the bias too)
     int mfma16;                            // 1 = fragments for v_mfma_f32_16x16x32: [tap][k32][cout16 block][lane (i, kb)][8 elements]
+    int ring;                              // Layer::ring; 3: the main fragments take input channels 0..63 (ck = 64) and conv_ring.inl's tail
+                                           // [j 3][nf 2][lane (r, h)][8] follows: W[32 nf + r][64 + (e & 3)][tap slot 4 j + 2 h + (e >> 2)]
     int first6;                            // conv_first.inl layout (6 -> 64, 16-bit): [kg 5][nf 2][lane (r, h)][8]: W[32 nf + r][channel e][tap 2 kg + h]
     int pack3;                             // deform_pack3.inl layouts (f16 elements, cin_take = 67): 1 = DCN 67 -> <= 67, 2 = offset_conv 67 -> 27;
                                            // 3 = deform_f32w.inl (fp32 elements, the fp32 DCN on an LDS window)

@@ -43,6 +43,7 @@ __global__ void pack_conv_kernel(const float *__restrict__ w, const float *__res
                                  float *__restrict__ bp, PackDesc d)
 {
     constexpr int CHKG = DT<T>::CHKG, EPV = DT<T>::EPV;
+    if (d.ring == 3) { d.ck = 64; }   // channels 64.. go to the tail below
     const int KG = d.ck / CHKG;
     const size_t total = (size_t)d.npass * d.nchunk * 9 * KG * d.nf * 64 * EPV;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -62,9 +63,22 @@ __global__ void pack_conv_kernel(const float *__restrict__ w, const float *__res
             ci = chunk * d.ck + k32 * 32 + (lane >> 4) * 8 + e;
         }
         float v = 0.0f;
-        if (co < d.cout && ci < d.cin_take) v = w[((size_t)co * d.cin_raw + d.cin_off + ci) * 9 + tap];
+        if (co < d.cout && ci < d.cin_take && ci < d.ck * d.nchunk) v = w[((size_t)co * d.cin_raw + d.cin_off + ci) * 9 + tap];
         if (d.via_bf16) v = (float)(bf16_t)v;
         wp[idx] = (T)v;
+    }
+    if (d.ring == 3 && EPV == 8) {
+        for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (size_t)3 * 2 * 64 * 8; idx += (size_t)gridDim.x * blockDim.x) {
+            size_t t = idx;
+            const int e = t % 8; t /= 8;
+            const int lane = t % 64; t /= 64;
+            const int n = t % 2; t /= 2;
+            const int j = (int)t;
+            const int ts = 4 * j + 2 * (lane >> 5) + (e >> 2), ci = 64 + (e & 3), co = n * 32 + (lane & 31);
+            float v = 0.0f;
+            if (ts < 9 && ci < d.cin_take && co < d.cout) v = w[((size_t)co * d.cin_raw + d.cin_off + ci) * 9 + ts];
+            wp[total + idx] = (T)v;
+        }
     }
     if (d.first6 && EPV == 8) {   // a second copy behind the regular fragments: conv_first.inl's ten tap slots of 8
         for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (size_t)5 * 2 * 64 * 8; idx += (size_t)gridDim.x * blockDim.x) {
