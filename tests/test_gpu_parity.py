@@ -566,6 +566,36 @@ def test_ring_conv_agrees_with_the_tile_kernels(dtype, cin, cout, act, shape, mo
     assert (err > 0).float().mean().item() < 0.02, "the two kernels should differ in rare last-place roundings only"
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(2, 75, 131), (1, 1, 7), (1, 2, 62), (1, 3, 63), (1, 17, 124), (1, 40, 125), (1, 360, 640)])
+def test_fused_flow_head_equals_the_two_launch_path(dtype, shape, monkeypatch):
+    """16-bit modes at mid_channels 64 run motion_estimation.1 + .2 as ONE launch: .1's rows stay in an LDS ring (zeroed outside
+    the image - they are .2's padding) and the flow head is computed from them two rows behind (csrc/conv_ring.inl, HEAD).
+    EMAVFI_CONV_HEAD=0 writes .1's tensor and runs the planar-head kernel (conv_light.inl).  Same rounded .1 rows, same head
+    weights and MFMA shape; the head accumulates in two chains instead of one, so the fp32 flow agrees to accumulation-order
+    rounding.  Widths around the 62-column strip pitch, one- and two-row images, several segments per strip."""
+    B, H, W = shape
+    sd = synth.synthetic_state_dict(seed=5)
+    f1, f2 = (t.to(DEV) for t in synth.synthetic_frames(31, B, H, W, "natural"))
+    flows, outs = [], []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("EMAVFI_CONV_HEAD", flag)
+        m = make_model(sd, dtype=dtype)
+        with torch.no_grad():
+            out, taps = m(f1, f2, return_taps=True)
+        flows.append(taps["flow"].clone()); outs.append(out.clone())
+    names = [n for n, _, _ in lib.forward_launches(3, 64, 3, B, H, W, dtype)]
+    assert sum("+head" in n for n in names) == 0   # (EMAVFI_CONV_HEAD=0 still set: the enumeration follows the switch)
+    monkeypatch.delenv("EMAVFI_CONV_HEAD")
+    names = [n for n, _, _ in lib.forward_launches(3, 64, 3, B, H, W, dtype)]
+    assert sum("+head" in n for n in names) == 1
+    err = (flows[0] - flows[1]).abs().max().item()
+    scale = flows[1].abs().max().item()
+    print(f"{dtype} {shape}: flow max-abs diff {err:.3e} (|flow| <= {scale:.3f}); frame diff {(outs[0] - outs[1]).abs().max().item():.3e}")
+    assert torch.isfinite(flows[0]).all() and err <= 2e-5 * max(1.0, scale)
+    assert (outs[0] - outs[1]).abs().max().item() <= (1.5e-2 if dtype == "bf16" else 3e-3)
+
+
 def test_fused_first_layer_equals_pack_input_plus_conv(monkeypatch):
     """16-bit modes at mid_channels 64 compute cat(frame1, frame2) + feat_ext_conv1 + ReLU in ONE launch straight from the NCHW
     fp32 frames (csrc/conv_first.inl); EMAVFI_CONV_FIRST=0 runs pack_input + conv3x3.  Same rounded inputs, weights and products;
@@ -669,7 +699,9 @@ def test_forward_fuzz_sizes_16bit_against_fp32_path():
         f1, f2 = synth.synthetic_frames(1000 + k, B, H, W, "natural" if k % 3 else "stress")
         with torch.no_grad():
             ref = m32(f1.to(DEV), f2.to(DEV))
-            for name, m, tol in (("bf16", mb, 4e-2), ("fp16", mh, 8e-3)):
+            # the worst single element of a bf16 frame is a maximum over ~1e5 rounding decisions: it moved 3.5e-2 -> 4.0e-2 (other
+            # shape, same seeds) when the 64 -> 64 kernels changed their fp32 accumulation order; the PSNR floor below did not move
+            for name, m, tol in (("bf16", mb, 5e-2), ("fp16", mh, 8e-3)):
                 out = m(f1.to(DEV), f2.to(DEV))
                 err = (out - ref).abs().max().item()
                 assert torch.isfinite(out).all() and err <= tol, (name, B, H, W, err)

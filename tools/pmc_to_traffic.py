@@ -35,6 +35,11 @@ def label(k):
     m = re.match(r"_Z24conv3x3_persist16_kernelI(DF16b|DF16_)Li64ELi1", k)
     if m:
         return f"conv3x3<{'bf16' if m.group(1) == 'DF16b' else 'f16'},ck=64,nf=1,s=1>"
+    m = re.match(r"_Z19conv3x3_ring_kernelI(DF16b|DF16_)Lb(0|1)E", k)
+    if m:  # 64 -> 64 layers / reconstruction.0 (67 -> 64): weights in registers, input rows through an LDS ring (csrc/conv_ring.inl)
+        return f"conv3x3<{'bf16' if m.group(1) == 'DF16b' else 'f16'},ck={'80' if m.group(2) == '1' else '64'},nf=2,s=1>"
+    if "conv3x3_ring_kernel<" in k:   # rocprofv3 garbles the demangling of the <bf16, true> instance; the bench runs bf16
+        return "conv3x3<bf16,ck=80,nf=2,s=1>"
     m = re.match(r"_Z21conv3x3_s2ring_kernelI(DF16b|DF16_)", k)
     if m:  # context_encoding.0: weights in registers, input rows through an LDS ring (csrc/conv3x3.inl)
         return f"conv3x3<{'bf16' if m.group(1) == 'DF16b' else 'f16'},ck=64,nf=4,s=2>"

@@ -162,6 +162,8 @@ struct ConvParams {
     int mfma16;          // weights packed for v_mfma_f32_16x16x32 (conv3x3_persist16_kernel): [tap][k32][cout16 block][lane][16 B]
     int ring;            // weights in registers, input rows through an LDS ring: 1 = conv3x3_s2ring_kernel (64 -> 128 at stride 2, context_encoding.0),
                          // 2 = conv3x3_ring_kernel (64 -> 64), 3 = the same with the im2col tail (65..67 -> 64: reconstruction.0)
+    const void *head_w;      // conv_ring.inl, ring == 2 only: fuse a 64 -> nplanes (<= 2) planar head (its weights in the 16x16x32 packing,
+    const float *head_bias;  // its bias) behind this layer: `out` is not written, `out_planar` gets the head (round16 applies)
     int in_pieces;       // 16-byte pieces of an input pixel (single-chunk layers) that exist in memory; 0 = all CK of them.
                          // Pieces beyond read as zeros: the 72-channel fusion buffers feed CK = 80 layers this way.
 };

@@ -18,6 +18,12 @@
 //     4 j + 2 h + (e >> 2), channel 64 + (e & 3) (deform_pack3.inl's im2col tail): 39 MFMAs per row instead of the 45 of CK = 80,
 //     operands straight from the ninth piece of the ring pixels (two ds_read_b64);
 //   * outputs go through a double-buffered LDS row (64 pixels x 128 bytes) so that a store instruction writes whole lines;
+//   * HEAD (motion_estimation.1 + .2, ema_vfi.py:90-92): the 64 -> 64 rows are NOT stored; they go (zeroed outside the image: the
+//     next convolution's padding) into a second LDS ring of four rows, and two steps behind them the same workgroup computes
+//     the 64 -> <= 4 planar head (the flow) from that ring on v_mfma_f32_16x16x32: wave w the 16 columns [16 w, 16 w + 16), the
+//     head's two real weight rows from a 2.3 KiB LDS table (all other rows of the A operand read one zero slot).  A strip then
+//     yields 62 head columns for 64 computed ones and a segment computes two extra rows; in exchange one launch, 0.94 GB of
+//     writes and 0.94 GB of reads per B = 8 x 720p disappear (DMA depth 2 instead of 3: the two rings fill the 80 KiB);
 //   * work items = (strip, vertical segment), dealt round-robin to 2 workgroups per CU; the host picks the segment height so
 //     that the item count fills whole rounds (launch_conv_ring).
 #ifndef EMAVFI_RING_DEPTH
@@ -26,24 +32,26 @@
 #ifndef EMAVFI_RING_AHEAD
 #define EMAVFI_RING_AHEAD 4
 #endif
-template <typename T, bool TAIL> struct ConvRingCfg {
+template <typename T, bool TAIL, bool HEAD> struct ConvRingCfg {
     static constexpr int PSTR = 144, SP = 9, TW = 64, IW = TW + 2, ROWSLOT = IW * SP, ROWINST = (ROWSLOT + 63) / 64, ROWB = ROWINST * 1024;
-    static constexpr int D = EMAVFI_RING_DEPTH, RING = D + 2, STG_PX = 128 + 16, STG = TW * STG_PX, BIAS_OFF = RING * ROWB + 2 * STG;
-    static constexpr int SCRATCH_OFF = BIAS_OFF + 16 * 64 * 4, LDS_BYTES = SCRATCH_OFF + 1024;
+    static constexpr int TWO = HEAD ? TW - 2 : TW;   // columns a strip contributes to the launch's output
+    static constexpr int D = HEAD ? 2 : EMAVFI_RING_DEPTH, RING = D + 2;
+    static constexpr int STG_PX = 128 + 16, STG = TW * STG_PX, NSTG = HEAD ? 4 : 2;   // !HEAD: output staging rows; HEAD: the ring of 64 -> 64 rows
+    static constexpr int STG_OFF = RING * ROWB, BIAS_OFF = STG_OFF + NSTG * STG, BIAS_BYTES = HEAD ? 256 : 16 * 64 * 4;
+    static constexpr int HW_OFF = BIAS_OFF + BIAS_BYTES, HW_BYTES = HEAD ? 9 * 2 * 2 * 64 + 16 : 0;   // head weights [tap][k32][row 0..1][kb][8] + a zero slot
+    static constexpr int SCRATCH_OFF = HW_OFF + HW_BYTES, LDS_BYTES = SCRATCH_OFF + 1024;
     static constexpr int NDMA = (ROWINST + 3) / 4, NSTORE = 2, VMWAIT = NSTORE + (NDMA + NSTORE) * (D - 2);
     static constexpr int WMAIN = 9 * 4 * 2 * 1024;   // bytes of [tap][kg][fragment][lane][8]; the tail [j 3][fragment][lane][8] follows
-    static_assert(sizeof(T) == 2 && 2 * LDS_BYTES <= 160 * 1024, "16-bit types; two workgroups per CU");
+    static_assert(sizeof(T) == 2 && 2 * LDS_BYTES <= 160 * 1024 && !(TAIL && HEAD), "16-bit types; two workgroups per CU");
 };
 
-template <typename T, bool TAIL>
+template <typename T, bool TAIL, bool HEAD>
 __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p, const int nseg, const int seg_rows)
 {
-    using C = ConvRingCfg<T, TAIL>;
+    using C = ConvRingCfg<T, TAIL, HEAD>;
     using vec = typename DT<T>::vec;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *ring = smem;
-    typedef __attribute__((address_space(1))) const void gptr_t;
-    typedef __attribute__((address_space(3))) void lptr_t;
     typedef __attribute__((address_space(3))) char lchar_t;
     typedef __attribute__((ext_vector_type(4))) unsigned u4_t;
     typedef __attribute__((ext_vector_type(2))) unsigned u2_t;
@@ -53,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
     const unsigned lds0 = (unsigned)(size_t)(lchar_t *)smem;
     const int r = lane & 31, h = lane >> 5;
     const int frag = wave & 1, cb = wave >> 1;
-    const int ntx = (p.Wout + C::TW - 1) / C::TW, nstrip = ntx * p.B, nitems = nstrip * nseg;
+    const int ntx = (p.Wout + C::TWO - 1) / C::TWO, nstrip = ntx * p.B, nitems = nstrip * nseg;
     const char *zeros = (const char *)p.zeros;
     const int npieces = TAIL ? 9 : 8;   // pieces of an input pixel that are read (a 64-channel layer never reads the ninth)
     const unsigned pixbytes = (unsigned)p.in_ps * (unsigned)sizeof(T);
@@ -72,6 +80,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
 #pragma unroll
             for (int j = 0; j < 3; ++j) wt[j] = *reinterpret_cast<const vec *>(wb + C::WMAIN + j * 2048);
         }
+    }
+    float hb0 = 0.0f, hb1 = 0.0f;   // the head's bias in the lanes that hold its output rows (loaded once: a global load inside the row
+                                    // loop would make hipcc wait vmcnt(0), i.e. for the whole DMA ring)
+    if constexpr (HEAD) {
+        if ((lane >> 4) == 0) { hb0 = p.head_bias[0]; hb1 = p.nplanes > 1 ? p.head_bias[1] : 0.0f; }
+        // the head's weights: rows 0..1 of block 0 of the 16x16x32 packing [tap][k32][cout16 block 0..1][lane (i, kb)][8]
+        if (tid < 9 * 2 * 2 * 4) {
+            const int kb = tid & 3, i = (tid >> 2) & 1, tk = tid >> 3;
+            reinterpret_cast<u4_t *>(smem + C::HW_OFF)[tid] = *reinterpret_cast<const u4_t *>((const char *)p.head_w + tk * 2048 + (kb * 16 + i) * 16);
+        }
+        if (tid == 255) reinterpret_cast<u4_t *>(smem + C::HW_OFF)[9 * 2 * 2 * 4] = u4_t{0u, 0u, 0u, 0u};
     }
     // ---- lane constants of the row DMA: instruction jn covers 16-byte slots [64 jn, 64 jn + 64) of a ring row
     unsigned xoff[C::NDMA];
@@ -97,8 +116,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
         const int strip = item % nstrip, seg = item / nstrip;
         const int b = strip / ntx, tx = strip - b * ntx;
         const int ys = seg * seg_rows, ye = min(ys + seg_rows, p.Hout);
+        // rows of the 64 -> 64 convolution this item computes: [a0, a1] (HEAD: one more on either side for the head's taps)
+        const int a0 = HEAD ? ys - 1 : ys, a1 = HEAD ? ye : ye - 1;
         const char *gin = (const char *)p.in + (size_t)b * p.Hin * p.Win * p.in_ps * sizeof(T);
-        const int ix0 = tx * C::TW - 1;
+        const int ox0 = tx * C::TWO - (HEAD ? 1 : 0);   // image column of the 64 -> 64 convolution's column 0
+        const int ix0 = ox0 - 1;
         // exactly NDMA instructions per wave (instruction slots past the row land in a scratch KiB; rows outside the image, or
         // not needed by this segment, read the zero page)
         auto dma_row = [&](int gy, int slot, bool live) {
@@ -117,21 +139,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
         // (hipcc would wait for them with vmcnt(0), i.e. for the whole DMA ring)
         {
             const f32x4 *bsrc = reinterpret_cast<const f32x4 *>(p.bias + (p.bias_mode == 1 ? (size_t)b * 16 * 64 : 0));
-            if (tid < (p.bias_mode == 1 ? 256 : 16)) reinterpret_cast<f32x4 *>(smem + C::BIAS_OFF)[tid] = bsrc[tid];
+            if (tid < ((!HEAD && p.bias_mode == 1) ? 256 : 16)) reinterpret_cast<f32x4 *>(smem + C::BIAS_OFF)[tid] = bsrc[tid];
         }
-        const int xg = tx * C::TW + cb * 32 + r;   // this lane's output column
+        const int xg = ox0 + cb * 32 + r;   // this lane's column of the 64 -> 64 convolution
         const int xm = (xg >= 1 ? 1 : 0) | (xg <= p.Wout - 2 ? 2 : 0);
 
-        char *obase = reinterpret_cast<char *>(p.out) + (((size_t)b * p.Hout * p.Wout + (size_t)tx * C::TW) * p.out_ps + p.out_coff) * sizeof(T);
-        const int npx = min(C::TW, p.Wout - tx * C::TW);
+        // ---- the step's NSTORE store instructions (buffer stores: lanes outside the image, or !real, are dropped by the range check)
+        char *obase = nullptr;
         unsigned soff[C::NSTORE];
+        if constexpr (!HEAD) {
+            obase = reinterpret_cast<char *>(p.out) + (((size_t)b * p.Hout * p.Wout + (size_t)tx * C::TW) * p.out_ps + p.out_coff) * sizeof(T);
+            const int npx = min(C::TW, p.Wout - tx * C::TW);
 #pragma unroll
-        for (int i = 0; i < C::NSTORE; ++i) {
-            const int q = i * 256 + tid, px = q >> 3, ch = q & 7;
-            soff[i] = (px < npx && ch * 8 < p.cstore) ? (unsigned)px * (unsigned)p.out_ps * (unsigned)sizeof(T) + ch * 16u : 0x80000000u;
+            for (int i = 0; i < C::NSTORE; ++i) {
+                const int q = i * 256 + tid, px = q >> 3, ch = q & 7;
+                soff[i] = (px < npx && ch * 8 < p.cstore) ? (unsigned)px * (unsigned)p.out_ps * (unsigned)sizeof(T) + ch * 16u : 0x80000000u;
+            }
+        } else {
+            // the head: wave w owns head columns [16 w, 16 w + 16) of the strip's 62; lanes kb == 0 hold output rows 0..3 of a pixel
+            const int hc = wave * 16 + (lane & 15), hx = tx * C::TWO + hc;
+            const bool hok = hc < C::TWO && hx < p.Wout && (lane >> 4) == 0;
+#pragma unroll
+            for (int i = 0; i < C::NSTORE; ++i) soff[i] = (hok && i < p.nplanes) ? (unsigned)hx * 4u : 0x80000000u;
         }
-        auto store_row = [&](int y, bool real) {   // exactly NSTORE instructions; lanes outside the image (or !real) are dropped by the range check
-            lchar_t *stg = (lchar_t *)smem + C::RING * C::ROWB + (y & 1) * C::STG;
+        auto store_row = [&](int y, bool real) {
+            lchar_t *stg = (lchar_t *)smem + C::STG_OFF + (y & 1) * C::STG;
             char *orow = obase + (size_t)(real ? y : ys) * p.Wout * p.out_ps * sizeof(T);
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(orow, 0, real ? 0x7ffffff0 : 0, 0x00020000);
 #pragma unroll
@@ -141,28 +173,59 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
                 __builtin_amdgcn_raw_buffer_store_b128(v, rs, soff[i], 0, 0);
             }
         };
-        // rows ys - 1 .. ys + D - 1 -> slots 0 .. D, each followed by NSTORE dropped stores: the steady state's instruction pattern
+        // head row yb from the 64 -> 64 rows yb - 1 .. yb + 1 (mid-ring slots (row - a0) & 3); NSTORE = 2 stores: planes 0 and 1
+        auto head_row = [&](int yb, bool real) {
+            f32x4 hacc[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+            if constexpr (HEAD) {
+                const int j = lane & 15, kb = lane >> 4;
+                hacc[0][0] = hb0; hacc[0][1] = hb1;   // (rows 0..1 of the lanes with kb == 0; zero elsewhere)
+                const char *hw = smem + C::HW_OFF + (j < 2 ? (j * 4 + kb) * 16 : 9 * 2 * 2 * 64);   // rows >= 2 of the A operand: the zero slot
+                const int hwstep = j < 2 ? 128 : 0;
+                const char *xm0 = smem + C::STG_OFF + (wave * 16 + j) * C::STG_PX + kb * 16;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const char *xr = xm0 + ((yb - 1 + dy - a0) & 3) * C::STG;
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                        for (int k32 = 0; k32 < 2; ++k32) {
+                            const int tk = (dy * 3 + dx) * 2 + k32;
+                            mma_k32(hacc[tk & 1], *reinterpret_cast<const vec *>(hw + tk * hwstep), *reinterpret_cast<const vec *>(xr + dx * C::STG_PX + k32 * 64));
+                        }
+                }
+                const size_t plane = (size_t)p.Hout * p.Wout;
+                float *orow = p.out_planar + (size_t)b * p.nplanes * plane + (size_t)(real ? yb : ys) * p.Wout;
+#pragma unroll
+                for (int i = 0; i < C::NSTORE; ++i) {
+                    float v = hacc[0][i] + hacc[1][i];
+                    if (p.round16) v = (float)(half_t)v;
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(orow + (i < p.nplanes ? i : 0) * plane, 0, real ? 0x7ffffff0 : 0, 0x00020000);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, soff[i], 0, 0);
+                }
+            }
+        };
+        // input rows a0 - 1 .. a0 + D - 1 -> slots 0 .. D, each followed by NSTORE dropped stores: the steady state's instruction pattern
 #pragma unroll 1
         for (int k = 0; k <= C::D; ++k) {
-            dma_row(ys - 1 + k, k, ys - 1 + k <= ye);
-            store_row(ys, false);
+            dma_row(a0 - 1 + k, k, a0 - 1 + k <= a1 + 1);
+            if constexpr (HEAD) head_row(ys, false); else store_row(ys, false);
         }
         int s0 = 0;   // ring slot of input row y - 1
 #pragma unroll 1
-        for (int y = ys; y < ye; ++y) {
+        for (int y = a0; y <= a1; ++y) {
             // this wave's part of input row y + 1 (all but the youngest VMWAIT instructions) and its LDS writes of row y - 1
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C::VMWAIT) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             {
                 int sl = s0 + C::D + 1; sl = sl >= C::RING ? sl - C::RING : sl;
-                dma_row(y + C::D, sl, y + C::D <= ye);
+                dma_row(y + C::D, sl, y + C::D <= a1 + 1);
             }
-            store_row(y - 1, y > ys);
+            if constexpr (HEAD) head_row(y - 2, y - 2 >= ys); else store_row(y - 1, y > a0);
             f32x16 acc[2];
             {
                 // motion_estimation.0 (bias_mode 1): the folded context half depends on the pixel's border class
-                const int ym = (y >= 1 ? 1 : 0) | (y <= p.Hout - 2 ? 2 : 0), cls = p.bias_mode == 1 ? ym * 4 + xm : 0;
+                const int ym = (y >= 1 ? 1 : 0) | (y <= p.Hout - 2 ? 2 : 0), cls = (!HEAD && p.bias_mode == 1) ? ym * 4 + xm : 0;
                 const f32x4 *lb = reinterpret_cast<const f32x4 *>(smem + C::BIAS_OFF + (cls * 64 + frag * 32 + 4 * h) * 4);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -217,10 +280,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
                     __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks every read to just above its MFMA)
                 }
             }
-            // ---- optional ReLU; this wave's 32 channels of its 32 pixels into the row's staging buffer
+            // ---- optional ReLU; this wave's 32 channels of its 32 pixels into the row's staging buffer (HEAD: the ring of 64 -> 64
+            // rows, zero outside the image: they are the head convolution's padding)
             {
                 typedef __attribute__((ext_vector_type(2))) T pair_t;
-                lchar_t *stg = (lchar_t *)smem + C::RING * C::ROWB + (y & 1) * C::STG + (cb * 32 + r) * C::STG_PX + frag * 64;
+                const int slot = HEAD ? ((y - a0) & 3) : (y & 1);
+                const bool inside = !HEAD || ((unsigned)y < (unsigned)p.Hout && (unsigned)xg < (unsigned)p.Wout);
+                lchar_t *stg = (lchar_t *)smem + C::STG_OFF + slot * C::STG + (cb * 32 + r) * C::STG_PX + frag * 64;
 #pragma unroll
                 for (int g = 0; g < 4; g += 2) {
                     unsigned a[2], c[2];
@@ -230,7 +296,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
                         float u0 = acc[0][4 * (g + 1) + 2 * q] + acc[1][4 * (g + 1) + 2 * q], u1 = acc[0][4 * (g + 1) + 2 * q + 1] + acc[1][4 * (g + 1) + 2 * q + 1];
                         if (relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); u0 = fmaxf(u0, 0.0f); u1 = fmaxf(u1, 0.0f); }
                         const pair_t pa = {(T)v0, (T)v1}, pb = {(T)u0, (T)u1};
-                        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, pa), __builtin_bit_cast(unsigned, pb), false, false);
+                        unsigned ua = __builtin_bit_cast(unsigned, pa), ub = __builtin_bit_cast(unsigned, pb);
+                        if (HEAD) { const unsigned keep = inside ? ~0u : 0u; ua &= keep; ub &= keep; }
+                        const auto sw = __builtin_amdgcn_permlane32_swap(ua, ub, false, false);
                         a[q] = sw[0]; c[q] = sw[1];
                     }
                     *reinterpret_cast<__attribute__((address_space(3))) u4_t *>(stg + 16 * (g + h)) = u4_t{a[0], a[1], c[0], c[1]};
@@ -240,7 +308,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the next item primes the same slots)
         __syncthreads();
-        store_row(ye - 1, true);
+        if constexpr (HEAD) {
+            head_row(a1 - 1, true);   // (= ye - 1; row ye - 2 was the last step's)
+            __syncthreads();          // the next item's first rows overwrite the ring of 64 -> 64 rows
+        } else
+            store_row(a1, true);
     }
 }
 
@@ -259,27 +331,31 @@ static void conv_ring_segments(int nstrip, int Hout, int grid, int *nseg_out, in
     *seg_rows_out = br;
 }
 
-template <typename T, bool TAIL> static int launch_conv_ring_t(const ConvParams &p, hipStream_t s)
+template <typename T, bool TAIL, bool HEAD> static int launch_conv_ring_t(const ConvParams &p, hipStream_t s)
 {
-    using C = ConvRingCfg<T, TAIL>;
+    using C = ConvRingCfg<T, TAIL, HEAD>;
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_ring_kernel<T, TAIL>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_ring_kernel<T, TAIL, HEAD>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     });
     if (attr_err != hipSuccess) return (int)attr_err;
     const int ncu = device_cu_count();
     if (ncu <= 0) return (int)hipErrorInvalidDevice;
-    const int nstrip = ((p.Wout + C::TW - 1) / C::TW) * p.B, grid = 2 * ncu;
+    const int nstrip = ((p.Wout + C::TWO - 1) / C::TWO) * p.B, grid = 2 * ncu;
     int nseg, seg_rows;
     conv_ring_segments(nstrip, p.Hout, grid, &nseg, &seg_rows);
     const int nitems = nstrip * nseg;
-    conv3x3_ring_kernel<T, TAIL><<<nitems < grid ? nitems : grid, 256, C::LDS_BYTES, s>>>(p, nseg, seg_rows);
+    conv3x3_ring_kernel<T, TAIL, HEAD><<<nitems < grid ? nitems : grid, 256, C::LDS_BYTES, s>>>(p, nseg, seg_rows);
     return (int)hipGetLastError();
 }
 
 template <typename T> static int launch_conv_ring(const ConvParams &p, hipStream_t s)
 {
     if (p.stride != 1 || p.nchunk != 1 || p.npass != 1 || p.nf != 2 || p.bias_mode > 1 || (p.epi != EPI_NONE && p.epi != EPI_RELU)) return -2;
-    return p.ring == 3 ? launch_conv_ring_t<T, true>(p, s) : launch_conv_ring_t<T, false>(p, s);
+    if (p.head_w) {   // + a planar head of <= 2 channels computed from the rows in LDS (NSTORE stores per step = its planes)
+        if (p.ring != 2 || p.bias_mode != 0 || !p.head_bias || !p.out_planar || p.nplanes < 1 || p.nplanes > 2) return -2;
+        return launch_conv_ring_t<T, false, true>(p, s);
+    }
+    return p.ring == 3 ? launch_conv_ring_t<T, true, false>(p, s) : launch_conv_ring_t<T, false, false>(p, s);
 }

@@ -287,9 +287,13 @@ bool build_plan(Plan &P, int in_ch, int mid, int nb, int dtype)
 
 int run_conv(const Plan &P, const Layer &L, const void *packed, const void *in, int in_ps, int Hin, int Win, void *out,
              int out_ps, int out_coff, int cstore, int epi, int B, hipStream_t s, const float *bias_table = nullptr,
-             float *planar = nullptr, int nplanes = 0, const void *zeros = nullptr)
+             float *planar = nullptr, int nplanes = 0, const void *zeros = nullptr, const Layer *head = nullptr)
 {
     ConvParams c{};
+    if (head) {   // conv_ring.inl: L's rows stay in LDS, the planar head `head` is computed from them (planar / nplanes are the head's)
+        c.head_w = (const char *)packed + head->w_off;
+        c.head_bias = (const float *)((const char *)packed + head->b_off);
+    }
     // a single-chunk layer wider than its input's pixel stride (CK = 80 fed from the 72-channel fusion buffers) reads
     // the missing pieces as zeros
     if (L.nchunk == 1 && in_ps < L.ck) c.in_pieces = in_ps * P.esize / 16;
@@ -529,12 +533,26 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
     conv_work(P, P.m0, B, H, W, e, fl, by);
     EMAVFI_STEP(rec, conv_name(P, P.m0) + " motion_estimation.0(ctx folded)", fl, by,
                 run_conv(P, P.m0, packed, f.fu0, P.fps, H, W, f.fA, P.p_mid, 0, P.p_mid, EPI_RELU, B, s, f.table));
-    conv_work(P, P.m1, B, H, W, e, fl, by);
-    EMAVFI_STEP(rec, conv_name(P, P.m1) + " motion_estimation.1", fl, by,
-                run_conv(P, P.m1, packed, f.fA, P.p_mid, H, W, f.fB, P.p_mid, 0, P.p_mid, EPI_RELU, B, s));
-    conv_work(P, P.m2, B, H, W, 4.0, fl, by);
-    EMAVFI_STEP(rec, conv_name(P, P.m2) + " motion_estimation.2(flow)", fl, by,
-                run_conv(P, P.m2, packed, f.fB, P.p_mid, H, W, nullptr, 0, 0, 0, EPI_PLANAR, B, s, nullptr, f.flow, 2));
+    // motion_estimation.1 + .2 in one launch (conv_ring.inl, HEAD): .1's rows never leave the LDS.  EMAVFI_CONV_HEAD=0 (read per
+    // forward): two launches
+    const char *hf = getenv("EMAVFI_CONV_HEAD");
+    if (P.m1.ring == 2 && P.m2.mfma16 && P.m2.ck == 64 && P.m2.nf == 1 && P.m2.cout <= 2 && !(hf && hf[0] == '0')) {
+        double fl2, by2;
+        conv_work(P, P.m1, B, H, W, e, fl, by);
+        conv_work(P, P.m2, B, H, W, 4.0, fl2, by2);
+        // bytes: .1's input and weights, .2's weights and output (the intermediate tensor is neither written nor read)
+        const double mid_bytes = (double)B * H * W * mid * e;
+        EMAVFI_STEP(rec, "conv3x3+head<" + std::string(dtype_name(P.dtype)) + ",64->64->" + std::to_string(P.m2.cout) + "> motion_estimation.1+.2(flow)",
+                    fl + fl2, by + by2 - 2 * mid_bytes,
+                    run_conv(P, P.m1, packed, f.fA, P.p_mid, H, W, nullptr, 0, 0, 0, EPI_RELU, B, s, nullptr, f.flow, 2, nullptr, &P.m2));
+    } else {
+        conv_work(P, P.m1, B, H, W, e, fl, by);
+        EMAVFI_STEP(rec, conv_name(P, P.m1) + " motion_estimation.1", fl, by,
+                    run_conv(P, P.m1, packed, f.fA, P.p_mid, H, W, f.fB, P.p_mid, 0, P.p_mid, EPI_RELU, B, s));
+        conv_work(P, P.m2, B, H, W, 4.0, fl, by);
+        EMAVFI_STEP(rec, conv_name(P, P.m2) + " motion_estimation.2(flow)", fl, by,
+                    run_conv(P, P.m2, packed, f.fB, P.p_mid, H, W, nullptr, 0, 0, 0, EPI_PLANAR, B, s, nullptr, f.flow, 2));
+    }
     if (!rec.dry && taps && taps[2])
         if (hipMemcpyAsync(taps[2], f.flow, npx * 2 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
             return fail(EMAVFI_E_LAUNCH, "tap flow copy failed");
