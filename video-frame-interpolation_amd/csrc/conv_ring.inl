@@ -26,6 +26,9 @@
 //     writes and 0.94 GB of reads per B = 8 x 720p disappear (DMA depth 2 instead of 3: the two rings fill the 80 KiB);
 //   * work items = (strip, vertical segment), dealt round-robin to 2 workgroups per CU; the host picks the segment height so
 //     that the item count fills whole rounds (launch_conv_ring).
+#ifndef EMAVFI_RING_ABL
+#define EMAVFI_RING_ABL 0   // timing-only ablations (diagnostic builds): 1 every DMA reads the zero page, 2 no row is stored, 4 no epilogue arithmetic
+#endif
 #ifndef EMAVFI_RING_DEPTH
 #define EMAVFI_RING_DEPTH 3
 #endif
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
         // exactly NDMA instructions per wave (instruction slots past the row land in a scratch KiB; rows outside the image, or
         // not needed by this segment, read the zero page)
         auto dma_row = [&](int gy, int slot, bool live) {
-            const bool rowok = live && (unsigned)gy < (unsigned)p.Hin;   // wave-uniform
+            const bool rowok = live && (unsigned)gy < (unsigned)p.Hin && !(EMAVFI_RING_ABL & 1);   // wave-uniform
             const char *rowp = gin + (size_t)(rowok ? gy : 0) * rowbytes + (ptrdiff_t)ix0 * (ptrdiff_t)pixbytes;
 #pragma unroll
             for (int i = 0; i < C::NDMA; ++i) {
@@ -180,18 +183,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
                 const int j = lane & 15, kb = lane >> 4;
                 hacc[0][0] = hb0; hacc[0][1] = hb1;   // (rows 0..1 of the lanes with kb == 0; zero elsewhere)
                 const char *hw = smem + C::HW_OFF + (j < 2 ? (j * 4 + kb) * 16 : 9 * 2 * 2 * 64);   // rows >= 2 of the A operand: the zero slot
-                const int hwstep = j < 2 ? 128 : 0;
+                int hwstep = j < 2 ? 128 : 0;
                 const char *xm0 = smem + C::STG_OFF + (wave * 16 + j) * C::STG_PX + kb * 16;
+                const char *xr[3];
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    const char *xr = xm0 + ((yb - 1 + dy - a0) & 3) * C::STG;
+                for (int dy = 0; dy < 3; ++dy) xr[dy] = xm0 + ((yb - 1 + dy - a0) & 3) * C::STG;
+                // operands four steps ahead of their MFMAs, fenced like the main loop's (18 dependent read -> MFMA pairs would cost
+                // an LDS round trip each)
+                constexpr int HA = 4;
+                vec hx[HA + 1], hv[HA + 1];
+                auto hload = [&](int tk) {
+                    asm volatile("" : "+v"(hwstep));   // (or hipcc keeps 18 weight addresses in registers)
+                    hv[tk % (HA + 1)] = *reinterpret_cast<const vec *>(hw + tk * hwstep);
+                    hx[tk % (HA + 1)] = *reinterpret_cast<const vec *>(xr[tk / 6] + ((tk >> 1) % 3) * C::STG_PX + (tk & 1) * 64);
+                };
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int dx = 0; dx < 3; ++dx)
+                for (int tk = 0; tk < HA; ++tk) hload(tk);
 #pragma unroll
-                        for (int k32 = 0; k32 < 2; ++k32) {
-                            const int tk = (dy * 3 + dx) * 2 + k32;
-                            mma_k32(hacc[tk & 1], *reinterpret_cast<const vec *>(hw + tk * hwstep), *reinterpret_cast<const vec *>(xr + dx * C::STG_PX + k32 * 64));
-                        }
+                for (int tk = 0; tk < 18; ++tk) {
+                    if (tk + HA < 18) hload(tk + HA);
+                    mma_k32(hacc[tk & 1], hv[tk % (HA + 1)], hx[tk % (HA + 1)]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 const size_t plane = (size_t)p.Hout * p.Wout;
                 float *orow = p.out_planar + (size_t)b * p.nplanes * plane + (size_t)(real ? yb : ys) * p.Wout;
@@ -221,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
                 int sl = s0 + C::D + 1; sl = sl >= C::RING ? sl - C::RING : sl;
                 dma_row(y + C::D, sl, y + C::D <= a1 + 1);
             }
-            if constexpr (HEAD) head_row(y - 2, y - 2 >= ys); else store_row(y - 1, y > a0);
+            if constexpr (HEAD) head_row(y - 2, y - 2 >= ys && !(EMAVFI_RING_ABL & 2)); else store_row(y - 1, y > a0 && !(EMAVFI_RING_ABL & 2));
             f32x16 acc[2];
             {
                 // motion_estimation.0 (bias_mode 1): the folded context half depends on the pixel's border class
@@ -295,6 +308,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
                         float v0 = acc[0][4 * g + 2 * q] + acc[1][4 * g + 2 * q], v1 = acc[0][4 * g + 2 * q + 1] + acc[1][4 * g + 2 * q + 1];
                         float u0 = acc[0][4 * (g + 1) + 2 * q] + acc[1][4 * (g + 1) + 2 * q], u1 = acc[0][4 * (g + 1) + 2 * q + 1] + acc[1][4 * (g + 1) + 2 * q + 1];
                         if (relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); u0 = fmaxf(u0, 0.0f); u1 = fmaxf(u1, 0.0f); }
+                        if (EMAVFI_RING_ABL & 4) { v0 = acc[0][4 * g + 2 * q]; v1 = acc[1][4 * g + 2 * q]; u0 = v0; u1 = v1; }
                         const pair_t pa = {(T)v0, (T)v1}, pb = {(T)u0, (T)u1};
                         unsigned ua = __builtin_bit_cast(unsigned, pa), ub = __builtin_bit_cast(unsigned, pb);
                         if (HEAD) { const unsigned keep = inside ? ~0u : 0u; ua &= keep; ub &= keep; }
