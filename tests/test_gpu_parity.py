@@ -596,6 +596,30 @@ def test_fused_flow_head_equals_the_two_launch_path(dtype, shape, monkeypatch):
     assert (outs[0] - outs[1]).abs().max().item() <= (1.5e-2 if dtype == "bf16" else 3e-3)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(2, 75, 131), (1, 1, 7), (1, 2, 62), (1, 3, 63), (1, 17, 124), (3, 40, 125), (1, 360, 640)])
+def test_fused_first_two_layers_equal_the_two_launch_path(dtype, shape, monkeypatch):
+    """16-bit modes at mid_channels 64 run cat + feat_ext_conv1 + ReLU + conv_block_0 + ReLU as ONE launch: feat_ext_conv1's rows
+    exist only in an LDS ring (csrc/conv_ring_first.inl).  EMAVFI_CONV_FIRSTRING=0 runs conv_first + the ring kernel.  Both
+    stages repeat the unfused kernels' arithmetic operation for operation, so `feat` (three layers later) and the frame must
+    be bit-identical.  Widths around the 62-column strip pitch, one- and two-row images, several segments per strip."""
+    B, H, W = shape
+    sd = synth.synthetic_state_dict(seed=6)
+    f1, f2 = (t.to(DEV) for t in synth.synthetic_frames(32, B, H, W, "natural"))
+    feats, outs = [], []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("EMAVFI_CONV_FIRSTRING", flag)
+        m = make_model(sd, dtype=dtype)
+        with torch.no_grad():
+            out, taps = m(f1, f2, return_taps=True)
+        feats.append(taps["feat"].clone()); outs.append(out.clone())
+        names = [n for n, _, _ in lib.forward_launches(3, 64, 3, B, H, W, dtype)]
+        assert sum(n.startswith("conv_first+conv3x3") for n in names) == int(flag)
+    assert torch.isfinite(feats[0]).all()
+    assert torch.equal(feats[0], feats[1]), f"feat: {int((feats[0] != feats[1]).sum())} of {feats[0].numel()} differ, max {(feats[0] - feats[1]).abs().max().item():.3e}"
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_fused_first_layer_equals_pack_input_plus_conv(monkeypatch):
     """16-bit modes at mid_channels 64 compute cat(frame1, frame2) + feat_ext_conv1 + ReLU in ONE launch straight from the NCHW
     fp32 frames (csrc/conv_first.inl); EMAVFI_CONV_FIRST=0 runs pack_input + conv3x3.  Same rounded inputs, weights and products;

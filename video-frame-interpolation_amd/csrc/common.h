@@ -205,6 +205,9 @@ int device_cu_count();
 struct FirstParams;
 int launch_conv_first_bf16(const FirstParams &p, hipStream_t s);
 int launch_conv_first_f16(const FirstParams &p, hipStream_t s);
+// conv_ring_first.inl: feat_ext_conv1 + conv_block_0 in one launch (p: the 64 -> 64 layer, ring == 2; p.in is not read)
+int launch_conv_ringfirst_bf16(const FirstParams &fp, const ConvParams &p, hipStream_t s);
+int launch_conv_ringfirst_f16(const FirstParams &fp, const ConvParams &p, hipStream_t s);
 int launch_conv3x3_f32(const ConvParams &p, hipStream_t s);
 int launch_conv3x3_bf16(const ConvParams &p, hipStream_t s);
 int launch_conv3x3_f16(const ConvParams &p, hipStream_t s);

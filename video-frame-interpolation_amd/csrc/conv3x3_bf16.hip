@@ -1,5 +1,6 @@
 #include "conv3x3.inl"
 #include "conv_first.inl"
+#include "conv_ring_first.inl"
 #include <cstdlib>
 int launch_conv3x3_bf16(const ConvParams &p, hipStream_t s)
 {
@@ -18,3 +19,4 @@ extern "C" int emavfi_debug_conv_stamps(unsigned long long *out, int reset)
 #endif
 
 int launch_conv_first_bf16(const FirstParams &p, hipStream_t s) { return launch_conv_first_t<bf16_t>(p, s); }
+int launch_conv_ringfirst_bf16(const FirstParams &fp, const ConvParams &p, hipStream_t s) { return launch_conv_ringfirst_t<bf16_t>(fp, p, s); }

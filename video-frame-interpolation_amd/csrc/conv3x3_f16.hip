@@ -1,5 +1,6 @@
 #include "conv3x3.inl"
 #include "conv_first.inl"
+#include "conv_ring_first.inl"
 #include <cstdlib>
 int launch_conv3x3_f16(const ConvParams &p, hipStream_t s)
 {
@@ -8,3 +9,4 @@ int launch_conv3x3_f16(const ConvParams &p, hipStream_t s)
 }
 
 int launch_conv_first_f16(const FirstParams &p, hipStream_t s) { return launch_conv_first_t<half_t>(p, s); }
+int launch_conv_ringfirst_f16(const FirstParams &fp, const ConvParams &p, hipStream_t s) { return launch_conv_ringfirst_t<half_t>(fp, p, s); }

@@ -287,7 +287,8 @@ bool build_plan(Plan &P, int in_ch, int mid, int nb, int dtype)
 
 int run_conv(const Plan &P, const Layer &L, const void *packed, const void *in, int in_ps, int Hin, int Win, void *out,
              int out_ps, int out_coff, int cstore, int epi, int B, hipStream_t s, const float *bias_table = nullptr,
-             float *planar = nullptr, int nplanes = 0, const void *zeros = nullptr, const Layer *head = nullptr)
+             float *planar = nullptr, int nplanes = 0, const void *zeros = nullptr, const Layer *head = nullptr,
+             const FirstParams *first = nullptr)
 {
     ConvParams c{};
     if (head) {   // conv_ring.inl: L's rows stay in LDS, the planar head `head` is computed from them (planar / nplanes are the head's)
@@ -308,6 +309,7 @@ int run_conv(const Plan &P, const Layer &L, const void *packed, const void *in, 
     c.B = B; c.nchunk = L.nchunk; c.npass = L.npass; c.cstore = cstore;
     c.epi = epi; c.nplanes = nplanes; c.bias_mode = bias_table ? 1 : 0;
     c.ck = L.ck; c.nf = L.nf; c.stride = L.stride; c.mfma16 = L.mfma16 ? 1 : 0; c.ring = L.ring;
+    if (first) return P.dtype == EMAVFI_F16 ? launch_conv_ringfirst_f16(*first, c, s) : launch_conv_ringfirst_bf16(*first, c, s);
     return P.dtype == EMAVFI_F32 ? launch_conv3x3_f32(c, s) : P.dtype == EMAVFI_F16 ? launch_conv3x3_f16(c, s) : launch_conv3x3_bf16(c, s);
 }
 
@@ -485,22 +487,38 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
 
     // --- feature extraction: cat + conv + ReLU, then num_blocks x (conv + ReLU)  (ema_vfi.py:112-116)
     conv_work(P, P.conv1, B, H, W, e, fl, by);
+    int first_blk = 0;
+    void *cur = f.fA, *nxt = f.fB;
     {
         const char *cf = getenv("EMAVFI_CONV_FIRST");   // read per call: the parity test flips it inside one process (the blob carries both layouts)
+        const char *rf = getenv("EMAVFI_CONV_FIRSTRING");
         if (P.conv1.first6 && !(cf && cf[0] == '0')) {
             // cat(frame1, frame2) + conv + ReLU in one launch, straight from the NCHW fp32 frames (ema_vfi.py:112-113)
             FirstParams fp{frame1, frame2, f.fA, (const char *)packed + P.conv1.w_off + P.conv1.w_bytes,
                            (const float *)((const char *)packed + P.conv1.b_off), P.p_mid, H, W, B, 1};
-            EMAVFI_STEP(rec, std::string("conv_first<") + dtype_name(dtype) + ",6->64> cat+feat_ext_conv1", fl, px * (8.0 * C + mid * e) + 9.0 * 2 * C * mid * e,
-                        dtype == EMAVFI_F16 ? launch_conv_first_f16(fp, s) : launch_conv_first_bf16(fp, s));
+            if (P.nb >= 1 && P.blk[0].ring == 2 && !(rf && rf[0] == '0')) {
+                // ... and feat_ext_blocks.conv_block_0 + ReLU behind it in the SAME launch (conv_ring_first.inl): feat_ext_conv1's
+                // tensor exists only as an LDS ring.  EMAVFI_CONV_FIRSTRING=0 (read per call): two launches
+                double fl2, by2;
+                const bool last = P.nb == 1;
+                void *dst = last ? f.fu0 : f.fB;
+                conv_work(P, P.blk[0], B, H, W, e, fl2, by2);
+                EMAVFI_STEP(rec, std::string("conv_first+conv3x3<") + dtype_name(dtype) + ",6->64->64> cat+feat_ext_conv1+conv_block_0", fl + fl2,
+                            px * (8.0 * C + mid * e) + 9.0 * 2 * C * mid * e + 9.0 * mid * mid * e,
+                            run_conv(P, P.blk[0], packed, nullptr, P.p_mid, H, W, dst, last ? P.fps : P.p_mid, 0, P.p_mid, EPI_RELU, B, s, nullptr, nullptr, 0, nullptr, nullptr, &fp));
+                first_blk = 1;
+                cur = f.fB; nxt = f.fA;
+            } else {
+                EMAVFI_STEP(rec, std::string("conv_first<") + dtype_name(dtype) + ",6->64> cat+feat_ext_conv1", fl, px * (8.0 * C + mid * e) + 9.0 * 2 * C * mid * e,
+                            dtype == EMAVFI_F16 ? launch_conv_first_f16(fp, s) : launch_conv_first_bf16(fp, s));
+            }
         } else {
             EMAVFI_STEP(rec, "pack_input", 0, px * (8.0 * C + 2.0 * C * e), launch_pack_input(frame1, frame2, f.in16, B, C, H, W, 16, dtype, s));
             EMAVFI_STEP(rec, conv_name(P, P.conv1) + " feat_ext_conv1", fl, by,
                         run_conv(P, P.conv1, packed, f.in16, 16, H, W, f.fA, P.p_mid, 0, P.p_mid, EPI_RELU, B, s));
         }
     }
-    void *cur = f.fA, *nxt = f.fB;
-    for (int i = 0; i < P.nb; ++i) {
+    for (int i = first_blk; i < P.nb; ++i) {
         const bool last = i == P.nb - 1;  // the last block writes feat straight into the fusion buffer
         void *dst = last ? f.fu0 : nxt;
         conv_work(P, P.blk[i], B, H, W, e, fl, by);
