@@ -14,7 +14,10 @@ def per_kernel(path, counter):
     d = collections.defaultdict(list)
     for row in csv.DictReader(open(path)):
         if row["Counter_Name"] == counter:
-            d[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+            k = row["Kernel_Name"]
+            if "conv3x3_ring_kernel<" in k:   # garbled demangling (any instance with a `true` argument): tell them apart by their LDS size
+                k += "|lds=" + row.get("LDS_Block_Size", "0")
+            d[k].append(float(row["Counter_Value"]))
     return d
 
 
@@ -35,11 +38,18 @@ def label(k):
     m = re.match(r"_Z24conv3x3_persist16_kernelI(DF16b|DF16_)Li64ELi1", k)
     if m:
         return f"conv3x3<{'bf16' if m.group(1) == 'DF16b' else 'f16'},ck=64,nf=1,s=1>"
-    m = re.match(r"_Z19conv3x3_ring_kernelI(DF16b|DF16_)Lb(0|1)E", k)
-    if m:  # 64 -> 64 layers / reconstruction.0 (67 -> 64): weights in registers, input rows through an LDS ring (csrc/conv_ring.inl)
-        return f"conv3x3<{'bf16' if m.group(1) == 'DF16b' else 'f16'},ck={'80' if m.group(2) == '1' else '64'},nf=2,s=1>"
-    if "conv3x3_ring_kernel<" in k:   # rocprofv3 garbles the demangling of the <bf16, true> instance; the bench runs bf16
-        return "conv3x3<bf16,ck=80,nf=2,s=1>"
+    m = re.match(r"_Z19conv3x3_ring_kernelI(DF16b|DF16_)Lb(0|1)ELb(0|1)E", k)
+    if m:  # 64 -> 64 layers / reconstruction.0 (67 -> 64) / motion_estimation.1 + .2: weights in registers, input rows through an LDS ring (csrc/conv_ring.inl)
+        t = 'bf16' if m.group(1) == 'DF16b' else 'f16'
+        if m.group(3) == '1':
+            return f"conv3x3+head<{t},64->64->2>"
+        return f"conv3x3<{t},ck={'80' if m.group(2) == '1' else '64'},nf=2,s=1>"
+    if "conv3x3_ring_kernel<" in k:   # rocprofv3 garbles the demangling of instances with a `true` argument; the bench runs bf16;
+        lds = int(k.rsplit("|lds=", 1)[1]) if "|lds=" in k else 0   # HEAD: two rings, 81 424 B; TAIL: 74 752 B
+        return "conv3x3+head<bf16,64->64->2>" if lds > 78000 else "conv3x3<bf16,ck=80,nf=2,s=1>"
+    m = re.match(r"_Z24conv3x3_ringfirst_kernelI(DF16b|DF16_)", k)
+    if m:
+        return f"conv_first+conv3x3<{'bf16' if m.group(1) == 'DF16b' else 'f16'},6->64->64>"
     m = re.match(r"_Z21conv3x3_s2ring_kernelI(DF16b|DF16_)", k)
     if m:  # context_encoding.0: weights in registers, input rows through an LDS ring (csrc/conv3x3.inl)
         return f"conv3x3<{'bf16' if m.group(1) == 'DF16b' else 'f16'},ck=64,nf=4,s=2>"
