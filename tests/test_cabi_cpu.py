@@ -160,3 +160,24 @@ def test_device_code_has_no_packed_f32_operations(tmp_path):
         packed += len(re.findall(r"v_pk_(?:add|mul|fma)_f32", dis))
     assert kernels > 100, "disassembly looks empty"
     assert packed == 0, f"{packed} packed f32 VALU operations in the device code: was NOPK dropped from the build?"
+
+
+def test_packed_cache_file_carries_a_checksum(tmp_path):
+    """ADVICE r2: the on-disk packed-weight cache trusted any file of the right size.  The file is now blob + sha256(blob);
+    a flipped byte, a truncated file or a file of the old format is ignored (the caller re-packs and overwrites it)."""
+    import torch
+    from emavfi import EMA_VFI
+    blob = torch.arange(4096, dtype=torch.int64).to(torch.uint8)
+    path = str(tmp_path / "packed_test.bin")
+    EMA_VFI._cache_write(path, blob)
+    assert os.path.getsize(path) == 4096 + 32
+    back = EMA_VFI._cache_read(path, 4096, "cpu")
+    assert back is not None and torch.equal(back, blob)
+    raw = bytearray(open(path, "rb").read())
+    raw[100] ^= 1
+    open(path, "wb").write(bytes(raw))
+    assert EMA_VFI._cache_read(path, 4096, "cpu") is None                 # bit rot
+    open(path, "wb").write(bytes(raw[:4096]))
+    assert EMA_VFI._cache_read(path, 4096, "cpu") is None                 # old format / truncated
+    assert EMA_VFI._cache_read(path, 4095, "cpu") is None                 # other size
+    assert EMA_VFI._cache_read(str(tmp_path / "missing.bin"), 4096, "cpu") is None

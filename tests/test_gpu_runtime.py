@@ -63,6 +63,29 @@ def test_captured_graph_survives_workspace_growth():
     lib.release_workspaces()
 
 
+def test_workspace_cache_is_bounded_over_transient_streams(monkeypatch):
+    """A caller that runs every forward on a fresh stream must not pin one workspace per stream handle for ever: the cache keeps
+    the EMAVFI_WS_CACHE_MAX most recently used buffers (buffers a captured graph may point at are exempt)."""
+    lib.release_workspaces()
+    monkeypatch.setenv("EMAVFI_WS_CACHE_MAX", "3")
+    sd = synth.synthetic_state_dict(seed=0, mid_channels=8)
+    m = make_model(sd, mid=8, dtype="fp32")
+    x = [t.to(DEV) for t in synth.synthetic_frames(53, 1, 48, 64, "natural")]
+    with torch.no_grad():
+        ref = m(*x).clone()
+        streams = [torch.cuda.Stream() for _ in range(7)]
+        outs = []
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                outs.append(m(*x))
+            assert len(lib._ws_cache) <= 3
+        torch.cuda.synchronize()
+    assert all(torch.equal(o, ref) for o in outs)
+    assert list(lib._ws_cache)[-1][1] == streams[-1].cuda_stream      # most recently used last
+    lib.release_workspaces()
+
+
 def test_two_streams_run_forwards_concurrently():
     """Two streams enqueue forwards back to back without host synchronisation; each stream has its own workspace, so
     the interleaved results equal the serial ones bit for bit (a shared scratch buffer would be a data race)."""
@@ -261,3 +284,10 @@ def test_packed_blob_is_cached_on_disk_by_content(tmp_path, monkeypatch):
         monkeypatch.setenv("EMAVFI_CACHE", "0")                      # disabled: packs again, writes nothing
         make_model(sd, mid=8, dtype="bf16")(f1, f2)
         assert len(calls) == 4 and len(list(tmp_path.glob("packed_*.bin"))) == 3
+        monkeypatch.setenv("EMAVFI_CACHE", "1")                      # a corrupted entry is not run: re-packed and rewritten
+        for f in tmp_path.glob("packed_*.bin"):
+            raw = bytearray(f.read_bytes()); raw[64] ^= 0x10; f.write_bytes(bytes(raw))
+        c = make_model(sd, mid=8, dtype="bf16")(f1, f2)
+        assert len(calls) == 5 and torch.equal(a, c)
+        make_model(sd, mid=8, dtype="bf16")(f1, f2)
+        assert len(calls) == 5

@@ -62,7 +62,24 @@ struct Layer {
     bool first6 = false;       // feat_ext_conv1 at mid_channels 64, 16-bit: a second copy of the weights in conv_first.inl's layout (10 KiB)
 };
 
-bool conv_geometry(Layer &L, int esize)
+// Environment switches the PACKED LAYOUT depends on.  emavfi_pack_weights and emavfi_forward must agree on them, so the plan of
+// a model reads them ONCE per process (process_layout_env: a switch flipped between packing and running cannot desynchronise
+// the two); only the stage-level entry emavfi_conv3x3, which packs and runs inside one call, reads them per call (the
+// parity tests compare kernels inside one process that way).  A blob packed by ANOTHER process under other switches is the
+// caller's responsibility: the Python binding keys its caches by them (emavfi/lib.py, layout_switches).
+struct LayoutEnv { bool m16_off, ring_off, s2ring_off, s2_ck64; };
+LayoutEnv read_layout_env()
+{
+    const auto off = [](const char *name) { const char *e = getenv(name); return e && e[0] == '0'; };
+    return LayoutEnv{off("EMAVFI_CONV_MFMA16"), off("EMAVFI_CONV_RING"), off("EMAVFI_CONV_S2RING"), getenv("EMAVFI_CONV_S2_CK64") != nullptr};
+}
+const LayoutEnv &process_layout_env()
+{
+    static const LayoutEnv env = read_layout_env();
+    return env;
+}
+
+bool conv_geometry(Layer &L, int esize, const LayoutEnv &env)
 {
     L.cin_pad = rup(L.cin_take, 16);
     // Stride-2 layers: 32-channel chunks, two workgroups per CU.  PMC shows 2.6 GB of HBM reads per launch for 0.7 GB of
@@ -72,10 +89,10 @@ bool conv_geometry(Layer &L, int esize)
     // 4-wave workgroup per CU, and measured SLOWER (64->128: 757 vs 513 us, 128->256: 534 vs 513 us at B=8 x 720p):
     // these layers are not bound by the over-fetch but by how little of a tile's DMA / MFMA / store phases one
     // workgroup per CU can overlap.  Kept as an experiment switch, not the default.
-    static const bool s2_ck64 = getenv("EMAVFI_CONV_S2_CK64") != nullptr;
+    const bool s2_ck64 = env.s2_ck64;
     // 64 -> 128 at stride 2 (context_encoding.0): one 64-channel chunk, each wave keeps one output fragment's weights in registers
     // (conv3x3.inl, conv3x3_s2ring_kernel); EMAVFI_CONV_S2RING=0 keeps the 32-channel-chunk plan (changes the packing: set before packing)
-    static const bool s2r_off = [] { const char *e = getenv("EMAVFI_CONV_S2RING"); return e && e[0] == '0'; }();
+    const bool s2r_off = env.s2ring_off;
     L.ring = (L.stride == 2 && esize == 2 && L.cin_pad == 64 && (L.cout + 31) / 32 == 4 && !s2r_off) ? 1 : 0;
     if (L.ring) {
         L.ck = 64; L.nchunk = 1; L.nf = 4; L.npass = 1; L.coutpad = 128;
@@ -85,9 +102,7 @@ bool conv_geometry(Layer &L, int esize)
     }
     // 64 -> 64 and 65..67 -> 64 at stride 1 (feat_ext_blocks, motion_estimation.0 / .1, reconstruction.0): conv_ring.inl.
     // EMAVFI_CONV_RING=0 keeps round 2's plans (conv3x3_pingpong16_kernel / the CK = 80 tile kernel; changes the packing: set before packing)
-    // (read per call, like EMAVFI_CONV_MFMA16 below: tests compare the plans inside one process)
-    const char *ring_env = getenv("EMAVFI_CONV_RING");
-    const bool ring_off = ring_env && ring_env[0] == '0';
+    const bool ring_off = env.ring_off;
     if (L.stride == 1 && esize == 2 && L.cout > 32 && L.cout <= 64 && L.cin_take >= 64 && L.cin_take <= 67 && !ring_off) {
         L.ring = L.cin_take == 64 ? 2 : 3;
         L.ck = L.cin_pad; L.nchunk = 1; L.nf = 2; L.npass = 1; L.coutpad = 64;
@@ -124,11 +139,10 @@ bool conv_geometry(Layer &L, int esize)
     if (!conv_inst_exists(L.ck, L.nf, L.stride, esize)) return false;
     L.w_bytes = (size_t)L.npass * L.nchunk * 9 * (L.ck * esize / 32) * L.nf * 1024;
     // full-resolution 64-channel layers with two output fragments: the 16x16x32 MFMA shape (conv3x3.inl, conv3x3_persist16_kernel).
-    // EMAVFI_CONV_MFMA16=0 keeps the 32x32x16 kernels (read per call: tests compare the two inside one process).
-    const char *m16 = getenv("EMAVFI_CONV_MFMA16");
-    L.mfma16 = esize == 2 && L.stride == 1 && L.ck == 64 && (L.nf == 2 || L.nf == 1) && L.nchunk == 1 && L.npass == 1 && !(m16 && m16[0] == '0');
+    // EMAVFI_CONV_MFMA16=0 keeps the 32x32x16 kernels.
+    L.mfma16 = esize == 2 && L.stride == 1 && L.ck == 64 && (L.nf == 2 || L.nf == 1) && L.nchunk == 1 && L.npass == 1 && !env.m16_off;
     // 32 -> <= 4 channels (reconstruction.2): the planar-head kernel on 16x16x32 (conv_light.inl) reads the same regrouped packing
-    if (esize == 2 && L.stride == 1 && L.ck == 32 && L.nf == 1 && L.nchunk == 1 && L.npass == 1 && L.cout <= 4 && !(m16 && m16[0] == '0')) L.mfma16 = true;
+    if (esize == 2 && L.stride == 1 && L.ck == 32 && L.nf == 1 && L.nchunk == 1 && L.npass == 1 && L.cout <= 4 && !env.m16_off) L.mfma16 = true;
     return true;
 }
 
@@ -220,7 +234,7 @@ bool build_plan(Plan &P, int in_ch, int mid, int nb, int dtype)
 
     size_t o = 0;
     auto place = [&](Layer &L, bool deform) {
-        const bool ok = deform ? deform_geometry(L, P.esize) : conv_geometry(L, P.esize);
+        const bool ok = deform ? deform_geometry(L, P.esize) : conv_geometry(L, P.esize, process_layout_env());
         if (!ok) return false;
         L.w_off = o; o = rup256(o + L.w_bytes);
         L.b_off = o; o = rup256(o + (size_t)L.coutpad * sizeof(float));
@@ -228,7 +242,7 @@ bool build_plan(Plan &P, int in_ch, int mid, int nb, int dtype)
     };
     // 16-bit, 6 -> 64: the fused cat + conv kernel (conv_first.inl) reads its own 10 KiB fragment copy behind the regular one
     // (the blob always carries both layouts: EMAVFI_CONV_FIRST=0, read per forward, runs pack_input + conv3x3<16,2,1> - A/B, parity test)
-    bool ok = conv_geometry(P.conv1, P.esize);
+    bool ok = conv_geometry(P.conv1, P.esize, process_layout_env());
     if (ok) {
         P.conv1.first6 = P.esize == 2 && P.conv1.cout == 64 && P.conv1.cin_take == 6;
         P.conv1.w_off = o; o = rup256(o + P.conv1.w_bytes + (P.conv1.first6 ? 10240 : 0));
@@ -835,7 +849,7 @@ int emavfi_postprocess_u8(const float *frames_nchw, unsigned char *out_hwc, int 
 static bool single_conv_layer(Layer &L, int Cin, int Cout, int stride, int esize)
 {
     L = mk(0, Cout, Cin, stride);
-    return conv_geometry(L, esize);
+    return conv_geometry(L, esize, read_layout_env());   // stage-level entry: packs and runs inside one call
 }
 
 size_t emavfi_conv3x3_workspace_bytes(int B, int Cin, int Cout, int H, int W, int stride, int dtype)

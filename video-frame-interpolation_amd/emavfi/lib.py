@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import collections
 import threading
 from ctypes import c_int, c_size_t, c_void_p, c_char_p, POINTER
 
@@ -128,8 +129,12 @@ def _f32c(t):
 #     dropping the old buffer on growth safe: it was only ever used on that stream;
 #   * a buffer that was handed out while its stream was being captured into a hipGraph has its address baked into the
 #     graph: it is never freed on growth but parked in _ws_graph_held (until release_workspaces()), so replaying the
-#     graph after a later, larger forward still writes to memory nobody else owns.
-_ws_cache = {}        # (device index, stream handle) -> uint8 tensor
+#     graph after a later, larger forward still writes to memory nobody else owns;
+#   * the cache holds at most EMAVFI_WS_CACHE_MAX (default 8) buffers: a caller that runs forwards on transient streams would
+#     otherwise pin one workspace (GBs at B = 8 x 720p) per stream handle it ever used.  The least recently used buffer that no
+#     captured graph may point at is dropped first (the caching allocator keeps a freed block on its allocation stream's pool,
+#     so work still queued on that stream is not disturbed).  Captured buffers are only released by release_workspaces().
+_ws_cache = collections.OrderedDict()   # (device index, stream handle) -> uint8 tensor, least recently used first
 _ws_captured = set()  # keys whose current buffer a captured graph may point at
 _ws_graph_held = []
 _ws_lock = threading.Lock()
@@ -150,6 +155,10 @@ def workspace(nbytes: int, device):
             with torch.cuda.device(index):
                 buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=torch.device("cuda", index))
             _ws_cache[key] = buf
+            cap = max(1, int(os.environ.get("EMAVFI_WS_CACHE_MAX", "8")))
+            for old in [k for k in _ws_cache if k != key and k not in _ws_captured][:max(0, len(_ws_cache) - cap)]:
+                del _ws_cache[old]
+        _ws_cache.move_to_end(key)
         if capturing:
             _ws_captured.add(key)
     return buf

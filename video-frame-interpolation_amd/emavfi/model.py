@@ -231,13 +231,18 @@ class EMA_VFI(nn.Module):
 
     @staticmethod
     def _cache_read(path, nbytes, device):
-        if path is None or not os.path.isfile(path) or os.path.getsize(path) != nbytes:
+        """The file is the blob followed by the sha256 of the blob: a truncated, foreign or bit-rotten file is ignored (and
+        overwritten by the re-pack), never run."""
+        if path is None or not os.path.isfile(path) or os.path.getsize(path) != nbytes + 32:
             return None
         try:
             import numpy as np
-            return torch.from_numpy(np.fromfile(path, dtype=np.uint8)).to(device)
+            raw = np.fromfile(path, dtype=np.uint8)
         except OSError:
             return None
+        if raw.size != nbytes + 32 or hashlib.sha256(raw[:nbytes].tobytes()).digest() != raw[nbytes:].tobytes():
+            return None
+        return torch.from_numpy(raw[:nbytes].copy()).to(device)
 
     @staticmethod
     def _cache_write(path, blob):
@@ -246,8 +251,10 @@ class EMA_VFI(nn.Module):
         try:  # best effort: a read-only or full cache directory must never fail a forward
             os.makedirs(os.path.dirname(path), exist_ok=True)
             fd, tmp = tempfile.mkstemp(dir=os.path.dirname(path), suffix=".tmp")
+            data = blob.cpu().numpy().tobytes()
             with os.fdopen(fd, "wb") as f:
-                f.write(blob.cpu().numpy().tobytes())
+                f.write(data)
+                f.write(hashlib.sha256(data).digest())
             os.replace(tmp, path)  # atomic: concurrent ranks write identical bytes
         except OSError:
             pass
