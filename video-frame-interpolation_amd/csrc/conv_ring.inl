@@ -39,7 +39,11 @@ template <typename T, bool TAIL, bool HEAD> struct ConvRingCfg {
     static constexpr int PSTR = 144, SP = 9, TW = 64, IW = TW + 2, ROWSLOT = IW * SP, ROWINST = (ROWSLOT + 63) / 64, ROWB = ROWINST * 1024;
     static constexpr int TWO = HEAD ? TW - 2 : TW;   // columns a strip contributes to the launch's output
     static constexpr int D = HEAD ? 2 : EMAVFI_RING_DEPTH, RING = D + 2;
-    static constexpr int STG_PX = 128 + 16, STG = TW * STG_PX, NSTG = HEAD ? 4 : 2;   // !HEAD: output staging rows; HEAD: the ring of 64 -> 64 rows
+    // !HEAD: two output staging rows, 144-byte pixels (conflict-free for the 32x32 epilogue's writes and the 8-lanes-per-pixel store reads).
+    // HEAD: the ring of four 64 -> 64 rows, UNPADDED 128-byte pixels whose 16-byte unit u of pixel c lies at u ^ swz16(c): the head's
+    // 16x16x32 operand reads (lane (j, kb): unit 4 k32 + kb of pixel c0 + j) are conflict-free that way; at 144 bytes every service
+    // group of every read had a two-way conflict (20.3 % of the kernel's LDS cycles; tools/lds_swizzle_search.py)
+    static constexpr int STG_PX = HEAD ? 128 : 128 + 16, STG = TW * STG_PX, NSTG = HEAD ? 4 : 2;
     static constexpr int STG_OFF = RING * ROWB, BIAS_OFF = STG_OFF + NSTG * STG, BIAS_BYTES = HEAD ? 256 : 16 * 64 * 4;
     static constexpr int HW_OFF = BIAS_OFF + BIAS_BYTES, HW_BYTES = HEAD ? 9 * 2 * 2 * 64 + 16 : 0;   // head weights [tap][k32][row 0..1][kb][8] + a zero slot
     static constexpr int SCRATCH_OFF = HW_OFF + HW_BYTES, LDS_BYTES = SCRATCH_OFF + 1024;
@@ -184,10 +188,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
                 hacc[0][0] = hb0; hacc[0][1] = hb1;   // (rows 0..1 of the lanes with kb == 0; zero elsewhere)
                 const char *hw = smem + C::HW_OFF + (j < 2 ? (j * 4 + kb) * 16 : 9 * 2 * 2 * 64);   // rows >= 2 of the A operand: the zero slot
                 int hwstep = j < 2 ? 128 : 0;
-                const char *xm0 = smem + C::STG_OFF + (wave * 16 + j) * C::STG_PX + kb * 16;
+                // byte offsets of this lane's operand inside a row: pixel c = 16 w + j + dx, unit (4 k32 + kb) ^ swz16(c)
+                int xo[3][2];
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int c = wave * 16 + j + dx;
+                    xo[dx][0] = c * C::STG_PX + ((kb ^ swz16(c)) << 4);
+                    xo[dx][1] = xo[dx][0] ^ 64;
+                }
                 const char *xr[3];
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy) xr[dy] = xm0 + ((yb - 1 + dy - a0) & 3) * C::STG;
+                for (int dy = 0; dy < 3; ++dy) xr[dy] = smem + C::STG_OFF + ((yb - 1 + dy - a0) & 3) * C::STG;
                 // operands four steps ahead of their MFMAs, fenced like the main loop's (18 dependent read -> MFMA pairs would cost
                 // an LDS round trip each)
                 constexpr int HA = 4;
@@ -195,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
                 auto hload = [&](int tk) {
                     asm volatile("" : "+v"(hwstep));   // (or hipcc keeps 18 weight addresses in registers)
                     hv[tk % (HA + 1)] = *reinterpret_cast<const vec *>(hw + tk * hwstep);
-                    hx[tk % (HA + 1)] = *reinterpret_cast<const vec *>(xr[tk / 6] + ((tk >> 1) % 3) * C::STG_PX + (tk & 1) * 64);
+                    hx[tk % (HA + 1)] = *reinterpret_cast<const vec *>(xr[tk / 6] + xo[(tk >> 1) % 3][tk & 1]);
                 };
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -299,7 +310,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
                 typedef __attribute__((ext_vector_type(2))) T pair_t;
                 const int slot = HEAD ? ((y - a0) & 3) : (y & 1);
                 const bool inside = !HEAD || ((unsigned)y < (unsigned)p.Hout && (unsigned)xg < (unsigned)p.Wout);
-                lchar_t *stg = (lchar_t *)smem + C::STG_OFF + slot * C::STG + (cb * 32 + r) * C::STG_PX + frag * 64;
+                lchar_t *stg = (lchar_t *)smem + C::STG_OFF + slot * C::STG + (cb * 32 + r) * C::STG_PX;
+                const int usw = HEAD ? swz16(cb * 32 + r) : 0;
 #pragma unroll
                 for (int g = 0; g < 4; g += 2) {
                     unsigned a[2], c[2];
@@ -315,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
                         const auto sw = __builtin_amdgcn_permlane32_swap(ua, ub, false, false);
                         a[q] = sw[0]; c[q] = sw[1];
                     }
-                    *reinterpret_cast<__attribute__((address_space(3))) u4_t *>(stg + 16 * (g + h)) = u4_t{a[0], a[1], c[0], c[1]};
+                    *reinterpret_cast<__attribute__((address_space(3))) u4_t *>(stg + 16 * ((frag * 4 + g + h) ^ usw)) = u4_t{a[0], a[1], c[0], c[1]};
                 }
             }
             s0 = s0 + 1 >= C::RING ? 0 : s0 + 1;
