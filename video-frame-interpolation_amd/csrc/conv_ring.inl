@@ -20,8 +20,8 @@
 //   * outputs go through a double-buffered LDS row (64 pixels x 128 bytes) so that a store instruction writes whole lines;
 //   * HEAD (motion_estimation.1 + .2, ema_vfi.py:90-92): the 64 -> 64 rows are NOT stored; they go (zeroed outside the image: the
 //     next convolution's padding) into a second LDS ring of four rows, and two steps behind them the same workgroup computes
-//     the 64 -> <= 4 planar head (the flow) from that ring on v_mfma_f32_16x16x32: wave w the 16 columns [16 w, 16 w + 16), the
-//     head's two real weight rows from a 2.3 KiB LDS table (all other rows of the A operand read one zero slot).  A strip then
+//     the 64 -> <= 2 planar head (the flow) from that ring on v_mfma_f32_16x16x32, its 18 k-steps split over the four waves (the
+//     weights of a wave's steps are 20 registers; the partial sums meet in LDS one step later).  A strip then
 //     yields 62 head columns for 64 computed ones and a segment computes two extra rows; in exchange one launch, 0.94 GB of
 //     writes and 0.94 GB of reads per B = 8 x 720p disappear (DMA depth 2 instead of 3: the two rings fill the 80 KiB);
 //   * work items = (strip, vertical segment), dealt round-robin to 2 workgroups per CU; the host picks the segment height so
@@ -45,7 +45,7 @@ template <typename T, bool TAIL, bool HEAD> struct ConvRingCfg {
     // group of every read had a two-way conflict (20.3 % of the kernel's LDS cycles; tools/lds_swizzle_search.py)
     static constexpr int STG_PX = HEAD ? 128 : 128 + 16, STG = TW * STG_PX, NSTG = HEAD ? 4 : 2;
     static constexpr int STG_OFF = RING * ROWB, BIAS_OFF = STG_OFF + NSTG * STG, BIAS_BYTES = HEAD ? 256 : 16 * 64 * 4;
-    static constexpr int HW_OFF = BIAS_OFF + BIAS_BYTES, HW_BYTES = HEAD ? 9 * 2 * 2 * 64 + 16 : 0;   // head weights [tap][k32][row 0..1][kb][8] + a zero slot
+    static constexpr int HW_OFF = BIAS_OFF + BIAS_BYTES, HW_BYTES = HEAD ? 2 * 2048 : 0;   // head partial sums [row parity][wave][block][pixel][2] floats
     static constexpr int SCRATCH_OFF = HW_OFF + HW_BYTES, LDS_BYTES = SCRATCH_OFF + 1024;
     static constexpr int NDMA = (ROWINST + 3) / 4, NSTORE = 2, VMWAIT = NSTORE + (NDMA + NSTORE) * (D - 2);
     static constexpr int WMAIN = 9 * 4 * 2 * 1024;   // bytes of [tap][kg][fragment][lane][8]; the tail [j 3][fragment][lane][8] follows
@@ -88,16 +88,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
             for (int j = 0; j < 3; ++j) wt[j] = *reinterpret_cast<const vec *>(wb + C::WMAIN + j * 2048);
         }
     }
-    float hb0 = 0.0f, hb1 = 0.0f;   // the head's bias in the lanes that hold its output rows (loaded once: a global load inside the row
-                                    // loop would make hipcc wait vmcnt(0), i.e. for the whole DMA ring)
+    // ---- HEAD: the 18 k-steps (tap, k32) of the 64 -> 2 head are split over the four waves (wave w: steps w, w + 4, .., < 18), each
+    // for all four 16-pixel blocks of the strip: the step's weights are 4 registers of the wave (20 in all) instead of an LDS read per
+    // MFMA - the fused kernel is LDS-bandwidth-bound - and the waves' partial sums meet in LDS one step later (head_finish).
+    // Weights: block 0 of the 16x16x32 packing [tap][k32][cout16 block 0..1][lane (i, kb)][8] (rows >= 2 are zero in the blob).
+    float hb0 = 0.0f, hb1 = 0.0f;   // the head's bias (loaded once: a global load inside the row loop would make hipcc wait vmcnt(0),
+                                    // i.e. for the whole DMA ring)
+    vec hwr[HEAD ? 5 : 1];
+    int hxo[HEAD ? 5 : 1], hdy[HEAD ? 5 : 1];
     if constexpr (HEAD) {
-        if ((lane >> 4) == 0) { hb0 = p.head_bias[0]; hb1 = p.nplanes > 1 ? p.head_bias[1] : 0.0f; }
-        // the head's weights: rows 0..1 of block 0 of the 16x16x32 packing [tap][k32][cout16 block 0..1][lane (i, kb)][8]
-        if (tid < 9 * 2 * 2 * 4) {
-            const int kb = tid & 3, i = (tid >> 2) & 1, tk = tid >> 3;
-            reinterpret_cast<u4_t *>(smem + C::HW_OFF)[tid] = *reinterpret_cast<const u4_t *>((const char *)p.head_w + tk * 2048 + (kb * 16 + i) * 16);
+        hb0 = p.head_bias[0]; hb1 = p.nplanes > 1 ? p.head_bias[1] : 0.0f;
+        const int j = lane & 15, kb = lane >> 4;
+#pragma unroll
+        for (int sl = 0; sl < 5; ++sl) {
+            const int tk = min(wave_u + 4 * sl, 17), tap = tk >> 1, k32 = tk & 1, dy = tap / 3, dx = tap - 3 * dy;
+            hwr[sl] = *reinterpret_cast<const vec *>((const char *)p.head_w + tk * 2048 + lane * 16);
+            hdy[sl] = dy;
+            // byte offset of this lane's operand inside a row for column block 0: pixel c = j + dx, unit (4 k32 + kb) ^ swz16(c)
+            // (block n adds 16 pixels = 2048 bytes: swz16 has period 8 pixels)
+            hxo[sl] = ((j + dx) * C::STG_PX + ((kb ^ swz16(j + dx)) << 4)) ^ (k32 * 64);
         }
-        if (tid == 255) reinterpret_cast<u4_t *>(smem + C::HW_OFF)[9 * 2 * 2 * 4] = u4_t{0u, 0u, 0u, 0u};
     }
     // ---- lane constants of the row DMA: instruction jn covers 16-byte slots [64 jn, 64 jn + 64) of a ring row
     unsigned xoff[C::NDMA];
@@ -180,51 +190,57 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
                 __builtin_amdgcn_raw_buffer_store_b128(v, rs, soff[i], 0, 0);
             }
         };
-        // head row yb from the 64 -> 64 rows yb - 1 .. yb + 1 (mid-ring slots (row - a0) & 3); NSTORE = 2 stores: planes 0 and 1
-        auto head_row = [&](int yb, bool real) {
-            f32x4 hacc[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+        // head row yb from the 64 -> 64 rows yb - 1 .. yb + 1 (mid-ring slots (row - a0) & 3): this wave's k-steps, all four blocks
+        auto head_partial = [&](int yb) {
             if constexpr (HEAD) {
-                const int j = lane & 15, kb = lane >> 4;
-                hacc[0][0] = hb0; hacc[0][1] = hb1;   // (rows 0..1 of the lanes with kb == 0; zero elsewhere)
-                const char *hw = smem + C::HW_OFF + (j < 2 ? (j * 4 + kb) * 16 : 9 * 2 * 2 * 64);   // rows >= 2 of the A operand: the zero slot
-                int hwstep = j < 2 ? 128 : 0;
-                // byte offsets of this lane's operand inside a row: pixel c = 16 w + j + dx, unit (4 k32 + kb) ^ swz16(c)
-                int xo[3][2];
+                f32x4 hp[4];
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int c = wave * 16 + j + dx;
-                    xo[dx][0] = c * C::STG_PX + ((kb ^ swz16(c)) << 4);
-                    xo[dx][1] = xo[dx][0] ^ 64;
-                }
-                const char *xr[3];
+                for (int n = 0; n < 4; ++n) hp[n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                const char *xs[5];
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy) xr[dy] = smem + C::STG_OFF + ((yb - 1 + dy - a0) & 3) * C::STG;
-                // operands four steps ahead of their MFMAs, fenced like the main loop's (18 dependent read -> MFMA pairs would cost
-                // an LDS round trip each)
+                for (int sl = 0; sl < 5; ++sl) xs[sl] = smem + C::STG_OFF + ((yb - 1 + hdy[sl] - a0) & 3) * C::STG + hxo[sl];
+                // 16 (read, MFMA) pairs, operands four pairs ahead (fenced like the main loop's); four independent chains
                 constexpr int HA = 4;
-                vec hx[HA + 1], hv[HA + 1];
-                auto hload = [&](int tk) {
-                    asm volatile("" : "+v"(hwstep));   // (or hipcc keeps 18 weight addresses in registers)
-                    hv[tk % (HA + 1)] = *reinterpret_cast<const vec *>(hw + tk * hwstep);
-                    hx[tk % (HA + 1)] = *reinterpret_cast<const vec *>(xr[tk / 6] + xo[(tk >> 1) % 3][tk & 1]);
-                };
+                vec hx[HA + 1];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int tk = 0; tk < HA; ++tk) hload(tk);
+                for (int q = 0; q < HA; ++q) hx[q] = *reinterpret_cast<const vec *>(xs[q >> 2] + (q & 3) * 2048);
 #pragma unroll
-                for (int tk = 0; tk < 18; ++tk) {
-                    if (tk + HA < 18) hload(tk + HA);
-                    mma_k32(hacc[tk & 1], hv[tk % (HA + 1)], hx[tk % (HA + 1)]);
+                for (int q = 0; q < 16; ++q) {
+                    if (q + HA < 16) hx[(q + HA) % (HA + 1)] = *reinterpret_cast<const vec *>(xs[(q + HA) >> 2] + ((q + HA) & 3) * 2048);
+                    mma_k32(hp[q & 3], hwr[q >> 2], hx[q % (HA + 1)]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if (wave_u + 16 < 18) {   // waves 0 and 1 own a fifth k-step
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) hx[n] = *reinterpret_cast<const vec *>(xs[4] + n * 2048);
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) mma_k32(hp[n], hwr[4], hx[n]);
+                }
+                if (lane < 16) {   // output rows 0..1 of a pixel live in the lanes with kb == 0
+                    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+                    char *pp = smem + C::HW_OFF + (yb & 1) * 2048 + (wave * 4 * 16 + lane) * 8;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) *reinterpret_cast<f32x2_t *>(pp + n * 128) = f32x2_t{hp[n][0], hp[n][1]};
+                }
+            }
+        };
+        // one step later: wave b adds the four partial sums of block b and stores the row (NSTORE = 2 stores: planes 0 and 1)
+        auto head_finish = [&](int yb, bool real) {
+            if constexpr (HEAD) {
+                typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+                const char *pp = smem + C::HW_OFF + (yb & 1) * 2048 + (wave * 16 + (lane & 15)) * 8;
+                const f32x2_t p0 = *reinterpret_cast<const f32x2_t *>(pp), p1 = *reinterpret_cast<const f32x2_t *>(pp + 512);
+                const f32x2_t p2 = *reinterpret_cast<const f32x2_t *>(pp + 1024), p3 = *reinterpret_cast<const f32x2_t *>(pp + 1536);
+                float v[2] = {((p0[0] + p1[0]) + (p2[0] + p3[0])) + hb0, ((p0[1] + p1[1]) + (p2[1] + p3[1])) + hb1};
                 const size_t plane = (size_t)p.Hout * p.Wout;
                 float *orow = p.out_planar + (size_t)b * p.nplanes * plane + (size_t)(real ? yb : ys) * p.Wout;
 #pragma unroll
                 for (int i = 0; i < C::NSTORE; ++i) {
-                    float v = hacc[0][i] + hacc[1][i];
-                    if (p.round16) v = (float)(half_t)v;
+                    float o = v[i];
+                    if (p.round16) o = (float)(half_t)o;
                     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(orow + (i < p.nplanes ? i : 0) * plane, 0, real ? 0x7ffffff0 : 0, 0x00020000);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, soff[i], 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rs, soff[i], 0, 0);
                 }
             }
         };
@@ -232,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
 #pragma unroll 1
         for (int k = 0; k <= C::D; ++k) {
             dma_row(a0 - 1 + k, k, a0 - 1 + k <= a1 + 1);
-            if constexpr (HEAD) head_row(ys, false); else store_row(ys, false);
+            if constexpr (HEAD) head_finish(ys, false); else store_row(ys, false);
         }
         int s0 = 0;   // ring slot of input row y - 1
 #pragma unroll 1
@@ -245,7 +261,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
                 int sl = s0 + C::D + 1; sl = sl >= C::RING ? sl - C::RING : sl;
                 dma_row(y + C::D, sl, y + C::D <= a1 + 1);
             }
-            if constexpr (HEAD) head_row(y - 2, y - 2 >= ys && !(EMAVFI_RING_ABL & 2)); else store_row(y - 1, y > a0 && !(EMAVFI_RING_ABL & 2));
+            if constexpr (HEAD) {
+                head_finish(y - 3, y - 3 >= ys && !(EMAVFI_RING_ABL & 2));
+                head_partial(y - 2);
+            } else
+                store_row(y - 1, y > a0 && !(EMAVFI_RING_ABL & 2));
             f32x16 acc[2];
             {
                 // motion_estimation.0 (bias_mode 1): the folded context half depends on the pixel's border class
@@ -335,8 +355,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the next item primes the same slots)
         __syncthreads();
         if constexpr (HEAD) {
-            head_row(a1 - 1, true);   // (= ye - 1; row ye - 2 was the last step's)
-            __syncthreads();          // the next item's first rows overwrite the ring of 64 -> 64 rows
+            head_finish(a1 - 2, a1 - 2 >= ys);   // (a1 = ye: rows ye - 2 and ye - 1 are still to come)
+            head_partial(a1 - 1);
+            __syncthreads();
+            head_finish(a1 - 1, true);
+            __syncthreads();                     // the next item's first rows overwrite the ring of 64 -> 64 rows and the partial sums
         } else
             store_row(a1, true);
     }
