@@ -3,7 +3,7 @@
 
   python tools/make_profiles.py gpurun_out/r02/prof_x r02_final [--install]
 
-  profiles/<tag>_bench_kernel_stats.csv      rocprofv3 --kernel-trace --stats summary of `bench.py --steps 5 --warmup 2 --no-extras`
+  profiles/<tag>_bench_kernel_stats.csv      rocprofv3 --kernel-trace --stats summary of `bench.py --steps 30 --warmup 2 --no-extras`
   profiles/<tag>_pmc_traffic_detail.json     HBM bytes per launch per kernel (FETCH_SIZE x2 + WRITE_SIZE, separate passes)
   profiles/<tag>_sq_counters.json            SQ counters (two passes) of the three heaviest kernels, with derived shares
   profiles/traffic.json (--install)          {kernel label: bytes}, stamped with the sha of the kernel sources
