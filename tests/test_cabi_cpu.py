@@ -162,6 +162,58 @@ def test_device_code_has_no_packed_f32_operations(tmp_path):
     assert packed == 0, f"{packed} packed f32 VALU operations in the device code: was NOPK dropped from the build?"
 
 
+def _device_disassembly(tmp_path):
+    import re
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(f"{llvm}/clang-offload-bundler") or shutil.which("objcopy") is None:
+        pytest.skip("ROCm binutils not available")
+    fat = tmp_path / "fat.bin"
+    subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib.LIB_PATH, str(fat)])
+    blob = fat.read_bytes()
+    starts = [m.start() for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", blob)]
+    out = []
+    for i, a in enumerate(starts):
+        part = tmp_path / f"b_{i}.bin"
+        part.write_bytes(blob[a:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+        co = tmp_path / f"d_{i}.co"
+        subprocess.check_call([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                               f"--input={part}", f"--output={co}"])
+        out.append(subprocess.run([f"{llvm}/llvm-objdump", "-d", str(co)], capture_output=True, text=True, check=True).stdout)
+    return out
+
+
+def test_ring_kernels_issue_a_fixed_number_of_vmem_instructions_per_step(tmp_path):
+    """csrc/conv_ring.inl retires its LDS-DMA ring with a COUNTED `s_waitcnt vmcnt(N)`: N is only right while every wave issues
+    exactly 3 DMA + 2 store instructions per row step and nothing else that counts.  hipcc is free to
+    break that silently (a branch over an all-inactive store, a spill, a hoisted load), so the shipped code objects are checked:
+    between the counted wait and the drain behind the row loop there are three global_load_lds, two buffer stores and no other
+    vector-memory instruction, and N is 2 + 5 (D - 2) (D = 3; the fused head kernel: D = 2)."""
+    import re
+    seen = {}
+    for dis in _device_disassembly(tmp_path):
+        for name, body in re.findall(r"<(_Z19conv3x3_ring_kernel\w+)>:\n(.*?)(?=\n\n|\Z)", dis, re.S):
+            lines = body.splitlines()
+            tops = [i for i, l in enumerate(lines) if re.search(r"s_waitcnt vmcnt\((\d+)\) lgkmcnt\(0\)", l) and "vmcnt(0)" not in l]
+            assert len(tops) == 1, (name, "one counted wait (the row loop's) expected", len(tops))
+            n = int(re.search(r"vmcnt\((\d+)\)", lines[tops[0]]).group(1))
+            assert "s_barrier" in " ".join(lines[tops[0]:tops[0] + 4]), name
+            # the loop body runs from the counted wait to the drain behind the loop, or to the end of the function where hipcc
+            # laid the exit block out in front of the loop
+            drain = next((i for i in range(tops[0] + 1, len(lines)) if re.search(r"s_waitcnt vmcnt\(0\)\s*$", lines[i].split("//")[0].rstrip())), len(lines))
+            region = "\n".join(lines[tops[0]:drain])
+            dma = len(re.findall(r"global_load_lds_dwordx4", region))
+            stores = len(re.findall(r"buffer_store_dword", region))
+            other = len(re.findall(r"\b(?:global_load_dword|global_store|buffer_load|flat_load|flat_store|scratch_)", region))
+            head = "Lb0ELb1E" in name
+            assert (dma, stores, other) == (3, 2, 0), (name, dma, stores, other)
+            assert n == (2 if head else 7), (name, n)
+            seen[name] = n
+    # bf16 and f16 instances of: 64 -> 64, TAIL (67 -> 64), HEAD (+ flow head)
+    assert len(seen) == 6, sorted(seen)
+
+
 def test_packed_cache_file_carries_a_checksum(tmp_path):
     """ADVICE r2: the on-disk packed-weight cache trusted any file of the right size.  The file is now blob + sha256(blob);
     a flipped byte, a truncated file or a file of the old format is ignored (the caller re-packs and overwrites it)."""
