@@ -620,6 +620,31 @@ def test_fused_first_two_layers_equal_the_two_launch_path(dtype, shape, monkeypa
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(2, 75, 131), (1, 1, 7), (1, 2, 62), (1, 3, 63), (1, 17, 124), (3, 40, 125), (1, 360, 640)])
+def test_fused_reconstruction_tail_equals_the_two_launch_path(dtype, shape, monkeypatch):
+    """16-bit modes at mid_channels 64 run reconstruction.1 + .2 (64 -> 32 + ReLU, 32 -> 3 + tanh, (t + 1) / 2) as ONE launch
+    (csrc/conv_ring_tail.inl): .1's rows stay in an LDS ring, its 18 k-steps are split between two waves (another fp32 summation
+    order than the unfused kernel's: .1's stored values may differ in the last place of the storage type in a few elements).
+    EMAVFI_CONV_TAILFUSE=0 runs conv3x3_persist16_kernel + conv_light_kernel.  The frames must agree to a few such units; widths
+    around the 62-column strip pitch, one- and two-row images, several segments per strip, several samples."""
+    B, H, W = shape
+    sd = synth.synthetic_state_dict(seed=7)
+    f1, f2 = (t.to(DEV) for t in synth.synthetic_frames(33, B, H, W, "natural"))
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("EMAVFI_CONV_TAILFUSE", flag)
+        m = make_model(sd, dtype=dtype)
+        with torch.no_grad():
+            outs.append(m(f1, f2).clone())
+        names = [n for n, _, _ in lib.forward_launches(3, 64, 3, B, H, W, dtype)]
+        assert sum(n.startswith("conv3x3+tail") for n in names) == int(flag)
+    err = (outs[0] - outs[1]).abs()
+    print(f"{dtype} {shape}: frame max-abs diff {err.max().item():.3e}, {100 * (err > 0).float().mean().item():.2f} % of the elements differ")
+    assert torch.isfinite(outs[0]).all() and outs[0].min() >= 0 and outs[0].max() <= 1
+    assert err.max().item() <= (8e-3 if dtype == "bf16" else 1e-3)
+
+
 def test_fused_first_layer_equals_pack_input_plus_conv(monkeypatch):
     """16-bit modes at mid_channels 64 compute cat(frame1, frame2) + feat_ext_conv1 + ReLU in ONE launch straight from the NCHW
     fp32 frames (csrc/conv_first.inl); EMAVFI_CONV_FIRST=0 runs pack_input + conv3x3.  Same rounded inputs, weights and products;

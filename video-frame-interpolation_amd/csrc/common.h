@@ -164,6 +164,8 @@ struct ConvParams {
                          // 2 = conv3x3_ring_kernel (64 -> 64), 3 = the same with the im2col tail (65..67 -> 64: reconstruction.0)
     const void *head_w;      // conv_ring.inl, ring == 2 only: fuse a 64 -> nplanes (<= 2) planar head (its weights in the 16x16x32 packing,
     const float *head_bias;  // its bias) behind this layer: `out` is not written, `out_planar` gets the head (round16 applies)
+    int epi2;                // conv_ring_tail.inl (64 -> 32 -> nplanes <= 3, this layer packed mfma16 with nf == 1): the head's epilogue
+                             // (EPI_PLANAR or EPI_PLANAR_TANH01)
     int in_pieces;       // 16-byte pieces of an input pixel (single-chunk layers) that exist in memory; 0 = all CK of them.
                          // Pieces beyond read as zeros: the 72-channel fusion buffers feed CK = 80 layers this way.
 };

@@ -26,6 +26,7 @@
 //   conv3x3_kernel            the tile-per-workgroup kernel described above (every shape; the only one for fp32, chunked K)
 //   conv3x3_s2ring_kernel     64 -> 128 at stride 2: weights in registers, input rows through an LDS ring (one strip per workgroup)
 //   conv3x3_ring_kernel       (conv_ring.inl) that structure at stride 1: the 64 -> 64 layers and reconstruction.0 (67 -> 64) (product)
+//   conv3x3_ringtail_kernel   (conv_ring_tail.inl) reconstruction.1 + .2 (64 -> 32 -> 3) through a second LDS ring (product)
 //   conv3x3_persist_kernel    persistent, nine taps' weights resident, 16 x 32 tiles, 8 waves in lock step (32x32x16 MFMAs)
 //   conv3x3_persist16_kernel  the same on v_mfma_f32_16x16x32 with an unpadded XOR-swizzled tile: 64 -> 32 and 64 -> planes
 //   conv3x3_pingpong16_kernel two four-wave groups half a tile out of phase on that shape: the 64 -> 64 layers (EMAVFI_CONV_RING=0)
@@ -955,10 +956,12 @@ template <typename T, int CK, int NF> static int launch_conv_pingpong16(const Co
 
 #include "conv_light.inl"
 #include "conv_ring.inl"
+#include "conv_ring_tail.inl"
 
 // weights packed for the 16x16x32 shape (ConvParams::mfma16): 64 -> 64 (four blocks), 64 -> 32 (two), 64 / 32 -> planes (one)
 template <typename T> static int launch_conv_mfma16(const ConvParams &p, hipStream_t s)
 {
+    if (p.head_w) return launch_conv_ringtail<T>(p, s);   // reconstruction.1 + .2 in one launch (conv_ring_tail.inl)
     const bool planar = p.epi == EPI_PLANAR || p.epi == EPI_PLANAR_TANH01;
     if (p.ck == 32 && p.stride == 1 && p.nchunk == 1 && p.npass == 1 && p.nf == 1 && planar && p.nplanes <= 4) return launch_conv_light<T, 32>(p, s);
     if (p.ck != 64 || p.stride != 1 || p.nchunk != 1 || p.npass != 1) return -2;

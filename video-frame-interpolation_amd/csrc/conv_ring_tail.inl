@@ -1,0 +1,252 @@
+// conv_ring_tail.inl - reconstruction.1 + .2 (64 -> 32 + ReLU, 32 -> 3 + tanh, (t + 1) / 2: ema_vfi.py:104-106, 146) in ONE launch for
+// the 16-bit modes at mid_channels = 64.  Included by conv3x3.inl behind conv_ring.inl, whose strip walk, LDS-DMA ring and counted
+// s_waitcnt it shares.
+//
+// The two layers ran as conv3x3_persist16_kernel (373 us) + conv_light_kernel (179 us) and moved 2.1 GB for 1.0 GB of input and
+// output: the 32-channel tensor between them was written and read back.  Here it exists only as an LDS ring of four rows:
+//   * stage A (64 -> 32) on v_mfma_f32_16x16x32 with the 18 (tap, k32) steps SPLIT between the two waves of a column block: wave
+//     (cb, kh) computes steps 9 kh .. 9 kh + 8 for both 16-channel output blocks and both 16-pixel halves of its 32 pixels -
+//     72 weight registers, 18 operand reads and 36 MFMAs per row; a step's operand read feeds four MFMAs (the 64 -> 64 ring kernel:
+//     one), which is what keeps this kernel off the LDS floor the fused flow head sits on.  The wave keeps the partial sums of
+//     "its" output block (kh) and hands the other block's to its partner through LDS; one step later each wave adds what it
+//     received, bias, ReLU, rounds to T and writes 16 channels of its 32 pixels into the row ring (zero outside the image);
+//   * stage B (32 -> 3, three steps behind): wave w computes the 16 columns [16 w, 16 w + 16) of the strip's 62, nine MFMAs with the
+//     weights in 36 registers; tanh, (t + 1) / 2, three planar fp32 stores;
+//   * both LDS images are UNPADDED and XOR-swizzled for the 16x16x32 operand pattern: the input ring (128-byte pixels, unit u of
+//     pixel c at u ^ swz16(c) - the DMA's lanes fetch the permuted piece) and the row ring (64-byte pixels, unit u at
+//     u ^ (((c >> 2) & 1) << 1)); both conflict-free on paper (tools/lds_swizzle_search.py);
+//   * per step and wave exactly 3 DMA + 3 store instructions: the counted wait is vmcnt(3 + 6 (D - 2)) = 9 at D = 3.
+#ifndef EMAVFI_RT_ABL
+#define EMAVFI_RT_ABL 0   // timing-only ablations (diagnostic builds): 1 every DMA reads the zero page, 2 no head, 4 no stage-A MFMAs
+#endif
+template <typename T> struct RingTailCfg {
+    static constexpr int TW = 64, TWO = TW - 2, IW = TW + 2, IN_PX = 128, ROWSLOT = IW * 8, ROWINST = (ROWSLOT + 63) / 64, ROWB = ROWINST * 1024;
+    static constexpr int D = 3, RING = D + 2, MID_PX = 64, MID = TW * MID_PX, NMID = 4, PART = 4 * 2048;
+    static constexpr int MID_OFF = RING * ROWB, PART_OFF = MID_OFF + NMID * MID, SCRATCH_OFF = PART_OFF + 2 * PART, LDS_BYTES = SCRATCH_OFF + 1024;
+    static constexpr int NDMA = (ROWINST + 3) / 4, NSTORE = 3, VMWAIT = NSTORE + (NDMA + NSTORE) * (D - 2);
+    static_assert(sizeof(T) == 2 && 2 * LDS_BYTES <= 160 * 1024 && NDMA == 3, "16-bit types; two workgroups per CU");
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvParams p, const int nseg, const int seg_rows)
+{
+    using C = RingTailCfg<T>;
+    using vec = typename DT<T>::vec;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) char lchar_t;
+    typedef __attribute__((ext_vector_type(2))) unsigned u2_t;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned lds0 = (unsigned)(size_t)(lchar_t *)smem;
+    const int j = lane & 15, kb = lane >> 4;
+    const int cb = wave_u >> 1, kh = wave_u & 1;
+    const int ntx = (p.Wout + C::TWO - 1) / C::TWO, nstrip = ntx * p.B, nitems = nstrip * nseg;
+    const char *zeros = (const char *)p.zeros;
+    const unsigned pixbytes = (unsigned)p.in_ps * (unsigned)sizeof(T);
+    const unsigned rowbytes = (unsigned)p.Win * pixbytes;
+    const auto s4 = [](int c) { return ((c >> 2) & 1) << 1; };   // the row ring's unit permutation
+
+    // ---- stage A: this wave's nine (tap, k32) steps; [0] = the output block it finalizes (kh), [1] = its partner's
+    // (weights: the 16x16x32 packing [tap][k32][cout16 block 0..1][lane (i, kb)][8])
+    vec wr[9][2];
+    int xoA[9], dyA[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int s = kh * 9 + i, tap = s >> 1, k32 = s & 1, dy = tap / 3, dx = tap - 3 * dy;
+        const char *wb = (const char *)p.w + ((tap * 2 + k32) * 2) * 1024 + lane * 16;
+        wr[i][0] = *reinterpret_cast<const vec *>(wb + kh * 1024);
+        wr[i][1] = *reinterpret_cast<const vec *>(wb + (1 - kh) * 1024);
+        dyA[i] = dy;
+        // operand of pixel half 0: pixel c = 32 cb + j + dx, unit (4 k32 + kb) ^ swz16(c) (half 1: + 16 pixels = 2048 bytes, same permutation)
+        xoA[i] = (cb * 32 + j + dx) * C::IN_PX + (((k32 * 4 + kb) ^ swz16(j + dx)) << 4);
+    }
+    float ba[4];   // bias of output channels 16 kh + 4 kb .. + 3 (the accumulator rows of this lane)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ba[e] = p.bias[kh * 16 + kb * 4 + e];
+    // ---- stage B: the head's nine taps (K = 32 each), block 0 of its packing; bias of rows 0..2 (lanes kb == 0)
+    vec hw[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) hw[t] = *reinterpret_cast<const vec *>((const char *)p.head_w + t * 2048 + lane * 16);
+    const float hb0 = p.head_bias[0], hb1 = p.nplanes > 1 ? p.head_bias[1] : 0.0f, hb2 = p.nplanes > 2 ? p.head_bias[2] : 0.0f;
+    int hxo[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) hxo[dx] = (wave * 16 + j + dx) * C::MID_PX + ((kb ^ s4(wave * 16 + j + dx)) << 4);
+    // ---- lane constants of the row DMA: 16-byte slot q of a ring row holds piece (q & 7) ^ swz16(q >> 3) of pixel q >> 3
+    unsigned xoff[C::NDMA], xcol[C::NDMA];
+#pragma unroll
+    for (int i = 0; i < C::NDMA; ++i) {
+        const int q = (i * 4 + wave) * 64 + lane, px = q >> 3, pc = (q & 7) ^ swz16(px);
+        xoff[i] = (unsigned)px * pixbytes + (unsigned)pc * 16u;
+        xcol[i] = q < C::ROWSLOT ? (unsigned)px : 0x40000000u;
+    }
+
+#pragma unroll 1
+    for (int item = (int)blockIdx.x; item < nitems; item += (int)gridDim.x) {
+        const int strip = item % nstrip, seg = item / nstrip;
+        const int b = strip / ntx, tx = strip - b * ntx;
+        const int ys = seg * seg_rows, ye = min(ys + seg_rows, p.Hout);
+        const int a0 = ys - 1, a1 = ye;             // stage-A rows of this item
+        const int ox0 = tx * C::TWO - 1, ix0 = ox0 - 1;
+        const char *gin = (const char *)p.in + (size_t)b * p.Hin * p.Win * p.in_ps * sizeof(T);
+        auto dma_row = [&](int gy, int slot, bool live) {   // exactly NDMA instructions per wave (conv_ring.inl)
+            const bool rowok = live && (unsigned)gy < (unsigned)p.Hin && !(EMAVFI_RT_ABL & 1);
+            const char *rowp = gin + (size_t)(rowok ? gy : 0) * rowbytes + (ptrdiff_t)ix0 * (ptrdiff_t)pixbytes;
+#pragma unroll
+            for (int i = 0; i < C::NDMA; ++i) {
+                const int jn = i * 4 + wave_u;
+                const bool ok = rowok && (unsigned)(ix0 + (int)xcol[i]) < (unsigned)p.Win;
+                const char *src = ok ? rowp + xoff[i] : zeros;
+                const unsigned dst = lds0 + (jn < C::ROWINST ? (unsigned)(slot * C::ROWB + jn * 1024) : (unsigned)C::SCRATCH_OFF);
+                // (no "memory" clobber: the slot written is not touched before the next counted wait, and LDS reads of this step
+                // may be scheduled around the DMA issue)
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst));
+            }
+        };
+        // the head's stores: wave w owns head columns [16 w, 16 w + 16); output rows 0..2 of a pixel live in the lanes with kb == 0
+        const int hc = wave * 16 + j, hx = tx * C::TWO + hc;
+        const unsigned soff = (hc < C::TWO && hx < p.Wout && kb == 0) ? (unsigned)hx * 4u : 0x80000000u;
+        const size_t plane = (size_t)p.Hout * p.Wout;
+        f32x4 keep[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};   // this wave's own-block partial sums of the previous stage-A row
+
+        // stage A, first half: row y's partial sums over this wave's nine steps; the partner's block goes to LDS
+        auto partial_a = [&](int y, int s0) {
+            f32x4 acc[2][2];
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb) acc[n][pb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            // LDS byte offsets, not pointers: a row-base array indexed by a run-time dy loses its address space and the reads become
+            // flat_load (vmcnt AND lgkmcnt: the counted wait would be wrong - tests/test_cabi_cpu.py checks the code object)
+            int xs[3];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                int sl = s0 + dy; sl = sl >= C::RING ? sl - C::RING : sl;
+                xs[dy] = sl * C::ROWB;
+            }
+            int xrow[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) xrow[i] = (dyA[i] == 0 ? xs[0] : dyA[i] == 1 ? xs[1] : xs[2]) + xoA[i];
+            constexpr int AH = 4;
+            vec xq[AH + 1];
+            auto xread = [&](int q) { return *reinterpret_cast<const __attribute__((address_space(3))) vec *>((lchar_t *)smem + xrow[q >> 1] + (q & 1) * 2048); };
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < AH; ++q) xq[q] = xread(q);
+#pragma unroll
+            for (int q = 0; q < 18; ++q) {
+                if (q + AH < 18) xq[(q + AH) % (AH + 1)] = xread(q + AH);
+                if (!(EMAVFI_RT_ABL & 4) || q == 0) {
+                    mma_k32(acc[0][q & 1], wr[q >> 1][0], xq[q % (AH + 1)]);
+                    mma_k32(acc[1][q & 1], wr[q >> 1][1], xq[q % (AH + 1)]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            lchar_t *pp = (lchar_t *)smem + C::PART_OFF + (y & 1) * C::PART + wave * 2048 + lane * 16;
+            *reinterpret_cast<__attribute__((address_space(3))) f32x4 *>(pp) = acc[1][0];
+            *reinterpret_cast<__attribute__((address_space(3))) f32x4 *>(pp + 1024) = acc[1][1];
+            keep[0] = acc[0][0]; keep[1] = acc[0][1];
+        };
+        // stage A, second half (one step later): own sums + the partner's + bias, ReLU, T; 16 channels of 32 pixels into the row ring
+        auto finish_a = [&](int y) {
+            const lchar_t *pp = (lchar_t *)smem + C::PART_OFF + (y & 1) * C::PART + (wave ^ 1) * 2048 + lane * 16;
+            const bool rowin = (unsigned)y < (unsigned)p.Hout;
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                const f32x4 r = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>(pp + pb * 1024);
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = (keep[pb][e] + r[e]) + ba[e];
+                    if (p.epi == EPI_RELU) v[e] = fmaxf(v[e], 0.0f);
+                }
+                typedef __attribute__((ext_vector_type(2))) T pair_t;
+                const pair_t lo = {(T)v[0], (T)v[1]}, hi = {(T)v[2], (T)v[3]};
+                const int c = cb * 32 + pb * 16 + j;
+                const bool inside = rowin && (unsigned)(ox0 + c) < (unsigned)p.Wout;
+                const unsigned keepm = inside ? ~0u : 0u;
+                // channels 16 kh + 4 kb .. + 3 = bytes 32 kh + 8 kb of the 64-byte pixel: unit 2 kh + (kb >> 1), half kb & 1
+                lchar_t *mp = (lchar_t *)smem + C::MID_OFF + ((y - a0) & 3) * C::MID + c * C::MID_PX + (((2 * kh + (kb >> 1)) ^ s4(c)) << 4) + (kb & 1) * 8;
+                *reinterpret_cast<__attribute__((address_space(3))) u2_t *>(mp) = u2_t{__builtin_bit_cast(unsigned, lo) & keepm, __builtin_bit_cast(unsigned, hi) & keepm};
+            }
+        };
+        // stage B: head row yb from the stage-A rows yb - 1 .. yb + 1; NSTORE = 3 stores (planes 0..2)
+        auto head_row = [&](int yb, bool real) {
+            f32x4 hacc[3] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+            int mr[3];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) mr[dy] = C::MID_OFF + ((yb - 1 + dy - a0) & 3) * C::MID;
+            vec hxv[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) hxv[t] = *reinterpret_cast<const __attribute__((address_space(3))) vec *>((lchar_t *)smem + mr[t / 3] + hxo[t % 3]);
+#pragma unroll
+            for (int t = 0; t < ((EMAVFI_RT_ABL & 2) ? 1 : 9); ++t) mma_k32(hacc[t % 3], hw[t], hxv[t]);
+            float v[3] = {(hacc[0][0] + hacc[1][0]) + hacc[2][0] + hb0, (hacc[0][1] + hacc[1][1]) + hacc[2][1] + hb1, (hacc[0][2] + hacc[1][2]) + hacc[2][2] + hb2};
+            float *orow = p.out_planar + (size_t)b * p.nplanes * plane + (size_t)(real ? yb : ys) * p.Wout;
+#pragma unroll
+            for (int i = 0; i < C::NSTORE; ++i) {
+                float o = v[i];
+                if (p.epi2 == EPI_PLANAR_TANH01) {   // ema_vfi.py:106,146 (round16: every op rounds as an fp16 tensor op does under autocast)
+                    if (p.round16) { o = (float)(half_t)o; o = (float)(half_t)((float)(half_t)tanhf(o) + 1.0f) / 2.0f; }
+                    // (tanh(x) + 1) / 2 = 1 / (1 + exp(-2x)): v_exp_f32 + v_rcp_f32 (2 ulp) instead of ocml's branchy tanhf, which cost this
+                    // kernel as much as its MFMAs (three calls per pixel on all 64 lanes of the wave)
+                    else o = __frcp_rn(1.0f + __expf(-2.0f * o));
+                } else if (p.round16) o = (float)(half_t)o;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(orow + (i < p.nplanes ? i : 0) * plane, 0, (real && i < p.nplanes) ? 0x7ffffff0 : 0, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rs, soff, 0, 0);
+            }
+        };
+        // input rows a0 - 1 .. a0 + D - 1 -> slots 0 .. D, each followed by NSTORE dropped stores: the steady state's instruction pattern
+#pragma unroll 1
+        for (int k = 0; k <= C::D; ++k) {
+            dma_row(a0 - 1 + k, k, a0 - 1 + k <= a1 + 1);
+            head_row(ys, false);
+        }
+        int s0 = 0;   // ring slot of input row y - 1
+#pragma unroll 1
+        for (int y = a0; y <= a1; ++y) {
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C::VMWAIT) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            {
+                int sl = s0 + C::D + 1; sl = sl >= C::RING ? sl - C::RING : sl;
+                dma_row(y + C::D, sl, y + C::D <= a1 + 1);
+            }
+            // one basic block: the head's and finish_a's LDS round trips overlap (finish_a(a0 - 1) at the first step turns garbage into
+            // row-ring slot 3, which finish_a(a0 + 3) rewrites before any head row reads it)
+            head_row(y - 3, y - 3 >= ys);
+            finish_a(y - 1);
+            partial_a(y, s0);
+            s0 = s0 + 1 >= C::RING ? 0 : s0 + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        finish_a(a1);
+        head_row(a1 - 2, a1 - 2 >= ys);
+        __syncthreads();
+        head_row(a1 - 1, true);
+        __syncthreads();   // the next item's first rows overwrite the rings and the partial sums
+    }
+}
+
+template <typename T> static int launch_conv_ringtail(const ConvParams &p, hipStream_t s)
+{
+    using C = RingTailCfg<T>;
+    if (!p.mfma16 || p.ck != 64 || p.nf != 1 || p.stride != 1 || p.bias_mode != 0 || (p.epi != EPI_NONE && p.epi != EPI_RELU) || !p.head_w || !p.head_bias ||
+        !p.out_planar || p.nplanes < 1 || p.nplanes > 3)
+        return -2;
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_ringtail_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    });
+    if (attr_err != hipSuccess) return (int)attr_err;
+    const int ncu = device_cu_count();
+    if (ncu <= 0) return (int)hipErrorInvalidDevice;
+    const int nstrip = ((p.Wout + C::TWO - 1) / C::TWO) * p.B, grid = 2 * ncu;
+    int nseg, seg_rows;
+    conv_ring_segments(nstrip, p.Hout, grid, &nseg, &seg_rows);
+    const int nitems = nstrip * nseg;
+    conv3x3_ringtail_kernel<T><<<nitems < grid ? nitems : grid, 256, C::LDS_BYTES, s>>>(p, nseg, seg_rows);
+    return (int)hipGetLastError();
+}

@@ -302,10 +302,11 @@ bool build_plan(Plan &P, int in_ch, int mid, int nb, int dtype)
 int run_conv(const Plan &P, const Layer &L, const void *packed, const void *in, int in_ps, int Hin, int Win, void *out,
              int out_ps, int out_coff, int cstore, int epi, int B, hipStream_t s, const float *bias_table = nullptr,
              float *planar = nullptr, int nplanes = 0, const void *zeros = nullptr, const Layer *head = nullptr,
-             const FirstParams *first = nullptr)
+             const FirstParams *first = nullptr, int epi2 = 0)
 {
     ConvParams c{};
-    if (head) {   // conv_ring.inl: L's rows stay in LDS, the planar head `head` is computed from them (planar / nplanes are the head's)
+    c.epi2 = epi2;
+    if (head) {   // conv_ring.inl / conv_ring_tail.inl: L's rows stay in LDS, the planar head `head` is computed from them (planar / nplanes are the head's)
         c.head_w = (const char *)packed + head->w_off;
         c.head_bias = (const float *)((const char *)packed + head->b_off);
     }
@@ -670,7 +671,18 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
     conv_work(P, P.r0, B, H, W, e, fl, by);
     EMAVFI_STEP(rec, conv_name(P, P.r0) + " reconstruction.0", fl, by,
                 run_conv(P, P.r0, packed, x, P.fps, H, W, f.fA, P.p_mid, 0, P.p_mid, EPI_RELU, B, s));
-    {
+    // reconstruction.1 + .2 in one launch (conv_ring_tail.inl): .1's rows never leave the LDS.  EMAVFI_CONV_TAILFUSE=0 (read per forward): two
+    const char *tf = getenv("EMAVFI_CONV_TAILFUSE");
+    if (P.r1.mfma16 && P.r1.ck == 64 && P.r1.nf == 1 && P.r1.cout == 32 && P.r1.ring == 0 && P.r2.mfma16 && P.r2.ck == 32 && P.r2.nf == 1 && P.r2.cout <= 3 &&
+        !(tf && tf[0] == '0')) {
+        double fl2, by2;
+        conv_work(P, P.r1, B, H, W, e, fl, by);
+        conv_work(P, P.r2, B, H, W, 4.0, fl2, by2);
+        const double mid_bytes = (double)B * H * W * P.r1.cout * e;
+        EMAVFI_STEP(rec, "conv3x3+tail<" + std::string(dtype_name(P.dtype)) + ",64->32->" + std::to_string(P.r2.cout) + "> reconstruction.1+.2(tanh)",
+                    fl + fl2, by + by2 - 2 * mid_bytes,
+                    run_conv(P, P.r1, packed, f.fA, P.p_mid, H, W, nullptr, 0, 0, 0, EPI_RELU, B, s, nullptr, out, C, nullptr, &P.r2, nullptr, EPI_PLANAR_TANH01));
+    } else {
         conv_work(P, P.r1, B, H, W, e, fl, by);
         EMAVFI_STEP(rec, conv_name(P, P.r1) + " reconstruction.1", fl, by,
                     run_conv(P, P.r1, packed, f.fA, P.p_mid, H, W, f.fB, f.p_half, 0, f.p_half, EPI_RELU, B, s));
