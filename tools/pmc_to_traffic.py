@@ -47,6 +47,9 @@ def label(k):
     if "conv3x3_ring_kernel<" in k:   # rocprofv3 garbles the demangling of instances with a `true` argument; the bench runs bf16;
         lds = int(k.rsplit("|lds=", 1)[1]) if "|lds=" in k else 0   # HEAD: two rings, 81 424 B; TAIL: 74 752 B
         return "conv3x3+head<bf16,64->64->2>" if lds > 78000 else "conv3x3<bf16,ck=80,nf=2,s=1>"
+    m = re.match(r"_Z23conv3x3_ringtail_kernelI(DF16b|DF16_)", k)
+    if m:  # reconstruction.1 + .2 in one launch (csrc/conv_ring_tail.inl)
+        return f"conv3x3+tail<{'bf16' if m.group(1) == 'DF16b' else 'f16'},64->32->3>"
     m = re.match(r"_Z24conv3x3_ringfirst_kernelI(DF16b|DF16_)", k)
     if m:
         return f"conv_first+conv3x3<{'bf16' if m.group(1) == 'DF16b' else 'f16'},6->64->64>"
