@@ -188,8 +188,8 @@ def test_ring_kernels_issue_a_fixed_number_of_vmem_instructions_per_step(tmp_pat
     """csrc/conv_ring.inl retires its LDS-DMA ring with a COUNTED `s_waitcnt vmcnt(N)`: N is only right while every wave issues
     exactly 3 DMA + 2 store instructions per row step and nothing else that counts.  hipcc is free to
     break that silently (a branch over an all-inactive store, a spill, a hoisted load), so the shipped code objects are checked:
-    between the counted wait and the drain behind the row loop there are three global_load_lds, two buffer stores and no other
-    vector-memory instruction, and N is 2 + 5 (D - 2) (D = 3; the fused head kernel: D = 2)."""
+    between the counted wait and the drain behind the row loop there are three global_load_lds, three buffer stores (the fused head
+    kernel: two) and no other vector-memory instruction, and N is stores + (3 + stores) (D - 2) (D = 3; the fused head kernel: D = 2)."""
     import re
     seen = {}
     for dis in _device_disassembly(tmp_path):
@@ -206,12 +206,13 @@ def test_ring_kernels_issue_a_fixed_number_of_vmem_instructions_per_step(tmp_pat
             dma = len(re.findall(r"global_load_lds_dwordx4", region))
             stores = len(re.findall(r"buffer_store_dword", region))
             other = len(re.findall(r"\b(?:global_load_dword|global_store|buffer_load|flat_load|flat_store|scratch_)", region))
-            head, tail = "Lb0ELb1E" in name, "ringtail" in name   # (ringtail: three stores - the frame's planes -, D = 3)
-            assert (dma, stores, other) == (3, 3 if tail else 2, 0), (name, dma, stores, other)
-            assert n == (9 if tail else 2 if head else 7), (name, n)
+            m = re.search(r"ring_kernelI\w+?Lb(\d)ELb(\d)ELb(\d)E", name)   # <T, TAIL, HEAD, ALT>
+            head, tail = bool(m) and m.group(2) == "1", "ringtail" in name   # (ringtail: three stores - the frame's planes -, D = 3)
+            assert (dma, stores, other) == (3, 2 if head else 3, 0), (name, dma, stores, other)
+            assert n == (2 if head else 9), (name, n)
             seen[name] = n
-    # bf16 and f16 instances of: 64 -> 64, TAIL (67 -> 64), HEAD (+ flow head), reconstruction.1 + .2
-    assert len(seen) == 8, sorted(seen)
+    # bf16 and f16 instances of: 64 -> 64, the same storing the other 16-bit type (ALT), TAIL (67 -> 64), HEAD (+ flow head), reconstruction.1 + .2
+    assert len(seen) == 10, sorted(seen)
 
 
 def test_packed_cache_file_carries_a_checksum(tmp_path):

@@ -705,6 +705,34 @@ def test_fused_pack_equals_the_two_launch_path(tmp_path):
     assert d <= 8e-3 and pf >= 52.0 and pf >= ps - 0.5
 
 
+def test_bf16_feat_as_f16_is_at_least_as_close_to_fp32(tmp_path):
+    """bf16 model with the one-launch packs: `feat` and the warped tail are stored as IEEE f16 (what the first pack wants on chip: no
+    conversion pass in it), and their other readers - context_encoding.0, motion_estimation.0 - run the f16 ring kernels on the
+    bf16-rounded weights (Plan::feat16).  EMAVFI_PACK_F16_CHAIN=0 (read once per process: subprocesses) keeps bf16 everywhere.
+    f16 keeps three more mantissa bits of `feat`, so the frame must be as close to the exact-fp32 frame as before, and the two
+    bf16-model frames must agree to a fraction of a bf16 output step.  fp16 and fp32 models are not touched by the switch."""
+    import os
+    import subprocess
+    import sys
+    from conftest import PKG
+    outs = []
+    for tag, extra in (("f16feat", {}), ("bf16feat", {"EMAVFI_PACK_F16_CHAIN": "0"})):
+        env = dict(os.environ, **extra)
+        if not extra:
+            env.pop("EMAVFI_PACK_F16_CHAIN", None)
+        env["EMAVFI_CACHE"] = "0"
+        code = _FUSION_AB % {"pkg": PKG, "out": str(tmp_path / tag)}
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append({dt: torch.from_numpy(np.load(str(tmp_path / tag) + f"_{dt}.npy")) for dt in ("bf16", "fp16", "fp32")})
+    new, old = outs
+    assert torch.equal(new["fp32"], old["fp32"]) and torch.equal(new["fp16"], old["fp16"])
+    d = (new["bf16"] - old["bf16"]).abs().max().item()
+    pn, po = psnr(new["bf16"], new["fp32"]), psnr(old["bf16"], new["fp32"])
+    print(f"bf16 model, feat as f16 vs bf16: max-abs {d:.3e}; PSNR vs fp32 frame: {pn:.2f} dB vs {po:.2f} dB")
+    assert d <= 1.5e-2 and pn >= 52.0 and pn >= po - 0.3
+
+
 def test_forward_is_capturable_in_a_hip_graph():
     """The forward only enqueues kernels on the stream it is given and allocates nothing once its workspace exists, so
     it can be captured with torch.cuda.graph (hipGraph) and replayed on new frame contents - what a launch-bound small

@@ -38,7 +38,7 @@ def label(k):
     m = re.match(r"_Z24conv3x3_persist16_kernelI(DF16b|DF16_)Li64ELi1", k)
     if m:
         return f"conv3x3<{'bf16' if m.group(1) == 'DF16b' else 'f16'},ck=64,nf=1,s=1>"
-    m = re.match(r"_Z19conv3x3_ring_kernelI(DF16b|DF16_)Lb(0|1)ELb(0|1)E", k)
+    m = re.match(r"_Z19conv3x3_ring_kernelI(DF16b|DF16_)Lb(0|1)ELb(0|1)ELb[01]E", k)
     if m:  # 64 -> 64 layers / reconstruction.0 (67 -> 64) / motion_estimation.1 + .2: weights in registers, input rows through an LDS ring (csrc/conv_ring.inl)
         t = 'bf16' if m.group(1) == 'DF16b' else 'f16'
         if m.group(3) == '1':

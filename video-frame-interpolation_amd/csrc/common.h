@@ -74,6 +74,21 @@ __device__ __forceinline__ void mma_kg(f32x16 &acc, const f32x4 &w, const f32x4 
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[3], x[3], acc, 0, 0, 0);
 }
 
+// two fp32 values rounded (to nearest even) to T, or to the other 16-bit type, as one 32-bit register (ConvParams::out_alt)
+template <typename T> struct Other16;
+template <> struct Other16<bf16_t> { using type = half_t; };
+template <> struct Other16<half_t> { using type = bf16_t; };
+template <> struct Other16<float> { using type = float; };
+template <typename T> __device__ __forceinline__ unsigned pack16x2(float a, float b, bool alt)
+{
+    typedef __attribute__((ext_vector_type(2))) T pair_t;
+    typedef typename Other16<T>::type O;
+    typedef __attribute__((ext_vector_type(2))) O opair_t;
+    if (alt) { const opair_t q = {(O)a, (O)b}; return __builtin_bit_cast(unsigned, q); }
+    const pair_t q = {(T)a, (T)b};
+    return __builtin_bit_cast(unsigned, q);
+}
+
 // Accumulator register i of lane (r, h) is output channel (i&3) + 8*(i>>2) + 4*h of the
 // 32-channel fragment, pixel r (C/D map of the 32x32 MFMA, cdna_hip_programming.md section 3).
 __device__ __forceinline__ int acc_channel(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
@@ -164,6 +179,12 @@ struct ConvParams {
                          // 2 = conv3x3_ring_kernel (64 -> 64), 3 = the same with the im2col tail (65..67 -> 64: reconstruction.0)
     const void *head_w;      // conv_ring.inl, ring == 2 only: fuse a 64 -> nplanes (<= 2) planar head (its weights in the 16x16x32 packing,
     const float *head_bias;  // its bias) behind this layer: `out` is not written, `out_planar` gets the head (round16 applies)
+    int out_alt;             // ring kernels (64 -> 64, 64 -> 128 stride 2), channels-last epilogue: store the OTHER 16-bit type (a bf16 kernel writes
+                             // IEEE f16 bit patterns and vice versa).  bf16 model: `feat` lives as f16 (what the first pack wants on chip,
+                             // no conversion pass), its other readers run the f16 kernels on bf16-rounded weights and hand bf16 on
+    int out_fill;            // conv3x3_ring_kernel, 64 channels into 144-byte pixels (`feat` into the fusion tensor): also write the pixel's last
+                             // 16 bytes (zeros).  128 of every 144 bytes leave a hole in every 128-byte line - partial-line writes that cost
+                             // the layer ~240 us at B = 8 x 720p; the bytes belong to nobody yet (the warp writes them later, or never)
     int epi2;                // conv_ring_tail.inl (64 -> 32 -> nplanes <= 3, this layer packed mfma16 with nf == 1): the head's epilogue
                              // (EPI_PLANAR or EPI_PLANAR_TANH01)
     int in_pieces;       // 16-byte pieces of an input pixel (single-chunk layers) that exist in memory; 0 = all CK of them.

@@ -1030,7 +1030,7 @@ template <typename T> struct ConvS2RCfg {
     static_assert(sizeof(T) == 2 && 2 * LDS_BYTES <= 160 * 1024, "16-bit types; two workgroups per CU");
 };
 
-template <typename T>
+template <typename T, bool ALT = false>   // ALT: ConvParams::out_alt
 __global__ __launch_bounds__(256, 2) void conv3x3_s2ring_kernel(const ConvParams p, const int nseg, const int seg_rows)
 {
     using C = ConvS2RCfg<T>;
@@ -1148,8 +1148,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2ring_kernel(const ConvParams
                     float v0 = acc[0][4 * g + 2 * q] + acc[1][4 * g + 2 * q], v1 = acc[0][4 * g + 2 * q + 1] + acc[1][4 * g + 2 * q + 1];
                     float u0 = acc[0][4 * (g + 1) + 2 * q] + acc[1][4 * (g + 1) + 2 * q], u1 = acc[0][4 * (g + 1) + 2 * q + 1] + acc[1][4 * (g + 1) + 2 * q + 1];
                     if (relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); u0 = fmaxf(u0, 0.0f); u1 = fmaxf(u1, 0.0f); }
-                    const pair_t pa = {(T)v0, (T)v1}, pb = {(T)u0, (T)u1};
-                    const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, pa), __builtin_bit_cast(unsigned, pb), false, false);
+                    const auto sw = __builtin_amdgcn_permlane32_swap(pack16x2<T>(v0, v1, ALT), pack16x2<T>(u0, u1, ALT), false, false);
                     a[q] = sw[0]; c[q] = sw[1];
                 }
                 *reinterpret_cast<__attribute__((address_space(3))) u4_t *>(stg + 16 * (g + h)) = u4_t{a[0], a[1], c[0], c[1]};
@@ -1161,14 +1160,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2ring_kernel(const ConvParams
     store_row(ye - 1);
 }
 
-template <typename T> static int launch_conv_s2ring(const ConvParams &p, hipStream_t s)
+template <typename T, bool ALT> static int launch_conv_s2ring_t(const ConvParams &p, hipStream_t s)
 {
     using C = ConvS2RCfg<T>;
-    if (p.ck != 64 || p.nf != 4 || p.stride != 2 || p.nchunk != 1 || p.npass != 1 || p.bias_mode != 0 || (p.epi != EPI_NONE && p.epi != EPI_RELU)) return -2;
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_s2ring_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_s2ring_kernel<T, ALT>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     });
     if (attr_err != hipSuccess) return (int)attr_err;
     const int ncu = device_cu_count();
@@ -1178,8 +1176,13 @@ template <typename T> static int launch_conv_s2ring(const ConvParams &p, hipStre
     nseg = nseg < 1 ? 1 : (nseg > p.Hout ? p.Hout : nseg);
     const int seg_rows = (p.Hout + nseg - 1) / nseg;
     nseg = (p.Hout + seg_rows - 1) / seg_rows;
-    conv3x3_s2ring_kernel<T><<<nstrip * nseg, 256, C::LDS_BYTES, s>>>(p, nseg, seg_rows);
+    conv3x3_s2ring_kernel<T, ALT><<<nstrip * nseg, 256, C::LDS_BYTES, s>>>(p, nseg, seg_rows);
     return (int)hipGetLastError();
+}
+template <typename T> static int launch_conv_s2ring(const ConvParams &p, hipStream_t s)
+{
+    if (p.ck != 64 || p.nf != 4 || p.stride != 2 || p.nchunk != 1 || p.npass != 1 || p.bias_mode != 0 || (p.epi != EPI_NONE && p.epi != EPI_RELU)) return -2;
+    return p.out_alt ? launch_conv_s2ring_t<T, true>(p, s) : launch_conv_s2ring_t<T, false>(p, s);
 }
 
 // (CK, NF, stride) instantiations of the tile-per-workgroup kernel (keep in sync with kConvInst in emavfi_api.hip)

@@ -47,12 +47,15 @@ template <typename T, bool TAIL, bool HEAD> struct ConvRingCfg {
     static constexpr int STG_OFF = RING * ROWB, BIAS_OFF = STG_OFF + NSTG * STG, BIAS_BYTES = HEAD ? 256 : 16 * 64 * 4;
     static constexpr int HW_OFF = BIAS_OFF + BIAS_BYTES, HW_BYTES = HEAD ? 2 * 2048 : 0;   // head partial sums [row parity][wave][block][pixel][2] floats
     static constexpr int SCRATCH_OFF = HW_OFF + HW_BYTES, LDS_BYTES = SCRATCH_OFF + 1024;
-    static constexpr int NDMA = (ROWINST + 3) / 4, NSTORE = 2, VMWAIT = NSTORE + (NDMA + NSTORE) * (D - 2);
+    // stores per step and wave: HEAD the head's two planes; else two for the row's 512 16-byte units + one for the 64 pad units of
+    // ConvParams::out_fill (all lanes out of range when it is off: the count must not depend on it)
+    static constexpr int NDMA = (ROWINST + 3) / 4, NSTORE = HEAD ? 2 : 3, VMWAIT = NSTORE + (NDMA + NSTORE) * (D - 2);
     static constexpr int WMAIN = 9 * 4 * 2 * 1024;   // bytes of [tap][kg][fragment][lane][8]; the tail [j 3][fragment][lane][8] follows
     static_assert(sizeof(T) == 2 && 2 * LDS_BYTES <= 160 * 1024 && !(TAIL && HEAD), "16-bit types; two workgroups per CU");
 };
 
-template <typename T, bool TAIL, bool HEAD>
+template <typename T, bool TAIL, bool HEAD, bool ALT = false>   // ALT: ConvParams::out_alt (a template argument: a run-time select in
+                                                                // the epilogue cost the 64 -> 64 layers 20 us each)
 __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p, const int nseg, const int seg_rows)
 {
     using C = ConvRingCfg<T, TAIL, HEAD>;
@@ -168,10 +171,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
             obase = reinterpret_cast<char *>(p.out) + (((size_t)b * p.Hout * p.Wout + (size_t)tx * C::TW) * p.out_ps + p.out_coff) * sizeof(T);
             const int npx = min(C::TW, p.Wout - tx * C::TW);
 #pragma unroll
-            for (int i = 0; i < C::NSTORE; ++i) {
+            for (int i = 0; i < 2; ++i) {
                 const int q = i * 256 + tid, px = q >> 3, ch = q & 7;
                 soff[i] = (px < npx && ch * 8 < p.cstore) ? (unsigned)px * (unsigned)p.out_ps * (unsigned)sizeof(T) + ch * 16u : 0x80000000u;
             }
+            soff[2] = (p.out_fill && tid < npx) ? (unsigned)tid * (unsigned)p.out_ps * (unsigned)sizeof(T) + 128u : 0x80000000u;
         } else {
             // the head: wave w owns head columns [16 w, 16 w + 16) of the strip's 62; lanes kb == 0 hold output rows 0..3 of a pixel
             const int hc = wave * 16 + (lane & 15), hx = tx * C::TWO + hc;
@@ -184,11 +188,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
             char *orow = obase + (size_t)(real ? y : ys) * p.Wout * p.out_ps * sizeof(T);
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(orow, 0, real ? 0x7ffffff0 : 0, 0x00020000);
 #pragma unroll
-            for (int i = 0; i < C::NSTORE; ++i) {
+            for (int i = 0; i < 2; ++i) {
                 const int q = i * 256 + tid, px = q >> 3, ch = q & 7;
                 const u4_t v = *reinterpret_cast<const __attribute__((address_space(3))) u4_t *>(stg + px * C::STG_PX + ch * 16);
                 __builtin_amdgcn_raw_buffer_store_b128(v, rs, soff[i], 0, 0);
             }
+            __builtin_amdgcn_raw_buffer_store_b128(u4_t{0u, 0u, 0u, 0u}, rs, soff[2], 0, 0);
         };
         // head row yb from the 64 -> 64 rows yb - 1 .. yb + 1 (mid-ring slots (row - a0) & 3): this wave's k-steps, all four blocks
         auto head_partial = [&](int yb) {
@@ -341,8 +346,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
                         float u0 = acc[0][4 * (g + 1) + 2 * q] + acc[1][4 * (g + 1) + 2 * q], u1 = acc[0][4 * (g + 1) + 2 * q + 1] + acc[1][4 * (g + 1) + 2 * q + 1];
                         if (relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); u0 = fmaxf(u0, 0.0f); u1 = fmaxf(u1, 0.0f); }
                         if (EMAVFI_RING_ABL & 4) { v0 = acc[0][4 * g + 2 * q]; v1 = acc[1][4 * g + 2 * q]; u0 = v0; u1 = v1; }
-                        const pair_t pa = {(T)v0, (T)v1}, pb = {(T)u0, (T)u1};
-                        unsigned ua = __builtin_bit_cast(unsigned, pa), ub = __builtin_bit_cast(unsigned, pb);
+                        unsigned ua = pack16x2<T>(v0, v1, ALT), ub = pack16x2<T>(u0, u1, ALT);
                         if (HEAD) { const unsigned keep = inside ? ~0u : 0u; ua &= keep; ub &= keep; }
                         const auto sw = __builtin_amdgcn_permlane32_swap(ua, ub, false, false);
                         a[q] = sw[0]; c[q] = sw[1];
@@ -380,13 +384,13 @@ static void conv_ring_segments(int nstrip, int Hout, int grid, int *nseg_out, in
     *seg_rows_out = br;
 }
 
-template <typename T, bool TAIL, bool HEAD> static int launch_conv_ring_t(const ConvParams &p, hipStream_t s)
+template <typename T, bool TAIL, bool HEAD, bool ALT = false> static int launch_conv_ring_t(const ConvParams &p, hipStream_t s)
 {
     using C = ConvRingCfg<T, TAIL, HEAD>;
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_ring_kernel<T, TAIL, HEAD>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_ring_kernel<T, TAIL, HEAD, ALT>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     });
     if (attr_err != hipSuccess) return (int)attr_err;
     const int ncu = device_cu_count();
@@ -395,7 +399,7 @@ template <typename T, bool TAIL, bool HEAD> static int launch_conv_ring_t(const 
     int nseg, seg_rows;
     conv_ring_segments(nstrip, p.Hout, grid, &nseg, &seg_rows);
     const int nitems = nstrip * nseg;
-    conv3x3_ring_kernel<T, TAIL, HEAD><<<nitems < grid ? nitems : grid, 256, C::LDS_BYTES, s>>>(p, nseg, seg_rows);
+    conv3x3_ring_kernel<T, TAIL, HEAD, ALT><<<nitems < grid ? nitems : grid, 256, C::LDS_BYTES, s>>>(p, nseg, seg_rows);
     return (int)hipGetLastError();
 }
 
@@ -406,5 +410,6 @@ template <typename T> static int launch_conv_ring(const ConvParams &p, hipStream
         if (p.ring != 2 || p.bias_mode != 0 || !p.head_bias || !p.out_planar || p.nplanes < 1 || p.nplanes > 2) return -2;
         return launch_conv_ring_t<T, false, true>(p, s);
     }
+    if (p.out_alt) return p.ring == 2 ? launch_conv_ring_t<T, false, false, true>(p, s) : -2;
     return p.ring == 3 ? launch_conv_ring_t<T, true, false>(p, s) : launch_conv_ring_t<T, false, false>(p, s);
 }

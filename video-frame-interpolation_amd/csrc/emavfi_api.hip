@@ -174,6 +174,9 @@ bool pack_f16_chain()
 constexpr int kMaxBlocks = 8;
 
 struct Plan {
+    bool feat16 = false;       // bf16 model with the one-launch packs: `feat` (and the warped tail) is stored as IEEE f16 - what the first
+                               // pack wants on chip (no conversion pass in it) -; its other readers (context_encoding.0,
+                               // motion_estimation.0) run the f16 ring kernels on bf16-rounded weights and hand bf16 on
     int in_ch, mid, nb, dtype, esize;  // dtype = the KERNEL storage type (EMAVFI_AMP16 runs the f16 kernels)
     bool amp;                          // EMAVFI_AMP16: autocast op policy (fp32 DCN on an fp32 fusion tensor, fp16 roundings)
     Layer dcn32[kMaxBlocks];           // amp: the deformable convolutions' fp32 master weights
@@ -274,12 +277,17 @@ bool build_plan(Plan &P, int in_ch, int mid, int nb, int dtype)
         for (int i = 0; i < nb; ++i)
             if (deform_f32w_shape(P.dcn32[i].ck, P.dcn32[i].nf, P.dcn32[i].cin_take, P.dcn32[i].cout)) P.dcn32[i].pack3 = 3;
     P.has_offh = false;
+    P.feat16 = false;
     const bool p3 = ok && !P.amp && dtype != EMAVFI_F32 && nb > 0 && deform_pack3_shape(P.dcn[0].ck, P.dcn[0].nf, P.dcn[0].cin_take, P.dcn[0].cout) &&
                     P.off[0].nchunk == 1 && P.off[0].npass == 1 && P.off[0].ck == 80 && P.off[0].nf == 1;
     if (p3) {
         // a second copy of offset_conv for the one-launch pack: f16 fragments (bf16 model: the bf16-rounded values), and in
         // the deform_pack3.inl layout where that kernel serves the shape (both 16-bit models); off[i] keeps the conv3x3 layout
         P.has_offh = true;
+        // (feat16: see Plan; needs the ring kernels on both sides of `feat` and at least one block in front of the last one)
+        P.feat16 = dtype == EMAVFI_BF16 && pack_f16_chain() && nb >= 2 && P.blk[nb - 1].ring == 2 && P.c0.ring == 1 && P.m0.ring == 2 && P.fpad - mid == 16 &&
+                   deform16_can_fuse_offset_conv(P.dcn[0].ck, P.dcn[0].nf, P.dcn[0].cin_take, P.off[0].ck, P.off[0].nf);   // (EMAVFI_NO_FUSED_OFFSET: once per process)
+        if (P.feat16) P.c0.f16_of_bf16 = P.m0.f16_of_bf16 = true;
         for (int i = 0; i < nb && ok; ++i) {
             P.dcn[i].f16_of_bf16 = dtype == EMAVFI_BF16;
             P.dcn[i].pack3 = p3 ? 1 : 0;
@@ -302,10 +310,12 @@ bool build_plan(Plan &P, int in_ch, int mid, int nb, int dtype)
 int run_conv(const Plan &P, const Layer &L, const void *packed, const void *in, int in_ps, int Hin, int Win, void *out,
              int out_ps, int out_coff, int cstore, int epi, int B, hipStream_t s, const float *bias_table = nullptr,
              float *planar = nullptr, int nplanes = 0, const void *zeros = nullptr, const Layer *head = nullptr,
-             const FirstParams *first = nullptr, int epi2 = 0)
+             const FirstParams *first = nullptr, int epi2 = 0, int out_alt = 0)
 {
     ConvParams c{};
     c.epi2 = epi2;
+    c.out_alt = out_alt;
+    c.out_fill = (L.ring == 2 && !head && !first && out && out_coff == 0 && cstore == 64 && (size_t)out_ps * P.esize == 144) ? 1 : 0;
     if (head) {   // conv_ring.inl / conv_ring_tail.inl: L's rows stay in LDS, the planar head `head` is computed from them (planar / nplanes are the head's)
         c.head_w = (const char *)packed + head->w_off;
         c.head_bias = (const float *)((const char *)packed + head->b_off);
@@ -325,6 +335,7 @@ int run_conv(const Plan &P, const Layer &L, const void *packed, const void *in, 
     c.epi = epi; c.nplanes = nplanes; c.bias_mode = bias_table ? 1 : 0;
     c.ck = L.ck; c.nf = L.nf; c.stride = L.stride; c.mfma16 = L.mfma16 ? 1 : 0; c.ring = L.ring;
     if (first) return P.dtype == EMAVFI_F16 ? launch_conv_ringfirst_f16(*first, c, s) : launch_conv_ringfirst_bf16(*first, c, s);
+    if (L.f16_of_bf16 && !L.deform) return launch_conv3x3_f16(c, s);   // feat16: f16 activations in, bf16-rounded weights stored as f16
     return P.dtype == EMAVFI_F32 ? launch_conv3x3_f32(c, s) : P.dtype == EMAVFI_F16 ? launch_conv3x3_f16(c, s) : launch_conv3x3_bf16(c, s);
 }
 
@@ -433,7 +444,7 @@ const char *dtype_name(int dtype) { return dtype == EMAVFI_F32 ? "f32" : dtype =
 std::string conv_name(const Plan &P, const Layer &L)
 {
     char b[96];
-    snprintf(b, sizeof b, "conv3x3<%s,ck=%d,nf=%d,s=%d>", dtype_name(P.dtype), L.ck, L.nf, L.stride);
+    snprintf(b, sizeof b, "conv3x3<%s,ck=%d,nf=%d,s=%d>", L.f16_of_bf16 ? "f16" : dtype_name(P.dtype), L.ck, L.nf, L.stride);   // (feat16: f16 kernels in a bf16 model)
     return b;
 }
 std::string deform_name(const Plan &P, const Layer &L)
@@ -500,6 +511,9 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
     const size_t npx = (size_t)B * H * W;
     double fl, by;
 
+    // bf16 model: `feat` and the warped tail as f16 (Plan::feat16) when the first pack is the one-launch kernel that wants them so
+    const bool feat16 = P.feat16;
+    const int feat_dtype = feat16 ? (int)EMAVFI_F16 : dtype;
     // --- feature extraction: cat + conv + ReLU, then num_blocks x (conv + ReLU)  (ema_vfi.py:112-116)
     conv_work(P, P.conv1, B, H, W, e, fl, by);
     int first_blk = 0;
@@ -538,15 +552,17 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
         void *dst = last ? f.fu0 : nxt;
         conv_work(P, P.blk[i], B, H, W, e, fl, by);
         EMAVFI_STEP(rec, conv_name(P, P.blk[i]) + " feat_ext_blocks", fl, by,
-                    run_conv(P, P.blk[i], packed, cur, P.p_mid, H, W, dst, last ? P.fps : P.p_mid, 0, P.p_mid, EPI_RELU, B, s));
+                    run_conv(P, P.blk[i], packed, cur, P.p_mid, H, W, dst, last ? P.fps : P.p_mid, 0, P.p_mid, EPI_RELU, B, s, nullptr, nullptr, 0, nullptr,
+                             nullptr, nullptr, 0, last && feat16 ? 1 : 0));
         if (!last) { void *t = cur; cur = nxt; nxt = t; }
     }
-    if (!rec.dry && taps && taps[0]) EMAVFI_TRY(launch_cl_to_nchw(f.fu0, taps[0], B, mid, H, W, P.fps, 0, dtype, s), "tap feat");
+    if (!rec.dry && taps && taps[0]) EMAVFI_TRY(launch_cl_to_nchw(f.fu0, taps[0], B, mid, H, W, P.fps, 0, feat_dtype, s), "tap feat");
 
     // --- context encoding (ema_vfi.py:120): two stride-2 convs, one conv, global mean, linear
     conv_work(P, P.c0, B, H, W, e, fl, by);
     EMAVFI_STEP(rec, conv_name(P, P.c0) + " context_encoding.0", fl, by,
-                run_conv(P, P.c0, packed, f.fu0, P.fps, H, W, f.c1, f.p2, 0, f.p2, EPI_RELU, B, s));
+                run_conv(P, P.c0, packed, f.fu0, P.fps, H, W, f.c1, f.p2, 0, f.p2, EPI_RELU, B, s, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0,
+                         feat16 ? 1 : 0));
     conv_work(P, P.c1, B, f.H2, f.W2, e, fl, by);
     EMAVFI_STEP(rec, conv_name(P, P.c1) + " context_encoding.1", fl, by,
                 run_conv(P, P.c1, packed, f.c1, f.p2, f.H2, f.W2, f.c2, f.p4, 0, f.p4, EPI_RELU, B, s));
@@ -565,7 +581,8 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
     // --- motion estimation (ema_vfi.py:124-126); the broadcast-context concat is a per-border-class bias
     conv_work(P, P.m0, B, H, W, e, fl, by);
     EMAVFI_STEP(rec, conv_name(P, P.m0) + " motion_estimation.0(ctx folded)", fl, by,
-                run_conv(P, P.m0, packed, f.fu0, P.fps, H, W, f.fA, P.p_mid, 0, P.p_mid, EPI_RELU, B, s, f.table));
+                run_conv(P, P.m0, packed, f.fu0, P.fps, H, W, f.fA, P.p_mid, 0, P.p_mid, EPI_RELU, B, s, f.table, nullptr, 0, nullptr, nullptr, nullptr, 0,
+                         feat16 ? 1 : 0));
     // motion_estimation.1 + .2 in one launch (conv_ring.inl, HEAD): .1's rows never leave the LDS.  EMAVFI_CONV_HEAD=0 (read per
     // forward): two launches
     const char *hf = getenv("EMAVFI_CONV_HEAD");
@@ -635,11 +652,11 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
         };
         const bool split_tail = P.nb > 0 && pack_fuses(0) && P.fpad - mid == 16;
         EMAVFI_STEP(rec, std::string("warp_fused<") + dtype_name(dtype) + ">", 24.0 * px, px * (8.0 + 4.0 * C + C * e),
-                    split_tail ? launch_warp_fused(frame2, f.flow, f.in16, B, C, H, W, 8, 0, dtype, s)
-                               : launch_warp_fused(frame2, f.flow, f.fu0, B, C, H, W, P.fps, mid, dtype, s));
+                    split_tail ? launch_warp_fused(frame2, f.flow, f.in16, B, C, H, W, 8, 0, feat_dtype, s)
+                               : launch_warp_fused(frame2, f.flow, f.fu0, B, C, H, W, P.fps, mid, feat_dtype, s));
         if (!rec.dry && taps && taps[3])
-            EMAVFI_TRY(split_tail ? launch_cl_to_nchw(f.in16, taps[3], B, C, H, W, 8, 0, dtype, s)
-                                  : launch_cl_to_nchw(f.fu0, taps[3], B, C, H, W, P.fps, mid, dtype, s), "tap warped");
+            EMAVFI_TRY(split_tail ? launch_cl_to_nchw(f.in16, taps[3], B, C, H, W, 8, 0, feat_dtype, s)
+                                  : launch_cl_to_nchw(f.fu0, taps[3], B, C, H, W, P.fps, mid, feat_dtype, s), "tap warped");
 
         // --- multi-attention fusion: num_blocks x ModulatedDeformConvPack, no activation (ema_vfi.py:136-138)
         for (int i = 0; i < P.nb; ++i) {
@@ -653,7 +670,7 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
                             px * (2.0 * cf * e) + 9.0 * cf * (cf + 27.0) * e,
                             run_deform(P, P.dcn[i], packed, x, P.fps, f.om, y, P.fps, P.fps, B, H, W, s, nullptr,
                                        P.has_offh ? &P.offh[i] : &P.off[i],
-                                       i == 0 && split_tail ? f.in16 : nullptr, 8, -1, f16_link(i - 1) ? 1 : 0, f16_link(i) ? 1 : 0));
+                                       i == 0 && split_tail ? f.in16 : nullptr, 8, -1, (i == 0 ? feat16 : f16_link(i - 1)) ? 1 : 0, f16_link(i) ? 1 : 0));
             } else {
                 EMAVFI_STEP(rec, conv_name(P, P.off[i]) + " offset_conv", fl, by,
                             run_conv(P, P.off[i], packed, x, P.fps, H, W, f.om, 32, 0, 32, EPI_OM, B, s));

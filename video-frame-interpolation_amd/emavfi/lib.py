@@ -84,7 +84,7 @@ def fingerprint() -> str:
 def layout_switches() -> str:
     """Diagnostic environment switches the PACKED LAYOUT depends on (csrc/emavfi_api.hip, conv_geometry): a blob packed under one
     setting must not be run under another, so the setting is part of the in-memory and on-disk cache keys of the packed weights."""
-    return "|".join(f"{k}={os.environ.get(k, '')}" for k in ("EMAVFI_CONV_MFMA16", "EMAVFI_CONV_S2_CK64", "EMAVFI_CONV_RING", "EMAVFI_CONV_S2RING"))
+    return "|".join(f"{k}={os.environ.get(k, '')}" for k in ("EMAVFI_CONV_MFMA16", "EMAVFI_CONV_S2_CK64", "EMAVFI_CONV_RING", "EMAVFI_CONV_S2RING", "EMAVFI_PACK_F16_CHAIN", "EMAVFI_NO_FUSED_OFFSET"))
 
 
 def last_error() -> str:
