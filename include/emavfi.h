@@ -33,8 +33,12 @@
  *    through the bilinear blend, lose trailing bits below 6.1e-5 and SATURATE
  *    at +-65504 (v_cvt_pkrtz; no infinities are produced) - contracts bf16-
  *    rounded weights stored as f16, and hands the tensor between two
- *    consecutive packs on as f16 bit patterns.  Activations beyond +-65504 in
- *    the fusion stage are therefore clamped there, not propagated
+ *    consecutive packs on as f16 bit patterns.  Since round 3 the feature map
+ *    that enters the fusion stage (`feat`, and the warped frame beside it) is
+ *    itself stored as f16 in this mode, saturating the same way, and its two
+ *    other readers (context_encoding.0, motion_estimation.0) contract it with
+ *    bf16-rounded weights stored as f16.  Activations beyond +-65504 in `feat`
+ *    and in the fusion stage are therefore clamped there, not propagated
  *    (tests/test_gpu_parity.py::test_bf16_pack_saturates_at_the_f16_range).
  *    EMAVFI_F16 is the same data flow in IEEE half precision - the arithmetic
  *    torch.cuda.amp.autocast() gives the reference's convolutions on a GPU

@@ -733,6 +733,23 @@ def test_bf16_feat_as_f16_is_at_least_as_close_to_fp32(tmp_path):
     assert d <= 1.5e-2 and pn >= 52.0 and pn >= po - 0.3
 
 
+def test_bf16_feat_stored_as_f16_saturates_instead_of_overflowing():
+    """include/emavfi.h: in the bf16 model `feat` is stored as IEEE f16 for the one-launch packs (Plan::feat16) and SATURATES at +-65504
+    like the packs' own conversion: activations that bf16 could hold but f16 cannot must not become inf (inf - inf = NaN two layers
+    later).  conv_block_2's weights and bias are scaled until `feat` exceeds the f16 range by far."""
+    sd = synth.synthetic_state_dict(seed=3)
+    sd = {k: v.clone() for k, v in sd.items()}
+    for k in ("feat_ext_blocks.conv_block_2.0.weight", "feat_ext_blocks.conv_block_2.0.bias"):
+        sd[k] = sd[k] * 3.0e5
+    f1, f2 = (t.to(DEV) for t in synth.synthetic_frames(34, 1, 40, 70, "natural"))
+    m = make_model(sd, dtype="bf16")
+    with torch.no_grad():
+        out, taps = m(f1, f2, return_taps=True)
+    feat = taps["feat"]
+    assert torch.isfinite(feat).all() and feat.max().item() == 65504.0, feat.max().item()
+    assert torch.isfinite(out).all() and out.min() >= 0 and out.max() <= 1
+
+
 def test_forward_is_capturable_in_a_hip_graph():
     """The forward only enqueues kernels on the stream it is given and allocates nothing once its workspace exists, so
     it can be captured with torch.cuda.graph (hipGraph) and replayed on new frame contents - what a launch-bound small

@@ -72,16 +72,21 @@ def label(k):
 
 
 f, w = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
-out = {}
-for k in sorted(f, key=lambda k: -sum(f[k])):
+# several kernel instances can serve one bench label (e.g. the 64 -> 64 ring kernel and its instance that stores the other 16-bit
+# type): pool their launches
+fl, wl = collections.defaultdict(list), collections.defaultdict(list)
+for k in f:
     lab = label(k)
-    if not lab:
-        continue
-    fk, wk = sum(f[k]) / len(f[k]), sum(w.get(k, [0])) / max(1, len(w.get(k, [0])))
+    if lab:
+        fl[lab] += f[k]
+        wl[lab] += w.get(k, [])
+out = {}
+for lab in sorted(fl, key=lambda k: -sum(fl[k])):
+    fk, wk = sum(fl[lab]) / len(fl[lab]), sum(wl[lab]) / max(1, len(wl[lab]))
     rd, wr = fk * 1024 * 2, wk * 1024
     out[lab] = {"hbm_bytes_per_launch": rd + wr, "fetch_bytes_corrected_x2": rd, "write_bytes": wr,
-                "launches_sampled": len(f[k]), "raw_FETCH_SIZE_KiB": fk, "raw_WRITE_SIZE_KiB": wk}
-    print(f"{lab:42s} n={len(f[k]):3d} read {rd / 1e6:9.1f} MB  write {wr / 1e6:8.1f} MB  total {(rd + wr) / 1e6:9.1f} MB")
+                "launches_sampled": len(fl[lab]), "raw_FETCH_SIZE_KiB": fk, "raw_WRITE_SIZE_KiB": wk}
+    print(f"{lab:42s} n={len(fl[lab]):3d} read {rd / 1e6:9.1f} MB  write {wr / 1e6:8.1f} MB  total {(rd + wr) / 1e6:9.1f} MB")
 tag = sys.argv[4] if len(sys.argv) > 4 else "rXX"
 json.dump({"method": __doc__, "kernels": out}, open(sys.argv[3] + f"{tag}_pmc_traffic_detail.json", "w"), indent=1)
 if "--install" in sys.argv:

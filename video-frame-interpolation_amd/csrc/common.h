@@ -84,7 +84,14 @@ template <typename T> __device__ __forceinline__ unsigned pack16x2(float a, floa
     typedef __attribute__((ext_vector_type(2))) T pair_t;
     typedef typename Other16<T>::type O;
     typedef __attribute__((ext_vector_type(2))) O opair_t;
-    if (alt) { const opair_t q = {(O)a, (O)b}; return __builtin_bit_cast(unsigned, q); }
+    if (alt) {
+        if (sizeof(T) == 2 && !__is_same(T, half_t)) {   // bf16 kernel storing f16: SATURATE at the f16 range like the packs' own conversion
+            a = a > 65504.0f ? 65504.0f : (a < -65504.0f ? -65504.0f : a);   // (include/emavfi.h; NaN stays NaN)
+            b = b > 65504.0f ? 65504.0f : (b < -65504.0f ? -65504.0f : b);
+        }
+        const opair_t q = {(O)a, (O)b};
+        return __builtin_bit_cast(unsigned, q);
+    }
     const pair_t q = {(T)a, (T)b};
     return __builtin_bit_cast(unsigned, q);
 }
