@@ -66,6 +66,9 @@ __device__ __forceinline__ const char *conv_dma_src(const char *gin, const char 
     return ok ? gin + off : zeros;
 }
 
+#ifndef EMAVFI_CONV_TILE_PIPE
+#define EMAVFI_CONV_TILE_PIPE 2   // tile-per-workgroup kernel, 16-bit: weight fragments read this many steps ahead (0: the plain loop)
+#endif
 #ifndef EMAVFI_CONV_INTERLEAVE
 #define EMAVFI_CONV_INTERLEAVE 1
 #endif
@@ -240,6 +243,9 @@ __global__ __launch_bounds__(256, (conv_wg_per_cu<T, CK, NF, S>())) void conv3x3
         // of tap t's 1-KiB blocks; every wave issues the same number NW or NW-1 of them, so a
         // counted s_waitcnt leaves exactly the newest tap in flight across the barrier.
         auto issue_w = [&](int t) {
+#if defined(EMAVFI_TILE_ABL_NOW)   // timing-only: taps 1..8 reuse tap 0's weights (no weight stream)
+            if (t > 0) return;
+#endif
 #pragma unroll
             for (int i = 0; i < (C::WINST + 3) / 4; ++i) {
                 const int j = i * 4 + wave;
@@ -262,16 +268,42 @@ __global__ __launch_bounds__(256, (conv_wg_per_cu<T, CK, NF, S>())) void conv3x3
             for (int m = 0; m < MF; ++m)
                 xb[m] = lds_in + (((wave * MF + m) * S + dy) * IW + r * S + dx) * PSTR + h * 16;
             const char *wb = lds_w + (tap % C::WBUF) * C::WTAP + lane * 16;
+            if constexpr (sizeof(T) == 2 && EMAVFI_CONV_TILE_PIPE) {
+                // 16-bit: operands EMAVFI_CONV_TILE_PIPE weight fragments (and one k-group of pixel pieces) ahead of their MFMAs,
+                // every step fenced.  The plain loop below read a step's two operands right in front of its MFMAs: one LDS round
+                // trip per step and wave, which is what bounded the streamed-weight layers (context_encoding.1 / .2: 29 % / 42 % of
+                // the MFMA rate)
+                constexpr int PF = EMAVFI_CONV_TILE_PIPE, NS = C::KG * NF;
+                vec xk[2][MF], wq[PF + 1];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int kg = 0; kg < C::KG; ++kg) {
-                vec xv[MF];
+                for (int m = 0; m < MF; ++m) xk[0][m] = *reinterpret_cast<const vec *>(xb[m]);
 #pragma unroll
-                for (int m = 0; m < MF; ++m) xv[m] = *reinterpret_cast<const vec *>(xb[m] + kg * 32);
+                for (int q = 0; q < PF && q < NS; ++q) wq[q] = *reinterpret_cast<const vec *>(wb + q * 1024);
 #pragma unroll
-                for (int n = 0; n < NF; ++n) {
-                    const vec wv = *reinterpret_cast<const vec *>(wb + (kg * NF + n) * 1024);
+                for (int q = 0; q < NS; ++q) {
+                    const int kg = q / NF, n = q - kg * NF;
+                    if (q + PF < NS) wq[(q + PF) % (PF + 1)] = *reinterpret_cast<const vec *>(wb + (q + PF) * 1024);
+                    if (n == 0 && kg + 1 < C::KG) {
 #pragma unroll
-                    for (int m = 0; m < MF; ++m) mma_kg(acc[m][n], wv, xv[m]);
+                        for (int m = 0; m < MF; ++m) xk[(kg + 1) & 1][m] = *reinterpret_cast<const vec *>(xb[m] + (kg + 1) * 32);
+                    }
+#pragma unroll
+                    for (int m = 0; m < MF; ++m) mma_kg(acc[m][n], wq[q % (PF + 1)], xk[kg & 1][m]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int kg = 0; kg < C::KG; ++kg) {
+                    vec xv[MF];
+#pragma unroll
+                    for (int m = 0; m < MF; ++m) xv[m] = *reinterpret_cast<const vec *>(xb[m] + kg * 32);
+#pragma unroll
+                    for (int n = 0; n < NF; ++n) {
+                        const vec wv = *reinterpret_cast<const vec *>(wb + (kg * NF + n) * 1024);
+#pragma unroll
+                        for (int m = 0; m < MF; ++m) mma_kg(acc[m][n], wv, xv[m]);
+                    }
                 }
             }
             if (tap < 8) {
