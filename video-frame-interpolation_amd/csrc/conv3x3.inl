@@ -243,9 +243,6 @@ __global__ __launch_bounds__(256, (conv_wg_per_cu<T, CK, NF, S>())) void conv3x3
         // of tap t's 1-KiB blocks; every wave issues the same number NW or NW-1 of them, so a
         // counted s_waitcnt leaves exactly the newest tap in flight across the barrier.
         auto issue_w = [&](int t) {
-#if defined(EMAVFI_TILE_ABL_NOW)   // timing-only: taps 1..8 reuse tap 0's weights (no weight stream)
-            if (t > 0) return;
-#endif
 #pragma unroll
             for (int i = 0; i < (C::WINST + 3) / 4; ++i) {
                 const int j = i * 4 + wave;
