@@ -750,6 +750,24 @@ def test_bf16_feat_stored_as_f16_saturates_instead_of_overflowing():
     assert torch.isfinite(out).all() and out.min() >= 0 and out.max() <= 1
 
 
+@pytest.mark.parametrize("nb", [1, 2, 4])
+def test_other_block_counts_take_the_fused_paths_correctly(nb):
+    """num_blocks != 3 at mid_channels 64: the plan's fusions depend on it (the fused first two layers write `feat` themselves when
+    there is one block; `feat` is stored as f16 only from two blocks on; the pack chain has nb links).  The 16-bit paths must stay
+    as close to the exact-fp32 path as at the reference's three blocks."""
+    sd = synth.synthetic_state_dict(seed=2, mid_channels=64, num_blocks=nb)
+    f1, f2 = (t.to(DEV) for t in synth.synthetic_frames(5, 2, 70, 131, "natural"))
+    outs = {}
+    for dt in ("fp32", "bf16", "fp16"):
+        m = EMA_VFI(num_blocks=nb, compute_dtype=dt).to(DEV).eval()
+        m.load_state_dict(sd)
+        with torch.no_grad():
+            outs[dt] = m(f1, f2)
+    for dt, tol in (("bf16", 4e-2), ("fp16", 8e-3)):
+        err = (outs[dt] - outs["fp32"]).abs().max().item()
+        assert torch.isfinite(outs[dt]).all() and err <= tol, (nb, dt, err)
+
+
 def test_forward_is_capturable_in_a_hip_graph():
     """The forward only enqueues kernels on the stream it is given and allocates nothing once its workspace exists, so
     it can be captured with torch.cuda.graph (hipGraph) and replayed on new frame contents - what a launch-bound small
