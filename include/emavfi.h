@@ -61,7 +61,7 @@
 extern "C" {
 #endif
 
-#define EMAVFI_VERSION 300 /* 0.3.0: packed-blob layout of the deformable packs, the fp32 DCN and feat_ext_conv1 changed (round 3): re-pack */
+#define EMAVFI_VERSION 400 /* 0.4.0: the packed blob starts with a 256-byte self-describing header; emavfi_forward takes packed_bytes (round 4): re-pack */
 
 #define EMAVFI_F32 0
 #define EMAVFI_BF16 1
@@ -110,6 +110,27 @@ int emavfi_pack_weights(int in_channels, int mid_channels, int num_blocks,
                         const void *const *params, int n_params,
                         void *packed, size_t packed_bytes, int dtype, void *stream);
 
+/* The packed blob is self-describing.  Bytes [0, 256): header, little endian -
+ *   char magic[8] = "EMAVFIPK"; u32 version (EMAVFI_VERSION); u32 header_bytes (256); u32 in_channels, mid_channels, num_blocks;
+ *   u32 dtype (as requested: EMAVFI_AMP16 is a layout of its own); u32 layout_tag (emavfi_layout_tag() of the packing process);
+ *   u32 reserved; u64 total_bytes (= emavfi_packed_bytes); u64 checksum; zeros up to byte 256;
+ * bytes [256, total_bytes): the payload.  checksum = sum over the payload's 32-bit words w[i] of (w[i] + 0x9E3779B9) * (2 i + 1)
+ * mod 2^64.  The reference has no counterpart (torch.load of a state_dict, inference.py:69); the blob is what this library
+ * caches on disk and broadcasts between ranks, so it has to say what it is.
+ *
+ * emavfi_layout_tag: bit mask of the process-wide environment switches the packed LAYOUT depends on (read once per process):
+ *   1 EMAVFI_CONV_MFMA16=0, 2 EMAVFI_CONV_RING=0, 4 EMAVFI_CONV_S2RING=0, 8 EMAVFI_CONV_S2_CK64, 16 EMAVFI_PACK_F16_CHAIN=0,
+ *   32 EMAVFI_NO_FUSED_OFFSET.  Cache keys must use it (not the environment, which may have changed since the library latched it).
+ * emavfi_packed_check: verifies header (magic, version, model, dtype, layout tag, size) and checksum of a blob in device OR host
+ *   memory; EMAVFI_E_ARG with a message naming the mismatch.  THE ONE ENTRY THAT SYNCHRONISES (it copies a device blob to the
+ *   host): call it when a blob arrives - from a file, another rank, another process - not per frame.
+ * emavfi_forward itself (a) returns EMAVFI_E_ARG when packed_bytes is smaller than the model / dtype needs and (b) compares the
+ *   header ON THE DEVICE with what the call expects: a blob of another version / model / dtype / layout tag yields an all-NaN
+ *   frame (the context vector is poisoned), never plausible garbage; it cannot return a code for device-resident bytes without
+ *   synchronising. */
+int emavfi_layout_tag(void);
+int emavfi_packed_check(int in_channels, int mid_channels, int num_blocks, int dtype, const void *packed, size_t packed_bytes);
+
 /* EMA_VFI.forward(frame1, frame2) -> out, ema_vfi.py:110-147.
  * frame1, frame2: [B, in_channels, H, W] fp32; out: [B, in_channels, H, W] fp32 in [0,1].
  * `taps` is NULL, or 5 + num_blocks device pointers (any may be NULL) that receive NCHW fp32
@@ -118,7 +139,7 @@ int emavfi_pack_weights(int in_channels, int mid_channels, int num_blocks,
  *   [4] reserved  [5+i] output of attention block i [B,mid+3,H,W]. */
 size_t emavfi_workspace_bytes(int in_channels, int mid_channels, int num_blocks,
                               int B, int H, int W, int dtype);
-int emavfi_forward(int in_channels, int mid_channels, int num_blocks, const void *packed,
+int emavfi_forward(int in_channels, int mid_channels, int num_blocks, const void *packed, size_t packed_bytes,
                    const float *frame1, const float *frame2, float *out,
                    void *workspace, size_t workspace_bytes,
                    int B, int H, int W, int dtype, float *const *taps, void *stream);
@@ -132,7 +153,7 @@ int emavfi_forward(int in_channels, int mid_channels, int num_blocks, const void
  * events[2i] / events[2i+1] (caller-created hipEvent_t, timing enabled) on `stream`. */
 int emavfi_forward_launches(int in_channels, int mid_channels, int num_blocks, int B, int H, int W, int dtype,
                             char *names, size_t names_bytes, double *flops, double *bytes, int capacity);
-int emavfi_forward_profiled(int in_channels, int mid_channels, int num_blocks, const void *packed,
+int emavfi_forward_profiled(int in_channels, int mid_channels, int num_blocks, const void *packed, size_t packed_bytes,
                             const float *frame1, const float *frame2, float *out,
                             void *workspace, size_t workspace_bytes,
                             int B, int H, int W, int dtype, void *const *events, int n_events, void *stream);
@@ -174,6 +195,31 @@ int emavfi_deform_conv2d(const float *x, const float *offset, const float *mask,
                          const float *weight, const float *bias, float *y,
                          int B, int C, int O, int H, int W, int dtype,
                          void *workspace, size_t workspace_bytes, void *stream);
+
+/* ModulatedDeformConvPack.forward(x), ema_vfi.py:53-60, as one stage:
+ *   raw = offset_conv(x) (3x3, pad 1, C -> 27, :35-43); offset = cat(raw[:, 0:9], raw[:, 18:27]); mask = sigmoid(raw[:, 9:18]) (:56-59);
+ *   y = dcn_v2(x, offset, mask) (:60).
+ * x, y [B,C,H,W] fp32 NCHW; offset_weight [27,C,3,3], offset_bias [27], dcn_weight [C,C,3,3], dcn_bias [C] (may be NULL).
+ * C must be mid_channels + 3 of a supported model (the only width the reference builds the pack at, ema_vfi.py:97).
+ * Routed exactly as one attention block of emavfi_forward: EMAVFI_BF16 / EMAVFI_F16 at C = 67 run the ONE-LAUNCH kernel
+ * (offset_conv on the staged window, offsets / masks in registers, DCN, fix-up loop for samples that leave the window); EMAVFI_F32
+ * runs conv3x3 + the fp32 LDS-window DCN; EMAVFI_AMP16 the fp16 offset_conv + fp32 DCN pair; other widths conv3x3 + the
+ * global-gather DCN.  `flags` reproduce the forms the forward hands the tensor over in (one-launch kernel only):
+ *   EMAVFI_MDCN_IN_F16 / _OUT_F16  bf16 model: x is stored / y is produced as IEEE f16 bit patterns (hand-off between packs, `feat`);
+ *   EMAVFI_MDCN_SPLIT_TAIL         channels mid.. of x reach the kernel through the compact 8-channel buffer (the first pack's input). */
+#define EMAVFI_MDCN_IN_F16 1
+#define EMAVFI_MDCN_OUT_F16 2
+#define EMAVFI_MDCN_SPLIT_TAIL 4
+size_t emavfi_mdcn_workspace_bytes(int B, int C, int H, int W, int dtype, int flags);
+int emavfi_mdcn(const float *x, const float *offset_weight, const float *offset_bias, const float *dcn_weight, const float *dcn_bias,
+                float *y, int B, int C, int H, int W, int dtype, int flags, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Test hook: the A/B switches of the launch sequence (EMAVFI_CONV_FIRST / _FIRSTRING / _HEAD / _TAILFUSE / _LIGHT / _RING2 = 0,
+ * EMAVFI_NO_PERSISTENT_CONV) are read from the environment ONCE per process into one word; this replaces it by
+ * (word & and_mask) | or_mask and returns the previous value (bits: 1 no conv_first, 2 no fused first two layers, 4 no fused flow
+ * head, 8 no fused reconstruction tail, 16 no planar-head kernel, 32 no persistent conv, 64 no two-layer ring fusions).  None of
+ * them changes the packed layout.  Not for production callers. */
+int emavfi_debug_switches(int and_mask, int or_mask);
 
 #ifdef __cplusplus
 }

@@ -11,6 +11,8 @@ import torch
 from conftest import ROOT
 from emavfi import EMA_VFI, ModulatedDeformConvPack, lib, synth
 
+RING2 = False   # the two-layer ring fusions (conv_block_1+2, motion_estimation.0+.1+.2) are not in the default plan yet
+
 
 def header_symbols():
     text = open(os.path.join(ROOT, "include", "emavfi.h")).read()
@@ -25,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/emavfi.h but not exported"
     assert sorted(lib.SYMBOLS) == declared, "emavfi/lib.py prototypes out of sync with the header"
-    assert L.emavfi_version() == 300
+    assert L.emavfi_version() == 400
 
 
 def test_host_queries_and_error_codes():
@@ -57,7 +59,7 @@ def test_host_queries_and_error_codes():
     assert L.emavfi_workspace_bytes(3, 64, 3, 0, 720, 1280, lib.BF16) == 0
     # argument validation happens before any device work
     assert L.emavfi_warp(None, None, None, 1, 3, 8, 8, None) == -1
-    assert L.emavfi_forward(3, 64, 3, None, None, None, None, None, 0, 1, 8, 8, lib.F32, None, None) == -1
+    assert L.emavfi_forward(3, 64, 3, None, 0, None, None, None, None, 0, 1, 8, 8, lib.F32, None, None) == -1
     assert L.emavfi_conv3x3(None, None, None, None, 1, 3, 3, 8, 8, 1, 0, lib.F32, None, 0, None) == -1
     assert L.emavfi_conv3x3_workspace_bytes(1, 64, 64, 32, 32, 3, lib.F32) == 0
 
@@ -234,3 +236,102 @@ def test_packed_cache_file_carries_a_checksum(tmp_path):
     assert EMA_VFI._cache_read(path, 4096, "cpu") is None                 # old format / truncated
     assert EMA_VFI._cache_read(path, 4095, "cpu") is None                 # other size
     assert EMA_VFI._cache_read(str(tmp_path / "missing.bin"), 4096, "cpu") is None
+
+
+def _host_blob(L, mid, dt, tag=None, version=None, dtype_field=None):
+    """A blob in HOST memory built from include/emavfi.h's description of the header alone (no kernel runs here)."""
+    import numpy as np
+    total = L.emavfi_packed_bytes(3, mid, 3, dt)
+    blob = np.zeros(total, dtype=np.uint8)
+    rng = np.random.default_rng(7)
+    blob[256:] = rng.integers(0, 256, total - 256, dtype=np.uint8)
+    words = blob[256:].view(np.uint32).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        checksum = ((words + np.uint64(0x9E3779B9)) * (np.uint64(2) * np.arange(words.size, dtype=np.uint64) + np.uint64(1))).sum(dtype=np.uint64)
+    hdr = np.zeros(16, dtype=np.uint32)
+    hdr[0:2] = np.frombuffer(b"EMAVFIPK", dtype=np.uint32)
+    hdr[2] = L.emavfi_version() if version is None else version
+    hdr[3] = 256
+    hdr[4:8] = (3, mid, 3, dt if dtype_field is None else dtype_field)
+    hdr[8] = L.emavfi_layout_tag() if tag is None else tag
+    blob[:64] = hdr.view(np.uint8)
+    blob[40:48] = np.frombuffer(np.uint64(total).tobytes(), dtype=np.uint8)
+    blob[48:56] = np.frombuffer(np.uint64(checksum).tobytes(), dtype=np.uint8)
+    return blob
+
+
+def test_packed_blob_is_self_describing():
+    """VERDICT r3 item 8 / ADVICE r3: the packed blob starts with a header (magic, library version, model, dtype, layout-switch tag,
+    size, payload checksum) and emavfi_packed_check names what is wrong with a foreign one.  Host memory here: the check reads
+    device memory through a copy and anything else in place."""
+    L = lib.load()
+    assert L.emavfi_layout_tag() == 0, "the suite runs without layout switches in the environment"
+    assert lib.layout_switches() == "layout_tag=0"
+
+    def check(blob, mid=8, dt=lib.BF16, nbytes=None):
+        rc = L.emavfi_packed_check(3, mid, 3, dt, blob.ctypes.data, blob.size if nbytes is None else nbytes)
+        return rc, lib.last_error()
+
+    good = _host_blob(L, 8, lib.BF16)
+    assert check(good) == (0, lib.last_error())
+    flipped = good.copy()
+    flipped[5000] ^= 0x10
+    rc, msg = check(flipped)
+    assert rc == -1 and "checksum" in msg
+    rc, msg = check(good, dt=lib.F16)                       # same size, other dtype: only the header can tell
+    assert rc == -1 and "dtype" in msg
+    rc, msg = check(_host_blob(L, 8, lib.BF16, tag=2))       # packed under EMAVFI_CONV_RING=0
+    assert rc == -1 and "layout switches" in msg
+    rc, msg = check(_host_blob(L, 8, lib.BF16, version=300))
+    assert rc == -1 and "version 300" in msg
+    rc, msg = check(_host_blob(L, 16, lib.BF16), mid=16)
+    assert rc == 0
+    rc, msg = check(_host_blob(L, 16, lib.BF16)[:L.emavfi_packed_bytes(3, 16, 3, lib.BF16)], mid=8)   # a bigger model's blob
+    assert rc == -1 and "EMA_VFI(3, 16, 3)" in msg
+    headerless = good.copy()
+    headerless[:8] = 0
+    rc, msg = check(headerless)
+    assert rc == -1 and "EMAVFIPK" in msg
+    rc, msg = check(good, nbytes=good.size - 1)
+    assert rc == -1 and "bytes" in msg
+    assert L.emavfi_packed_check(3, 8, 3, lib.BF16, None, 100) == -1
+    # the forward refuses a buffer shorter than the model needs before it touches anything
+    fake = ctypes.c_void_p(256)
+    rc = L.emavfi_forward(3, 64, 3, fake, 1000, fake, fake, fake, fake, 1 << 40, 1, 64, 64, lib.BF16, None, None)
+    assert rc == -1 and "packed blob has 1000 bytes" in lib.last_error()
+
+
+def test_mdcn_entry_validates_its_arguments():
+    """emavfi_mdcn (one ModulatedDeformConvPack.forward, routed as a block of the forward): host-side queries and guards."""
+    L = lib.load()
+    assert L.emavfi_mdcn_workspace_bytes(1, 67, 32, 32, lib.BF16, 0) > 0
+    assert L.emavfi_mdcn_workspace_bytes(1, 67, 32, 32, lib.BF16, lib.MDCN_SPLIT_TAIL) > L.emavfi_mdcn_workspace_bytes(1, 67, 32, 32, lib.BF16, 0)
+    assert L.emavfi_mdcn_workspace_bytes(1, 67, 32, 32, lib.AMP16, 0) > L.emavfi_mdcn_workspace_bytes(1, 67, 32, 32, lib.F16, 0)
+    assert L.emavfi_mdcn_workspace_bytes(1, 11, 32, 32, lib.F32, 0) > 0
+    assert L.emavfi_mdcn_workspace_bytes(1, 66, 32, 32, lib.F32, 0) == 0 and "mid_channels + 3" in lib.last_error()
+    assert L.emavfi_mdcn_workspace_bytes(1, 67, 32, 32, lib.F32, lib.MDCN_IN_F16) == 0 and "f16 hand-off" in lib.last_error()
+    assert L.emavfi_mdcn_workspace_bytes(1, 67, 32, 32, lib.F16, lib.MDCN_OUT_F16) == 0      # bf16 models only
+    assert L.emavfi_mdcn_workspace_bytes(1, 11, 32, 32, lib.BF16, lib.MDCN_SPLIT_TAIL) == 0   # no one-launch kernel at that width
+    assert L.emavfi_mdcn_workspace_bytes(1, 67, 32, 32, lib.BF16, 8) == 0 and "flag" in lib.last_error()
+    fake = ctypes.c_void_p(256)
+    assert L.emavfi_mdcn(None, fake, fake, fake, fake, fake, 1, 67, 8, 8, lib.BF16, 0, fake, 0, None) == -1
+    assert L.emavfi_mdcn(fake, fake, fake, fake, fake, fake, 1, 67, 8, 8, lib.BF16, 0, fake, 16, None) == -3
+
+
+def test_switch_word_is_latched_and_settable():
+    """the launch-sequence switches are read from the environment once; tests flip them through emavfi_debug_switches."""
+    L = lib.load()
+    old = lib.debug_switches()
+    try:
+        assert L.emavfi_forward_launches(3, 64, 3, 1, 64, 64, lib.BF16, None, 0, None, None, 0) == 16 - (2 if RING2 else 0)
+        lib.debug_switches(~lib.SW_NO_HEAD, lib.SW_NO_HEAD)
+        os.environ["EMAVFI_CONV_HEAD"] = "1"            # the environment is not consulted again
+        try:
+            assert lib.debug_switches() & lib.SW_NO_HEAD
+            n = L.emavfi_forward_launches(3, 64, 3, 1, 64, 64, lib.BF16, None, 0, None, None, 0)
+        finally:
+            del os.environ["EMAVFI_CONV_HEAD"]
+        assert n > 16 - (2 if RING2 else 0)
+    finally:
+        lib.debug_switches(0, old)
+    assert lib.debug_switches() == old

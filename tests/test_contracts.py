@@ -34,15 +34,15 @@ def test_forward_launch_enumeration_matches_survey_flops():
 
 def test_size_limits_are_argument_errors_not_crashes():
     L = lib.load()
-    rc = L.emavfi_forward(3, 64, 3, None, None, None, None, None, 0, 1, 4096, 4096, lib.BF16, None, None)
+    rc = L.emavfi_forward(3, 64, 3, None, 0, None, None, None, None, 0, 1, 4096, 4096, lib.BF16, None, None)
     assert rc == -1 and "2^24" in lib.last_error()
-    rc = L.emavfi_forward(3, 64, 3, None, None, None, None, None, 0, 1, 8192, 4096, lib.F32, None, None)
+    rc = L.emavfi_forward(3, 64, 3, None, 0, None, None, None, None, 0, 1, 8192, 4096, lib.F32, None, None)
     assert rc == -1 and "4 GiB" in lib.last_error()
     # EMAVFI_AMP16 runs the fp32 deformable kernel on an fp32 fusion tensor (320-byte pixels) although its conv kernels are 16-bit:
     # 5120x2880 = 14.7M pixels passes the 2^24 pixel guard and the 2-byte plane guard but wraps 32-bit byte offsets at 4 bytes
-    rc = L.emavfi_forward(3, 64, 3, None, None, None, None, None, 0, 1, 2880, 5120, lib.AMP16, None, None)
+    rc = L.emavfi_forward(3, 64, 3, None, 0, None, None, None, None, 0, 1, 2880, 5120, lib.AMP16, None, None)
     assert rc == -1 and "4 GiB" in lib.last_error()
-    rc = L.emavfi_forward(3, 64, 3, None, None, None, None, None, 0, 1, 2880, 5120, lib.F16, None, None)
+    rc = L.emavfi_forward(3, 64, 3, None, 0, None, None, None, None, 0, 1, 2880, 5120, lib.F16, None, None)
     assert rc == -1 and "null pointer" in lib.last_error()     # the same size is fine for the all-16-bit mode (fails later, on the nulls)
     # stage-level conv entry: 32-bit DMA source offsets inside one sample (refused before anything is launched or dereferenced)
     import ctypes

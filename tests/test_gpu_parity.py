@@ -446,10 +446,10 @@ def test_cabi_errors_are_codes_not_aborts():
     o = torch.empty_like(x)
     blob = torch.empty(L.emavfi_packed_bytes(3, 64, 3, lib.F32), dtype=torch.uint8, device=DEV)
     small = torch.empty(1024, dtype=torch.uint8, device=DEV)
-    rc = L.emavfi_forward(3, 64, 3, blob.data_ptr(), x.data_ptr(), x.data_ptr(), o.data_ptr(), small.data_ptr(), small.numel(),
+    rc = L.emavfi_forward(3, 64, 3, blob.data_ptr(), blob.numel(), x.data_ptr(), x.data_ptr(), o.data_ptr(), small.data_ptr(), small.numel(),
                           1, 16, 16, lib.F32, None, None)
     assert rc == -3 and "workspace" in lib.last_error()
-    rc = L.emavfi_forward(3, 64, 3, blob.data_ptr(), x.data_ptr() + 4, x.data_ptr(), o.data_ptr(), small.data_ptr(),
+    rc = L.emavfi_forward(3, 64, 3, blob.data_ptr(), blob.numel(), x.data_ptr() + 4, x.data_ptr(), o.data_ptr(), small.data_ptr(),
                           small.numel(), 1, 16, 16, lib.F32, None, None)
     assert rc == -1 and "aligned" in lib.last_error()
     with pytest.raises(RuntimeError, match="inference-only"):
@@ -484,26 +484,16 @@ for dt in ("bf16", "fp16", "fp32"):
 """
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("cout,act", [(64, "relu"), (48, "none")])
-@pytest.mark.parametrize("shape", [(2, 75, 131), (1, 8, 32), (1, 17, 33), (2, 40, 64), (1, 360, 640)])
-def test_pingpong16_equals_the_lockstep_16x16x32_kernel(dtype, cout, act, shape, monkeypatch):
-    """Round 2's kernel of the 64 -> 64 layers (conv3x3_pingpong16_kernel, EMAVFI_CONV_RING=0) against conv3x3_persist16_kernel
-    (EMAVFI_CONV_PINGPONG=0): same MFMA shape, same accumulation order - bit-identical; one tile, odd tile counts per group,
-    tiles hanging over every edge."""
-    monkeypatch.setenv("EMAVFI_CONV_RING", "0")
-    B, H, W = shape
-    g = torch.Generator().manual_seed(13)
-    x = torch.randn(B, 64, H, W, generator=g).to(DEV)
-    w = (torch.randn(cout, 64, 3, 3, generator=g) * 0.05).to(DEV)
-    b = torch.randn(cout, generator=g).to(DEV)
-    kw = dict(dtype=dtype, act=lib.ACT_RELU if act == "relu" else lib.ACT_NONE)
-    monkeypatch.setenv("EMAVFI_CONV_PINGPONG", "0")
-    ref = lib.conv3x3(x, w, b, **kw).clone()
-    monkeypatch.delenv("EMAVFI_CONV_PINGPONG")
-    got = lib.conv3x3(x, w, b, **kw).clone()
-    assert torch.isfinite(got).all()
-    assert torch.equal(got, ref), f"{int((got != ref).sum())} of {got.numel()} elements differ, max {(got - ref).abs().max().item():.3e}"
+@pytest.fixture
+def switch():
+    """Flip A/B bits of the library's launch-sequence switch word (emavfi_debug_switches: the environment is read once per process,
+    never per call) and restore the word afterwards."""
+    old = lib.debug_switches()
+
+    def set_(bit, on):
+        lib.debug_switches(~bit, bit if on else 0)
+    yield set_
+    lib.debug_switches(0, old)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
@@ -568,7 +558,7 @@ def test_ring_conv_agrees_with_the_tile_kernels(dtype, cin, cout, act, shape, mo
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("shape", [(2, 75, 131), (1, 1, 7), (1, 2, 62), (1, 3, 63), (1, 17, 124), (1, 40, 125), (1, 360, 640)])
-def test_fused_flow_head_equals_the_two_launch_path(dtype, shape, monkeypatch):
+def test_fused_flow_head_equals_the_two_launch_path(dtype, shape, switch):
     """16-bit modes at mid_channels 64 run motion_estimation.1 + .2 as ONE launch: .1's rows stay in an LDS ring (zeroed outside
     the image - they are .2's padding) and the flow head is computed from them two rows behind (csrc/conv_ring.inl, HEAD).
     EMAVFI_CONV_HEAD=0 writes .1's tensor and runs the planar-head kernel (conv_light.inl).  Same rounded .1 rows, same head
@@ -579,14 +569,14 @@ def test_fused_flow_head_equals_the_two_launch_path(dtype, shape, monkeypatch):
     f1, f2 = (t.to(DEV) for t in synth.synthetic_frames(31, B, H, W, "natural"))
     flows, outs = [], []
     for flag in ("1", "0"):
-        monkeypatch.setenv("EMAVFI_CONV_HEAD", flag)
+        switch(lib.SW_NO_HEAD, flag == "0")
         m = make_model(sd, dtype=dtype)
         with torch.no_grad():
             out, taps = m(f1, f2, return_taps=True)
         flows.append(taps["flow"].clone()); outs.append(out.clone())
     names = [n for n, _, _ in lib.forward_launches(3, 64, 3, B, H, W, dtype)]
-    assert sum("+head" in n for n in names) == 0   # (EMAVFI_CONV_HEAD=0 still set: the enumeration follows the switch)
-    monkeypatch.delenv("EMAVFI_CONV_HEAD")
+    assert sum("+head" in n for n in names) == 0   # (the switch is still set: the enumeration follows it)
+    switch(lib.SW_NO_HEAD, False)
     names = [n for n, _, _ in lib.forward_launches(3, 64, 3, B, H, W, dtype)]
     assert sum("+head" in n for n in names) == 1
     err = (flows[0] - flows[1]).abs().max().item()
@@ -598,7 +588,7 @@ def test_fused_flow_head_equals_the_two_launch_path(dtype, shape, monkeypatch):
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("shape", [(2, 75, 131), (1, 1, 7), (1, 2, 62), (1, 3, 63), (1, 17, 124), (3, 40, 125), (1, 360, 640)])
-def test_fused_first_two_layers_equal_the_two_launch_path(dtype, shape, monkeypatch):
+def test_fused_first_two_layers_equal_the_two_launch_path(dtype, shape, switch):
     """16-bit modes at mid_channels 64 run cat + feat_ext_conv1 + ReLU + conv_block_0 + ReLU as ONE launch: feat_ext_conv1's rows
     exist only in an LDS ring (csrc/conv_ring_first.inl).  EMAVFI_CONV_FIRSTRING=0 runs conv_first + the ring kernel.  Both
     stages repeat the unfused kernels' arithmetic operation for operation, so `feat` (three layers later) and the frame must
@@ -608,7 +598,7 @@ def test_fused_first_two_layers_equal_the_two_launch_path(dtype, shape, monkeypa
     f1, f2 = (t.to(DEV) for t in synth.synthetic_frames(32, B, H, W, "natural"))
     feats, outs = [], []
     for flag in ("1", "0"):
-        monkeypatch.setenv("EMAVFI_CONV_FIRSTRING", flag)
+        switch(lib.SW_NO_FIRSTRING, flag == "0")
         m = make_model(sd, dtype=dtype)
         with torch.no_grad():
             out, taps = m(f1, f2, return_taps=True)
@@ -622,7 +612,7 @@ def test_fused_first_two_layers_equal_the_two_launch_path(dtype, shape, monkeypa
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("shape", [(2, 75, 131), (1, 1, 7), (1, 2, 62), (1, 3, 63), (1, 17, 124), (3, 40, 125), (1, 360, 640)])
-def test_fused_reconstruction_tail_equals_the_two_launch_path(dtype, shape, monkeypatch):
+def test_fused_reconstruction_tail_equals_the_two_launch_path(dtype, shape, switch):
     """16-bit modes at mid_channels 64 run reconstruction.1 + .2 (64 -> 32 + ReLU, 32 -> 3 + tanh, (t + 1) / 2) as ONE launch
     (csrc/conv_ring_tail.inl): .1's rows stay in an LDS ring, its 18 k-steps are split between two waves (another fp32 summation
     order than the unfused kernel's: .1's stored values may differ in the last place of the storage type in a few elements).
@@ -633,7 +623,7 @@ def test_fused_reconstruction_tail_equals_the_two_launch_path(dtype, shape, monk
     f1, f2 = (t.to(DEV) for t in synth.synthetic_frames(33, B, H, W, "natural"))
     outs = []
     for flag in ("1", "0"):
-        monkeypatch.setenv("EMAVFI_CONV_TAILFUSE", flag)
+        switch(lib.SW_NO_TAILFUSE, flag == "0")
         m = make_model(sd, dtype=dtype)
         with torch.no_grad():
             outs.append(m(f1, f2).clone())
@@ -645,7 +635,7 @@ def test_fused_reconstruction_tail_equals_the_two_launch_path(dtype, shape, monk
     assert err.max().item() <= (8e-3 if dtype == "bf16" else 1e-3)
 
 
-def test_fused_first_layer_equals_pack_input_plus_conv(monkeypatch):
+def test_fused_first_layer_equals_pack_input_plus_conv(switch):
     """16-bit modes at mid_channels 64 compute cat(frame1, frame2) + feat_ext_conv1 + ReLU in ONE launch straight from the NCHW
     fp32 frames (csrc/conv_first.inl); EMAVFI_CONV_FIRST=0 runs pack_input + conv3x3.  Same rounded inputs, weights and products;
     the fp32 accumulation groups two taps per MFMA instead of one, so conv1's stored output may differ by one unit in the last place
@@ -656,7 +646,7 @@ def test_fused_first_layer_equals_pack_input_plus_conv(monkeypatch):
     for dt, step, tol in (("bf16", 2.0 ** -7, 1.5e-2), ("fp16", 2.0 ** -10, 3e-3)):
         feats, outs = [], []
         for flag in ("1", "0"):
-            monkeypatch.setenv("EMAVFI_CONV_FIRST", flag)
+            switch(lib.SW_NO_CONV_FIRST, flag == "0")
             m = make_model(sd, dtype=dt)
             with torch.no_grad():
                 out, taps = m(f1, f2, return_taps=True)

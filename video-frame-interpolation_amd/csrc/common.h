@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -227,6 +228,40 @@ struct DeformParams {
 };
 #define DEFORM_STAMP_STRIDE 14
 #define DEFORM_STAMP_ROWS 16384
+
+// A/B switches of the launch sequence and of kernel selection.  They are read from the environment ONCE per process (first use)
+// into one atomic word - never per call: getenv racing a setenv from another thread is undefined behaviour, and a flip between
+// graph capture and replay, or between two ranks, silently changed the launch sequence.  The parity tests flip bits
+// in-process through emavfi_debug_switches() (include/emavfi.h) instead.  None of them changes the packed layout (those are
+// LayoutEnv in emavfi_api.hip: fixed per process, exported as emavfi_layout_tag(), verified against the blob header).
+enum {
+    SW_NO_CONV_FIRST = 1,        // EMAVFI_CONV_FIRST=0: pack_input + conv3x3<16,2,1> instead of conv_first
+    SW_NO_FIRSTRING = 2,         // EMAVFI_CONV_FIRSTRING=0: conv_first + ring kernel instead of conv_ring_first
+    SW_NO_HEAD = 4,              // EMAVFI_CONV_HEAD=0: motion_estimation.1 and .2 as two launches
+    SW_NO_TAILFUSE = 8,          // EMAVFI_CONV_TAILFUSE=0: reconstruction.1 and .2 as two launches
+    SW_NO_CONV_LIGHT = 16,       // EMAVFI_CONV_LIGHT=0: planar heads on conv3x3_persist16_kernel
+    SW_NO_PERSISTENT_CONV = 32,  // EMAVFI_NO_PERSISTENT_CONV: tile-per-workgroup kernel where the persistent one is the default
+    SW_NO_RING2 = 64,            // EMAVFI_CONV_RING2=0: conv_block_1 + conv_block_2 / motion_estimation.0 + .1 + .2 as separate launches
+};
+unsigned emavfi_switches();
+
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the function handle of ONE device: apply it once per (kernel, device).
+// (a per-process once-flag left every device but the first one of a multi-device process with the 64 KiB default.)
+// Thread-safe; a racing first call on a device merely sets the attribute twice.
+struct PerDeviceOnce {
+    std::atomic<unsigned long long> done{0};   // bit d: applied on device d (device ids >= 64: applied at every launch)
+};
+inline hipError_t set_lds_limit(PerDeviceOnce &o, const void *fn, int bytes)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = dev >= 0 && dev < 64 ? 1ull << dev : 0ull;
+    if (bit && (o.done.load(std::memory_order_acquire) & bit)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && bit) o.done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
 
 // compute units of the CURRENT device (persistent kernels size their grid by it); cached per device, thread-safe
 int device_cu_count();

@@ -28,31 +28,14 @@
 //   conv3x3_ring_kernel       (conv_ring.inl) that structure at stride 1: the 64 -> 64 layers and reconstruction.0 (67 -> 64) (product)
 //   conv3x3_ringtail_kernel   (conv_ring_tail.inl) reconstruction.1 + .2 (64 -> 32 -> 3) through a second LDS ring (product)
 //   conv3x3_persist_kernel    persistent, nine taps' weights resident, 16 x 32 tiles, 8 waves in lock step (32x32x16 MFMAs)
-//   conv3x3_persist16_kernel  the same on v_mfma_f32_16x16x32 with an unpadded XOR-swizzled tile: 64 -> 32 and 64 -> planes
-//   conv3x3_pingpong16_kernel two four-wave groups half a tile out of phase on that shape: the 64 -> 64 layers (EMAVFI_CONV_RING=0)
+//   conv3x3_persist16_kernel  the same on v_mfma_f32_16x16x32 with an unpadded XOR-swizzled tile: 64 -> 32 and 64 -> planes when the fused
+//                             ring kernels are switched off, 64 -> 64 with EMAVFI_CONV_RING=0 (round 2's ping-pong variant of it,
+//                             conv3x3_pingpong16_kernel, was removed in round 4: the ring kernels replaced it in the product)
 //   (round 2's conv3x3_pingpong_kernel - the schedule on 32x32x16 MFMAs - and conv3x3_tail_kernel - reconstruction.1 + .2 through
 //    the LDS - were measurement-only experiments that lost and were removed in round 3)
 #include "common.h"
 #include <cstdlib>
 #include <mutex>
-
-// Diagnostic build only (-DEMAVFI_CONV_STAMPS=1): s_memtime sums per phase of conv3x3_pingpong16_kernel, accumulated over all waves
-// into g_conv_stamps {contract, store, stage issue, wait at barrier (vmcnt + s_barrier), slots, waves}; read with
-// emavfi_debug_conv_stamps() (conv3x3_bf16.hip).  s_memtime counts at 100 MHz on gfx950.
-#ifndef EMAVFI_CONV_STAMPS
-#define EMAVFI_CONV_STAMPS 0
-#endif
-#if EMAVFI_CONV_STAMPS
-__device__ unsigned long long g_conv_stamps[8];
-__device__ __forceinline__ unsigned long long conv_stamp()
-{
-    unsigned long long t;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    __builtin_amdgcn_sched_barrier(0);
-    return t;
-}
-#endif
 
 // Source address of one 16-byte DMA piece: piece pc of input pixel (gy, gx) of the sample starting at gin, or the zero page when
 // the pixel lies outside the image (or `valid` is false).  32-bit offset arithmetic (a sample is < 4 GiB: checked at the API) and
@@ -369,13 +352,8 @@ __global__ __launch_bounds__(256, (conv_wg_per_cu<T, CK, NF, S>())) void conv3x3
 template <typename T, int CK, int NF, int S> static int launch_conv_inst(const ConvParams &p, hipStream_t s)
 {
     using C = ConvCfg<T, CK, NF, S>;
-    static std::once_flag once;  // the library is re-entrant: launchers may be called from several threads
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_kernel<T, CK, NF, S>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-    });
-    if (attr_err != hipSuccess) return (int)attr_err;
+    static PerDeviceOnce once;   // (the library is re-entrant and serves several devices per process)
+    if (const hipError_t e_ = set_lds_limit(once, reinterpret_cast<const void *>(&conv3x3_kernel<T, CK, NF, S>), C::LDS_BYTES); e_ != hipSuccess) return (int)e_;
     dim3 grid((p.Wout + 31) / 32, (p.Hout + C::TH - 1) / C::TH, p.B * p.npass);
     conv3x3_kernel<T, CK, NF, S><<<grid, 256, C::LDS_BYTES, s>>>(p);
     return (int)hipGetLastError();
@@ -671,7 +649,7 @@ __global__ __launch_bounds__(512) void conv3x3_persist16_kernel(const ConvParams
                 const int tap = s / C::K32, k32 = s - tap * C::K32;
                 const int dy = tap / 3, dx = tap - 3 * dy;
 #pragma unroll
-                for (int m = 0; m < MF; ++m) {   // see conv3x3_pingpong16_kernel: +16 pixels keeps the slot permutation, k32 flips byte 64
+                for (int m = 0; m < MF; ++m) {   // +16 pixels keeps the slot permutation, k32 flips byte 64
                     const int q = ((wave * MF + m) + dy) * IW + j + dx;
                     const int off = (q * PSTR + ((kb ^ swz16(q)) << 4)) ^ (k32 * 64);
                     xd[2 * m] = *reinterpret_cast<const vec *>(lds_in + off);
@@ -747,239 +725,12 @@ __global__ __launch_bounds__(512) void conv3x3_persist16_kernel(const ConvParams
 template <typename T, int CK, int NF, int NB> static int launch_conv_persist16(const ConvParams &p, hipStream_t s)
 {
     using C = ConvP16Cfg<T, CK, NF, NB>;
-    static std::once_flag once;
-    static hipError_t init_err = hipSuccess;
-    std::call_once(once, [] {
-        init_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_persist16_kernel<T, CK, NF, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-    });
-    if (init_err != hipSuccess) return (int)init_err;
+    static PerDeviceOnce once;   // (the library is re-entrant and serves several devices per process)
+    if (const hipError_t e_ = set_lds_limit(once, reinterpret_cast<const void *>(&conv3x3_persist16_kernel<T, CK, NF, NB>), C::LDS_BYTES); e_ != hipSuccess) return (int)e_;
     const int ncu = device_cu_count();
     if (ncu <= 0) return (int)hipErrorInvalidDevice;
     const int ntiles = ((p.Wout + 31) / 32) * ((p.Hout + C::TH - 1) / C::TH) * p.B;
     conv3x3_persist16_kernel<T, CK, NF, NB><<<ntiles < ncu ? ntiles : ncu, 512, C::LDS_BYTES, s>>>(p);
-    return (int)hipGetLastError();
-}
-
-// The 16x16x32 kernel with the ping-pong schedule (first built on 32x32x16 MFMAs in round 2: DESIGN.md section 4.2): two groups of four waves, each with
-// its own 8-row tile buffer (unpadded + XOR swizzle: 72 KiB of weights + 2 x 44 KiB fit), one group in its MFMA loop while the
-// other stores its previous tile and DMAs its next.  Channels-last epilogue only (64 -> 64).  The product's kernel for these
-// layers; bit-identical to conv3x3_persist16_kernel (EMAVFI_CONV_PINGPONG=0).
-template <typename T, int CK, int NF>
-__global__ __launch_bounds__(512) void conv3x3_pingpong16_kernel(const ConvParams p)
-{
-    constexpr int GW = 4, MF = 2, TH = GW * MF, IH = TH + 2, IW = 34, PSTR = 128, K32 = CK / 32, NB = NF * 2, PB = MF * 2;
-    constexpr int WTAP = K32 * NB * 1024, WINST = 9 * K32 * NB, NSLOT = IH * IW * 8, NINST = (NSLOT + 63) / 64;
-    constexpr int LDS_W = 9 * WTAP, LDS_IN = NINST * 1024;
-    static_assert(sizeof(T) == 2 && CK * 2 / 16 == 8 && LDS_W + 2 * LDS_IN <= 160 * 1024, "64 input channels, 16-bit, two tiles beside the weights");
-    using vec = typename DT<T>::vec;
-    typedef __attribute__((address_space(1))) const void gptr_t;
-    typedef __attribute__((address_space(3))) void lptr_t;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *lds_w = smem;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = wave >> 2, wq = wave & 3;
-    char *lds_in = smem + LDS_W + g * LDS_IN;
-    const int j = lane & 15, kb = lane >> 4;
-    const char *zeros = (const char *)p.zeros;
-    const int npieces = p.in_pieces > 0 ? p.in_pieces : 8;
-    const unsigned pixbytes = (unsigned)p.in_ps * (unsigned)sizeof(T);
-#pragma unroll 1
-    for (int i = wave; i < WINST; i += 8)
-        __builtin_amdgcn_global_load_lds((gptr_t *)((const char *)p.w + i * 1024 + lane * 16), (lptr_t *)(lds_w + i * 1024), 16, 0, 0);
-    const int ntx = (p.Wout + 31) / 32, nty = (p.Hout + TH - 1) / TH;
-    const int ntiles = ntx * nty * p.B;
-    const int first = (int)blockIdx.x * 2 + g, stride = (int)gridDim.x * 2;
-    const int rounds = ((int)blockIdx.x * 2 < ntiles) ? (ntiles - (int)blockIdx.x * 2 + stride - 1) / stride : 0;
-    const int coutpad = NF * 32;
-
-    // A DMA instruction's lanes -> (tile pixel, piece) never change, so for a tile that lies inside the image with its halo
-    // (all but the border tiles) the source is  tile origin (wave-uniform) + a per-lane byte offset computed ONCE per kernel:
-    // no address arithmetic at all beside the other group's MFMAs (the staging wave shares its SIMD's issue port with a
-    // contracting wave: every VALU instruction here delays an MFMA there; the generic path costs ~15 per DMA instruction).
-    constexpr int NDMA = (NINST + GW - 1) / GW;
-    unsigned dma_off[NDMA];
-    const bool fast_ok = EMAVFI_CONV_FASTDMA && npieces >= 8;
-#pragma unroll
-    for (int i = 0; i < NDMA; ++i) {
-        const int jn = i * GW + wq, sl = jn * 64 + lane;
-        const int pix = sl >> 3, pc = (sl & 7) ^ swz16(pix);
-        const int ly = pix / IW, lx = pix - ly * IW;
-        dma_off[i] = sl < NSLOT ? (unsigned)(ly * p.Win + lx) * pixbytes + (unsigned)pc * 16u : 0u;   // (slots past the tile: any valid address)
-    }
-    auto stage = [&](int tile) {
-        const int b = tile / (ntx * nty), trem = tile - b * (ntx * nty);
-        const int ty = trem / ntx, tx = trem - ty * ntx;
-        const int iy0 = ty * TH - 1, ix0 = tx * 32 - 1;
-        const char *gin = (const char *)p.in + (size_t)b * p.Hin * p.Win * p.in_ps * sizeof(T);
-        if (fast_ok && iy0 >= 0 && ix0 >= 0 && iy0 + IH <= p.Hin && ix0 + IW <= p.Win) {   // wave-uniform
-            const char *origin = gin + ((size_t)iy0 * p.Win + ix0) * pixbytes;
-#pragma unroll
-            for (int i = 0; i < NDMA; ++i) {
-                const int jn = i * GW + wq;
-                if (jn < NINST) __builtin_amdgcn_global_load_lds((gptr_t *)(origin + dma_off[i]), (lptr_t *)(lds_in + jn * 1024), 16, 0, 0);
-            }
-            return;
-        }
-#pragma unroll
-        for (int i = 0; i < NDMA; ++i) {
-            const int jn = i * GW + wq;
-            if (jn < NINST) {
-                const int sl = jn * 64 + lane;
-                const int pix = sl >> 3, pc = (sl & 7) ^ swz16(pix);
-                const int ly = pix / IW, lx = pix - ly * IW;
-                const int gy = iy0 + ly, gx = ix0 + lx;
-                const char *src = conv_dma_src(gin, zeros, gy, gx, pc, p.Hin, p.Win, pixbytes, sl < NSLOT && pc < npieces);
-                __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)(lds_in + jn * 1024), 16, 0, 0);
-            }
-        }
-    };
-    f32x4 acc[PB][NB];
-    auto contract = [&](int tile) {
-        const int b = tile / (ntx * nty), trem = tile - b * (ntx * nty);
-        const int ty = trem / ntx, tx = trem - ty * ntx;
-#pragma unroll
-        for (int pb = 0; pb < PB; ++pb) {
-            const float *bp = p.bias;
-            if (p.bias_mode == 1) {
-                const int y = ty * TH + wq * MF + (pb >> 1), x = tx * 32 + (pb & 1) * 16 + j;
-                const int ym = (y >= 1 ? 1 : 0) | (y <= p.Hout - 2 ? 2 : 0);
-                const int xm = (x >= 1 ? 1 : 0) | (x <= p.Wout - 2 ? 2 : 0);
-                bp += ((size_t)b * 16 + ym * 4 + xm) * coutpad;
-            }
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[pb][nb][e] = bp[nb * 16 + kb * 4 + e];
-        }
-        constexpr int NSTEP = 9 * K32;
-        vec xq[2][PB], wv[2][NB];
-        auto load_step = [&](int s, vec (&xd)[PB], vec (&wd)[NB]) {
-            const int tap = s / K32, k32 = s - tap * K32;
-            const int dy = tap / 3, dx = tap - 3 * dy;
-            // one address per row m: the second column block is 16 pixels = 2048 bytes further with the SAME slot permutation
-            // ((q + 16) >> 1 == (q >> 1) + 8), and the second 32-channel step flips bit 2 of the piece index = byte 64
-#pragma unroll
-            for (int m = 0; m < MF; ++m) {
-                const int q = ((wq * MF + m) + dy) * IW + j + dx;
-                const int off = (q * PSTR + ((kb ^ swz16(q)) << 4)) ^ (k32 * 64);   // bit 6 lies inside the 128-byte pixel
-                xd[2 * m] = *reinterpret_cast<const vec *>(lds_in + off);
-                xd[2 * m + 1] = *reinterpret_cast<const vec *>(lds_in + off + 2048);
-            }
-            const char *wb = lds_w + tap * WTAP + k32 * NB * 1024 + lane * 16;
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) wd[nb] = *reinterpret_cast<const vec *>(wb + nb * 1024);
-        };
-        load_step(0, xq[0], wv[0]);
-#pragma unroll
-        for (int s = 0; s < NSTEP; ++s) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (s + 1 < NSTEP) load_step(s + 1, xq[(s + 1) & 1], wv[(s + 1) & 1]);
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int pb = 0; pb < PB; ++pb) mma_k32(acc[pb][nb], wv[s & 1][nb], xq[s & 1][pb]);
-#if EMAVFI_CONV_INTERLEAVE
-            // one contracting wave per SIMD: a burst of 8 LDS reads in front of the 16 MFMAs leaves the matrix pipe idle while the
-            // wave issues them; spread the next step's reads between this step's MFMAs instead (1 read : 2 MFMAs)
-#pragma unroll
-            for (int u = 0; u < (PB + NB); ++u) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one DS read
-                __builtin_amdgcn_sched_group_barrier(0x008, (PB * NB) / (PB + NB), 0);   // MFMAs
-            }
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    auto store = [&](int tile) {
-        const int b = tile / (ntx * nty), trem = tile - b * (ntx * nty);
-        const int ty = trem / ntx, tx = trem - ty * ntx;
-        typedef __attribute__((ext_vector_type(2))) T pair_t;
-        typedef __attribute__((ext_vector_type(2))) short s16x2_t;
-        const bool relu = p.epi == EPI_RELU;
-        // (EMAVFI_CONV_PKRELU = 1, an experiment that lost: ReLU on the ROUNDED pair as a packed signed-16-bit max with 0)
-        const s16x2_t floor16 = (relu && EMAVFI_CONV_PKRELU) ? s16x2_t{0, 0} : s16x2_t{(short)-32768, (short)-32768};
-#pragma unroll
-        for (int pb = 0; pb < PB; ++pb) {
-            const int y = ty * TH + wq * MF + (pb >> 1), x = tx * 32 + (pb & 1) * 16 + j;
-            const bool inside = y < p.Hout && x < p.Wout;
-            T *ob = reinterpret_cast<T *>(p.out) + (((size_t)b * p.Hout + (inside ? y : 0)) * p.Wout + (inside ? x : 0)) * p.out_ps + p.out_coff;
-#pragma unroll
-            for (int t = 0; t < NB / 2; ++t) {
-                unsigned a[2], c2[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    float v0 = acc[pb][2 * t][2 * i], v1 = acc[pb][2 * t][2 * i + 1], u0 = acc[pb][2 * t + 1][2 * i], u1 = acc[pb][2 * t + 1][2 * i + 1];
-                    if (relu && !EMAVFI_CONV_PKRELU) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); u0 = fmaxf(u0, 0.0f); u1 = fmaxf(u1, 0.0f); }
-                    const pair_t pa = {(T)v0, (T)v1}, pc2 = {(T)u0, (T)u1};
-                    const s16x2_t ra = __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, pa), floor16);
-                    const s16x2_t rc = __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, pc2), floor16);
-                    const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, ra), __builtin_bit_cast(unsigned, rc), false, false);
-                    a[i] = sw[0];
-                    c2[i] = sw[1];
-                }
-                const int c0 = (2 * t + (kb & 1)) * 16 + (kb >> 1) * 8;
-                if (inside && c0 < p.cstore) *reinterpret_cast<uint4 *>(ob + c0) = make_uint4(a[0], a[1], c2[0], c2[1]);
-            }
-        }
-    };
-    if (g == 0 && first < ntiles) stage(first);
-    __syncthreads();
-#if EMAVFI_CONV_STAMPS
-    unsigned long long st_c = 0, st_s = 0, st_g = 0, st_w = 0;
-#endif
-#pragma unroll 1
-    for (int sl = 0; sl <= 2 * rounds; ++sl) {
-#if EMAVFI_CONV_STAMPS
-        const unsigned long long t0 = conv_stamp();
-        unsigned long long t1 = t0, t2 = t0;
-#endif
-        if (((sl + g) & 1) == 0) {
-            const int t = first + ((sl - g) >> 1) * stride;
-            if (sl < 2 * rounds && t < ntiles) contract(t);
-#if EMAVFI_CONV_STAMPS
-            t1 = t2 = conv_stamp();
-            st_c += t1 - t0;
-#endif
-        } else {
-            const int tp = first + ((sl - 1 - g) >> 1) * stride, tn = first + ((sl + 1 - g) >> 1) * stride;
-            if (sl - 1 - g >= 0 && tp < ntiles) store(tp);
-#if EMAVFI_CONV_STAMPS
-            t1 = conv_stamp();
-            st_s += t1 - t0;
-#endif
-            if (sl < 2 * rounds && tn < ntiles) stage(tn);
-#if EMAVFI_CONV_STAMPS
-            t2 = conv_stamp();
-            st_g += t2 - t1;
-#endif
-        }
-        __syncthreads();
-#if EMAVFI_CONV_STAMPS
-        st_w += conv_stamp() - t2;
-#endif
-    }
-#if EMAVFI_CONV_STAMPS
-    if (lane == 0) {
-        atomicAdd(&g_conv_stamps[0], st_c); atomicAdd(&g_conv_stamps[1], st_s); atomicAdd(&g_conv_stamps[2], st_g);
-        atomicAdd(&g_conv_stamps[3], st_w); atomicAdd(&g_conv_stamps[4], (unsigned long long)(2 * rounds + 1)); atomicAdd(&g_conv_stamps[5], 1ull);
-    }
-#endif
-}
-
-template <typename T, int CK, int NF> static int launch_conv_pingpong16(const ConvParams &p, hipStream_t s)
-{
-    constexpr int LDS_BYTES = 9 * (CK / 32) * NF * 2 * 1024 + 2 * (((10 * 34 * 8) + 63) / 64) * 1024;
-    static std::once_flag once;
-    static hipError_t init_err = hipSuccess;
-    std::call_once(once, [] {
-        init_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_pingpong16_kernel<T, CK, NF>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    });
-    if (init_err != hipSuccess) return (int)init_err;
-    const int ncu = device_cu_count();
-    if (ncu <= 0) return (int)hipErrorInvalidDevice;
-    const int ntiles = ((p.Wout + 31) / 32) * ((p.Hout + 7) / 8) * p.B;
-    const int wgs = (ntiles + 1) / 2;
-    conv3x3_pingpong16_kernel<T, CK, NF><<<wgs < ncu ? wgs : ncu, 512, LDS_BYTES, s>>>(p);
     return (int)hipGetLastError();
 }
 
@@ -995,15 +746,10 @@ template <typename T> static int launch_conv_mfma16(const ConvParams &p, hipStre
     if (p.ck == 32 && p.stride == 1 && p.nchunk == 1 && p.npass == 1 && p.nf == 1 && planar && p.nplanes <= 4) return launch_conv_light<T, 32>(p, s);
     if (p.ck != 64 || p.stride != 1 || p.nchunk != 1 || p.npass != 1) return -2;
     if (!planar && p.epi != EPI_NONE && p.epi != EPI_RELU) return -2;
-    // 64 -> 64: the ping-pong schedule is the default here (530 vs 612 us; the step keeps 1.7 % of it after the board's clock
-    // response); EMAVFI_CONV_PINGPONG=0 selects the lock-step kernel (read per call: parity test)
-    const char *pp_ = getenv("EMAVFI_CONV_PINGPONG");
-    if (p.nf == 2 && !planar && !(pp_ != nullptr && pp_[0] == '0')) return launch_conv_pingpong16<T, 64, 2>(p, s);
     if (p.nf == 2 && !planar) return launch_conv_persist16<T, 64, 2, 4>(p, s);
     if (p.nf == 1 && !planar) return launch_conv_persist16<T, 64, 1, 2>(p, s);
     if (p.nf == 1 && planar && p.nplanes <= 4) {
-        const char *cl_ = getenv("EMAVFI_CONV_LIGHT");   // 0: the lock-step persistent kernel (A/B; read per call)
-        if (!(cl_ != nullptr && cl_[0] == '0')) return launch_conv_light<T, 64>(p, s);
+        if (!(emavfi_switches() & SW_NO_CONV_LIGHT)) return launch_conv_light<T, 64>(p, s);   // EMAVFI_CONV_LIGHT=0: the lock-step persistent kernel (A/B)
         return launch_conv_persist16<T, 64, 1, 1>(p, s);
     }
     return -2;
@@ -1012,13 +758,12 @@ template <typename T> static int launch_conv_mfma16(const ConvParams &p, hipStre
 template <typename T, int CK, int NF, int WAVES> static int launch_conv_persist(const ConvParams &p, hipStream_t s)
 {
     using C = ConvPersistCfg<T, CK, NF, WAVES>;
-    static std::once_flag once;
+    static PerDeviceOnce lds_once;
+    if (const hipError_t e_ = set_lds_limit(lds_once, reinterpret_cast<const void *>(&conv3x3_persist_kernel<T, CK, NF, WAVES>), C::LDS_BYTES); e_ != hipSuccess) return (int)e_;
+    static std::once_flag once;   // (the occupancy of the first device is taken for all: one process drives one GPU model)
     static int wg_per_cu = 0;  // resident workgroups per CU: registers and LDS both limit it
     static hipError_t init_err = hipSuccess;
     std::call_once(once, [] {
-        const void *fn = reinterpret_cast<const void *>(&conv3x3_persist_kernel<T, CK, NF, WAVES>);
-        init_err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        if (init_err != hipSuccess) return;
         int n = 0;
         init_err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3x3_persist_kernel<T, CK, NF, WAVES>, 64 * WAVES, C::LDS_BYTES);
         if (init_err != hipSuccess) return;
@@ -1192,12 +937,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2ring_kernel(const ConvParams
 template <typename T, bool ALT> static int launch_conv_s2ring_t(const ConvParams &p, hipStream_t s)
 {
     using C = ConvS2RCfg<T>;
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_s2ring_kernel<T, ALT>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-    });
-    if (attr_err != hipSuccess) return (int)attr_err;
+    static PerDeviceOnce once;   // (the library is re-entrant and serves several devices per process)
+    if (const hipError_t e_ = set_lds_limit(once, reinterpret_cast<const void *>(&conv3x3_s2ring_kernel<T, ALT>), C::LDS_BYTES); e_ != hipSuccess) return (int)e_;
     const int ncu = device_cu_count();
     if (ncu <= 0) return (int)hipErrorInvalidDevice;
     const int nstrip = ((p.Wout + 31) / 32) * p.B;

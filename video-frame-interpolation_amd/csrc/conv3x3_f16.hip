@@ -4,8 +4,7 @@
 #include <cstdlib>
 int launch_conv3x3_f16(const ConvParams &p, hipStream_t s)
 {
-    static const bool off = getenv("EMAVFI_NO_PERSISTENT_CONV") != nullptr;  // A/B switch for measurements
-    return launch_conv16<half_t>(p, s, off);
+    return launch_conv16<half_t>(p, s, (emavfi_switches() & SW_NO_PERSISTENT_CONV) != 0);   // EMAVFI_NO_PERSISTENT_CONV: A/B switch for measurements
 }
 
 int launch_conv_first_f16(const FirstParams &p, hipStream_t s) { return launch_conv_first_t<half_t>(p, s); }

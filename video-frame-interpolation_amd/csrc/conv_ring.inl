@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
                 const bool ok = rowok && (unsigned)(ix0 + (int)xcol[i]) < (unsigned)p.Win;
                 const char *src = ok ? rowp + xoff[i] : zeros;
                 const unsigned dst = lds0 + (jn < C::ROWINST ? (unsigned)(slot * C::ROWB + jn * 1024) : (unsigned)C::SCRATCH_OFF);
-                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory");
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory", "m0");
             }
         };
         // the bias table in LDS: [border class 0..15][64] floats (bias_mode 0: one class) - no global loads inside the row loop
@@ -387,12 +387,8 @@ static void conv_ring_segments(int nstrip, int Hout, int grid, int *nseg_out, in
 template <typename T, bool TAIL, bool HEAD, bool ALT = false> static int launch_conv_ring_t(const ConvParams &p, hipStream_t s)
 {
     using C = ConvRingCfg<T, TAIL, HEAD>;
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_ring_kernel<T, TAIL, HEAD, ALT>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-    });
-    if (attr_err != hipSuccess) return (int)attr_err;
+    static PerDeviceOnce once;   // (the library is re-entrant and serves several devices per process)
+    if (const hipError_t e_ = set_lds_limit(once, reinterpret_cast<const void *>(&conv3x3_ring_kernel<T, TAIL, HEAD, ALT>), C::LDS_BYTES); e_ != hipSuccess) return (int)e_;
     const int ncu = device_cu_count();
     if (ncu <= 0) return (int)hipErrorInvalidDevice;
     const int nstrip = ((p.Wout + C::TWO - 1) / C::TWO) * p.B, grid = 2 * ncu;

@@ -234,12 +234,8 @@ template <typename T> static int launch_conv_ringfirst_t(const FirstParams &fp, 
 {
     using C = RingFirstCfg<T>;
     if (p.ring != 2 || p.stride != 1 || p.bias_mode != 0 || (p.epi != EPI_NONE && p.epi != EPI_RELU) || !fp.relu || fp.H != p.Hout || fp.W != p.Wout) return -2;
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_ringfirst_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-    });
-    if (attr_err != hipSuccess) return (int)attr_err;
+    static PerDeviceOnce once;   // (the library is re-entrant and serves several devices per process)
+    if (const hipError_t e_ = set_lds_limit(once, reinterpret_cast<const void *>(&conv3x3_ringfirst_kernel<T>), C::LDS_BYTES); e_ != hipSuccess) return (int)e_;
     const int ncu = device_cu_count();
     if (ncu <= 0) return (int)hipErrorInvalidDevice;
     const int nstrip = ((p.Wout + C::TWO - 1) / C::TWO) * p.B, grid = 2 * ncu;

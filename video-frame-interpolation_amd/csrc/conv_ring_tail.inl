@@ -98,9 +98,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvPara
                 const bool ok = rowok && (unsigned)(ix0 + (int)xcol[i]) < (unsigned)p.Win;
                 const char *src = ok ? rowp + xoff[i] : zeros;
                 const unsigned dst = lds0 + (jn < C::ROWINST ? (unsigned)(slot * C::ROWB + jn * 1024) : (unsigned)C::SCRATCH_OFF);
-                // (no "memory" clobber: the slot written is not touched before the next counted wait, and LDS reads of this step
-                // may be scheduled around the DMA issue)
-                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst));
+                // (no "memory" clobber on purpose: LDS reads of this step may be scheduled around the DMA issue.  Safe because the
+                // slot written - ring row (y + D) % RING - is read by no wave before the NEXT step's counted wait + s_barrier, which is
+                // followed by a compiler-level memory fence; no LDS WRITE of the kernel targets the input ring at all.  m0 IS
+                // clobbered: ADVICE r3)
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "m0");
             }
         };
         // the head's stores: wave w owns head columns [16 w, 16 w + 16); output rows 0..2 of a pixel live in the lanes with kb == 0
@@ -235,12 +237,8 @@ template <typename T> static int launch_conv_ringtail(const ConvParams &p, hipSt
     if (!p.mfma16 || p.ck != 64 || p.nf != 1 || p.stride != 1 || p.bias_mode != 0 || (p.epi != EPI_NONE && p.epi != EPI_RELU) || !p.head_w || !p.head_bias ||
         !p.out_planar || p.nplanes < 1 || p.nplanes > 3)
         return -2;
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_ringtail_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-    });
-    if (attr_err != hipSuccess) return (int)attr_err;
+    static PerDeviceOnce once;   // (the library is re-entrant and serves several devices per process)
+    if (const hipError_t e_ = set_lds_limit(once, reinterpret_cast<const void *>(&conv3x3_ringtail_kernel<T>), C::LDS_BYTES); e_ != hipSuccess) return (int)e_;
     const int ncu = device_cu_count();
     if (ncu <= 0) return (int)hipErrorInvalidDevice;
     const int nstrip = ((p.Wout + C::TWO - 1) / C::TWO) * p.B, grid = 2 * ncu;

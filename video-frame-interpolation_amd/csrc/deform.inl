@@ -316,13 +316,8 @@ __global__ __launch_bounds__(256, 2) void deform_kernel(const DeformParams p)
 template <typename T, int CK, int NF> static int launch_deform_inst(const DeformParams &p, hipStream_t s)
 {
     using C = DeformCfg<T, CK, NF>;
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&deform_kernel<T, CK, NF>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-    });
-    if (attr_err != hipSuccess) return (int)attr_err;
+    static PerDeviceOnce once;   // (the library is re-entrant and serves several devices per process)
+    if (const hipError_t e_ = set_lds_limit(once, reinterpret_cast<const void *>(&deform_kernel<T, CK, NF>), C::LDS_BYTES); e_ != hipSuccess) return (int)e_;
     dim3 grid((p.W + 31) / 32, (p.H + 7) / 8, p.B);
     deform_kernel<T, CK, NF><<<grid, 256, C::LDS_BYTES, s>>>(p);
     return (int)hipGetLastError();

@@ -289,12 +289,8 @@ __global__ __launch_bounds__(256, 2) void deform_f32w_kernel(const DeformParams 
 static int launch_deform_f32w(const DeformParams &p, hipStream_t s)
 {
     using C = F32W;
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&deform_f32w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-    });
-    if (attr_err != hipSuccess) return (int)attr_err;
+    static PerDeviceOnce once;   // (the library is re-entrant and serves several devices per process)
+    if (const hipError_t e_ = set_lds_limit(once, reinterpret_cast<const void *>(&deform_f32w_kernel), C::LDS_BYTES); e_ != hipSuccess) return (int)e_;
     const long long nwg = (long long)((p.W + C::TCOLS - 1) / C::TCOLS) * ((p.H + C::TROWS - 1) / C::TROWS) * p.B;
     if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     deform_f32w_kernel<<<(unsigned)nwg, C::THREADS, C::LDS_BYTES, s>>>(p);

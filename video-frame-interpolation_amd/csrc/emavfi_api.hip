@@ -6,10 +6,12 @@
 #include "misc_kernels.h"
 #include "conv_first.inl"
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -24,6 +26,25 @@ int fail(int code, const char *fmt, ...)
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     return code;
+}
+
+// common.h, SW_*: the A/B switches of the launch sequence, latched from the environment at first use
+std::atomic<unsigned> g_switches{0};
+std::once_flag g_switches_once;
+void init_switches()
+{
+    std::call_once(g_switches_once, [] {
+        const auto off = [](const char *name) { const char *e = getenv(name); return e && e[0] == '0'; };
+        unsigned v = 0;
+        if (off("EMAVFI_CONV_FIRST")) v |= SW_NO_CONV_FIRST;
+        if (off("EMAVFI_CONV_FIRSTRING")) v |= SW_NO_FIRSTRING;
+        if (off("EMAVFI_CONV_HEAD")) v |= SW_NO_HEAD;
+        if (off("EMAVFI_CONV_TAILFUSE")) v |= SW_NO_TAILFUSE;
+        if (off("EMAVFI_CONV_LIGHT")) v |= SW_NO_CONV_LIGHT;
+        if (off("EMAVFI_CONV_RING2")) v |= SW_NO_RING2;
+        if (getenv("EMAVFI_NO_PERSISTENT_CONV") != nullptr) v |= SW_NO_PERSISTENT_CONV;
+        g_switches.store(v, std::memory_order_relaxed);
+    });
 }
 
 inline int rup(int v, int m) { return (v + m - 1) / m * m; }
@@ -77,6 +98,15 @@ const LayoutEnv &process_layout_env()
 {
     static const LayoutEnv env = read_layout_env();
     return env;
+}
+
+// bit i of emavfi_layout_tag(): every process-wide switch a packed blob's LAYOUT depends on (the blob header carries the tag of the
+// packing process; emavfi_packed_check and the forward's guard compare it with this process's)
+bool pack_f16_chain();
+unsigned layout_tag_of(const LayoutEnv &e)
+{
+    return (e.m16_off ? 1u : 0u) | (e.ring_off ? 2u : 0u) | (e.s2ring_off ? 4u : 0u) | (e.s2_ck64 ? 8u : 0u) | (pack_f16_chain() ? 0u : 16u) |
+           (deform16_can_fuse_offset_conv(80, 3, 67, 80, 1) ? 0u : 32u);   // (EMAVFI_NO_FUSED_OFFSET, latched in deform_bf16.hip)
 }
 
 bool conv_geometry(Layer &L, int esize, const LayoutEnv &env)
@@ -235,7 +265,7 @@ bool build_plan(Plan &P, int in_ch, int mid, int nb, int dtype)
     P.r1 = mk(q, mid / 2, mid); q += 2;
     P.r2 = mk(q, in_ch, mid / 2); q += 2;
 
-    size_t o = 0;
+    size_t o = kBlobHeaderBytes;   // the blob's header (misc_kernels.h, BlobHeader) comes first
     auto place = [&](Layer &L, bool deform) {
         const bool ok = deform ? deform_geometry(L, P.esize) : conv_geometry(L, P.esize, process_layout_env());
         if (!ok) return false;
@@ -482,12 +512,74 @@ void conv_work(const Plan &P, const Layer &L, int B, int Hin, int Win, double ou
         (rec).idx++;                                                                                   \
     } while (0)
 
-int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *packed, const float *frame1,
+// ---- one ModulatedDeformConvPack.forward (ema_vfi.py:53-60) as the forward runs it; shared by forward_impl and the stage-level entry
+// emavfi_mdcn so that the stage test exercises exactly the product's routing, packing and flags.
+// Whether block i runs as ONE launch (offset_conv computed on the staged window, offsets / masks never leave the registers)
+bool pack_fuses(const Plan &P, int i)
+{
+    return P.dtype != EMAVFI_F32 && !P.amp && P.off[i].nchunk == 1 && P.off[i].npass == 1 && P.off[i].stride == 1 &&
+           deform16_can_fuse_offset_conv(P.dcn[i].ck, P.dcn[i].nf, P.dcn[i].cin_take, P.off[i].ck, P.off[i].nf) &&
+           (P.dcn[i].pack3 == 0 || P.has_offh);
+}
+// bf16 model, consecutive one-launch packs in the deform_pack3 layout: pack i writes f16 bit patterns for pack i + 1
+bool pack_f16_link(const Plan &P, int i)
+{
+    return P.dtype == EMAVFI_BF16 && pack_f16_chain() && i >= 0 && i + 1 < P.nb && P.dcn[i].pack3 && P.dcn[i + 1].pack3 && pack_fuses(P, i) &&
+           pack_fuses(P, i + 1);
+}
+// 16-bit / fp32 models: x -> y (channels-last, pixel stride P.fps).  x_tail: the compact 8-channel buffer the first pack takes channels
+// 64.. from (or null); in_f16 / out_f16: the bf16 model's f16 hand-off (DeformParams)
+int attention_block(const Plan &P, int i, const void *packed, const void *x, void *y, float *om, const void *x_tail, int in_f16, int out_f16,
+                    int B, int H, int W, hipStream_t s, Recorder &rec)
+{
+    const double px = (double)B * H * W, e = P.esize, cf = P.mid + 3;
+    double fl, by;
+    conv_work(P, P.off[i], B, H, W, 4.0, fl, by);
+    if (pack_fuses(P, i)) {
+        // one launch for the whole pack (ema_vfi.py:54-60): offset_conv on the staged window, then the DCN;
+        // the input is read once and the offsets / masks never leave the registers
+        EMAVFI_STEP(rec, deform_name(P, P.dcn[i]) + " offset_conv+dcn_v2", fl + 2.0 * 9.0 * cf * cf * px, px * (2.0 * cf * e) + 9.0 * cf * (cf + 27.0) * e,
+                    run_deform(P, P.dcn[i], packed, x, P.fps, om, y, P.fps, P.fps, B, H, W, s, nullptr, P.has_offh ? &P.offh[i] : &P.off[i], x_tail, 8,
+                               -1, in_f16, out_f16));
+    } else {
+        if (x_tail || in_f16 || out_f16) return fail(EMAVFI_E_UNSUPPORTED, "attention block: split tail / f16 hand-off need the one-launch pack kernel");
+        EMAVFI_STEP(rec, conv_name(P, P.off[i]) + " offset_conv", fl, by, run_conv(P, P.off[i], packed, x, P.fps, H, W, om, 32, 0, 32, EPI_OM, B, s));
+        EMAVFI_STEP(rec, deform_name(P, P.dcn[i]) + " dcn_v2", 2.0 * 9.0 * cf * cf * px, px * (2.0 * cf * e + 27.0 * 4.0) + 9.0 * cf * cf * e,
+                    run_deform(P, P.dcn[i], packed, x, P.fps, om, y, P.fps, P.fps, B, H, W, s));
+    }
+    return EMAVFI_OK;
+}
+// EMAVFI_AMP16: fp16 offset_conv on the fp16 rounding x16 of the fusion tensor, fp32 deform_conv2d on the fp32 tensor xF -> yF
+int attention_block_amp(const Plan &P, int i, const void *packed, const void *x16, const float *xF, float *yF, float *om, int B, int H, int W,
+                        hipStream_t s, Recorder &rec)
+{
+    const double px = (double)B * H * W, cf = P.mid + 3;
+    double fl, by;
+    conv_work(P, P.off[i], B, H, W, 4.0, fl, by);
+    EMAVFI_STEP(rec, conv_name(P, P.off[i]) + " offset_conv", fl, by, run_conv(P, P.off[i], packed, x16, P.fps, H, W, om, 32, 0, 32, EPI_OM, B, s));
+    EMAVFI_STEP(rec, "deform<f32,ck=80,nf=3> dcn_v2 (fp32 under autocast)", 2.0 * 9.0 * cf * cf * px, px * (2.0 * cf * 4.0 + 27.0 * 4.0) + 9.0 * cf * cf * 4.0,
+                run_deform(P, P.dcn32[i], packed, xF, P.fpad, om, yF, P.fpad, P.fpad, B, H, W, s, nullptr, nullptr, nullptr, 0, EMAVFI_F32));
+    return EMAVFI_OK;
+}
+
+BlobHeader expected_header(const Plan &P, int requested_dtype)
+{
+    BlobHeader h{};
+    memcpy(h.magic, "EMAVFIPK", 8);
+    h.version = EMAVFI_VERSION; h.header_bytes = kBlobHeaderBytes;
+    h.in_ch = (uint32_t)P.in_ch; h.mid = (uint32_t)P.mid; h.nb = (uint32_t)P.nb; h.dtype = (uint32_t)requested_dtype;
+    h.layout_tag = layout_tag_of(process_layout_env());
+    h.total_bytes = P.total;
+    return h;
+}
+
+int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *packed, size_t packed_bytes, const float *frame1,
                  const float *frame2, float *out, void *workspace, size_t workspace_bytes, int B, int H, int W, int dtype,
                  float *const *taps, void *stream, Recorder &rec)
 {
     Plan P;
     if (!build_plan(P, in_channels, mid_channels, num_blocks, dtype)) return fail(EMAVFI_E_UNSUPPORTED, "%s", P.why);
+    const int requested_dtype = dtype;
     dtype = P.dtype;  // the kernel storage type from here on (EMAVFI_AMP16 -> EMAVFI_F16, with P.amp set)
     if (B < 1 || H < 1 || W < 1) return fail(EMAVFI_E_ARG, "forward: B, H, W must be >= 1 (got %d, %d, %d)", B, H, W);
     if ((size_t)B * H * W >= ((size_t)1 << 31)) return fail(EMAVFI_E_ARG, "forward: B*H*W must be < 2^31");
@@ -504,8 +596,17 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
         if (!aligned16(packed) || !aligned16(workspace) || !aligned16(frame1) || !aligned16(frame2) || !aligned16(out))
             return fail(EMAVFI_E_ARG, "forward: pointers must be 16-byte aligned");
         if (ws.used > workspace_bytes) return fail(EMAVFI_E_WORKSPACE, "forward: workspace needs %zu bytes, got %zu", ws.used, workspace_bytes);
+        // every kernel reads the blob at offsets of THIS plan: a shorter buffer is another model's, another dtype's or a truncated one
+        if (packed_bytes < P.total)
+            return fail(EMAVFI_E_ARG, "forward: packed blob has %zu bytes, EMA_VFI(%d, %d, %d) in this dtype needs %zu (wrong model / dtype / version?)",
+                        packed_bytes, in_channels, mid_channels, num_blocks, P.total);
     }
     hipStream_t s = (hipStream_t)stream;
+    const unsigned sw = emavfi_switches();
+    // the header of the blob is compared ON THE DEVICE with what this call expects (ctx_finish_kernel): a blob of another version /
+    // model / dtype / layout-switch setting turns the context vector - and with it the flow, the warp and the frame - into NaN
+    // instead of plausible garbage.  emavfi_packed_check() is the (synchronising) entry that returns a code for it.
+    BlobGuard guard{rec.dry ? nullptr : (const BlobHeader *)packed, expected_header(P, requested_dtype)};
     const int mid = P.mid, C = P.in_ch;
     const double px = (double)B * H * W, e = P.esize;
     const size_t npx = (size_t)B * H * W;
@@ -519,13 +620,13 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
     int first_blk = 0;
     void *cur = f.fA, *nxt = f.fB;
     {
-        const char *cf = getenv("EMAVFI_CONV_FIRST");   // read per call: the parity test flips it inside one process (the blob carries both layouts)
-        const char *rf = getenv("EMAVFI_CONV_FIRSTRING");
-        if (P.conv1.first6 && !(cf && cf[0] == '0')) {
+        // EMAVFI_CONV_FIRST=0 / EMAVFI_CONV_FIRSTRING=0 (the blob carries both layouts; the switch word is latched once per process and
+        // flipped by the parity tests through emavfi_debug_switches)
+        if (P.conv1.first6 && !(sw & SW_NO_CONV_FIRST)) {
             // cat(frame1, frame2) + conv + ReLU in one launch, straight from the NCHW fp32 frames (ema_vfi.py:112-113)
             FirstParams fp{frame1, frame2, f.fA, (const char *)packed + P.conv1.w_off + P.conv1.w_bytes,
                            (const float *)((const char *)packed + P.conv1.b_off), P.p_mid, H, W, B, 1};
-            if (P.nb >= 1 && P.blk[0].ring == 2 && !(rf && rf[0] == '0')) {
+            if (P.nb >= 1 && P.blk[0].ring == 2 && !(sw & SW_NO_FIRSTRING)) {
                 // ... and feat_ext_blocks.conv_block_0 + ReLU behind it in the SAME launch (conv_ring_first.inl): feat_ext_conv1's
                 // tensor exists only as an LDS ring.  EMAVFI_CONV_FIRSTRING=0 (read per call): two launches
                 double fl2, by2;
@@ -573,7 +674,7 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
                 launch_pool_partial(f.c3, f.part, B, f.H4 * f.W4, f.p4, f.p4, f.nparts, dtype, s));
     EMAVFI_STEP(rec, "context_linear_fold", 0, (double)B * f.nparts * 4 * mid * 4,
                 launch_ctx_finish(f.part, (const float *)((const char *)packed + P.ctx_off), f.ctx, f.table, B, mid, f.p4,
-                                  f.nparts, f.H4 * f.W4, P.m0.coutpad, P.amp ? 1 : 0, s));
+                                  f.nparts, f.H4 * f.W4, P.m0.coutpad, P.amp ? 1 : 0, guard, s));
     if (!rec.dry && taps && taps[1])
         if (hipMemcpyAsync(taps[1], f.ctx, (size_t)B * mid * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
             return fail(EMAVFI_E_LAUNCH, "tap ctx copy failed");
@@ -583,10 +684,8 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
     EMAVFI_STEP(rec, conv_name(P, P.m0) + " motion_estimation.0(ctx folded)", fl, by,
                 run_conv(P, P.m0, packed, f.fu0, P.fps, H, W, f.fA, P.p_mid, 0, P.p_mid, EPI_RELU, B, s, f.table, nullptr, 0, nullptr, nullptr, nullptr, 0,
                          feat16 ? 1 : 0));
-    // motion_estimation.1 + .2 in one launch (conv_ring.inl, HEAD): .1's rows never leave the LDS.  EMAVFI_CONV_HEAD=0 (read per
-    // forward): two launches
-    const char *hf = getenv("EMAVFI_CONV_HEAD");
-    if (P.m1.ring == 2 && P.m2.mfma16 && P.m2.ck == 64 && P.m2.nf == 1 && P.m2.cout <= 2 && !(hf && hf[0] == '0')) {
+    // motion_estimation.1 + .2 in one launch (conv_ring.inl, HEAD): .1's rows never leave the LDS.  EMAVFI_CONV_HEAD=0: two launches
+    if (P.m1.ring == 2 && P.m2.mfma16 && P.m2.ck == 64 && P.m2.nf == 1 && P.m2.cout <= 2 && !(sw & SW_NO_HEAD)) {
         double fl2, by2;
         conv_work(P, P.m1, B, H, W, e, fl, by);
         conv_work(P, P.m2, B, H, W, 4.0, fl2, by2);
@@ -622,13 +721,7 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
         if (!rec.dry && taps && taps[3])
             EMAVFI_TRY(launch_cl_to_nchw(xF, taps[3], B, C, H, W, P.fpad, mid, EMAVFI_F32, s), "tap warped");
         for (int i = 0; i < P.nb; ++i) {
-            conv_work(P, P.off[i], B, H, W, 4.0, fl, by);
-            EMAVFI_STEP(rec, conv_name(P, P.off[i]) + " offset_conv", fl, by,
-                        run_conv(P, P.off[i], packed, x, P.fps, H, W, f.om, 32, 0, 32, EPI_OM, B, s));
-            EMAVFI_STEP(rec, "deform<f32,ck=80,nf=3> dcn_v2 (fp32 under autocast)", 2.0 * 9.0 * cf * cf * px,
-                        px * (2.0 * cf * 4.0 + 27.0 * 4.0) + 9.0 * cf * cf * 4.0,
-                        run_deform(P, P.dcn32[i], packed, xF, P.fpad, f.om, yF, P.fpad, P.fpad, B, H, W, s, nullptr, nullptr, nullptr, 0,
-                                   EMAVFI_F32));
+            if (const int rc = attention_block_amp(P, i, packed, x, xF, yF, f.om, B, H, W, s, rec); rc != EMAVFI_OK) return rc;
             EMAVFI_STEP(rec, "fusion_round", 0, px * cf * 6.0, launch_convert_cl(yF, y, npx, P.fpad, P.fps, 0, P.fpad, 0, s));
             if (!rec.dry && taps && taps[5 + i])
                 EMAVFI_TRY(launch_cl_to_nchw(yF, taps[5 + i], B, mid + 3, H, W, P.fpad, 0, EMAVFI_F32, s), "tap fused");
@@ -640,17 +733,7 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
         // When the first pack runs as the one-launch LDS kernel, those 16 channels go to a compact buffer of their own
         // (8 channels = 16 bytes per pixel, in the packed-input buffer, free since conv1) and the kernel's window DMA picks
         // them up from there: contiguous 16-byte pixels instead of 6 useful bytes scattered into every 160-byte fusion pixel.
-        auto pack_fuses = [&](int i) {
-            return dtype != EMAVFI_F32 && P.off[i].nchunk == 1 && P.off[i].npass == 1 && P.off[i].stride == 1 &&
-                   deform16_can_fuse_offset_conv(P.dcn[i].ck, P.dcn[i].nf, P.dcn[i].cin_take, P.off[i].ck, P.off[i].nf) &&
-                   (P.dcn[i].pack3 == 0 || P.has_offh);
-        };
-        // bf16 model, consecutive one-launch packs in the deform_pack3 layout: pack i writes f16 bit patterns for pack i + 1
-        auto f16_link = [&](int i) {   // true: the tensor between pack i and pack i + 1 is f16
-            return dtype == EMAVFI_BF16 && pack_f16_chain() && i >= 0 && i + 1 < P.nb && P.dcn[i].pack3 && P.dcn[i + 1].pack3 &&
-                   pack_fuses(i) && pack_fuses(i + 1);
-        };
-        const bool split_tail = P.nb > 0 && pack_fuses(0) && P.fpad - mid == 16;
+        const bool split_tail = P.nb > 0 && pack_fuses(P, 0) && P.fpad - mid == 16;
         EMAVFI_STEP(rec, std::string("warp_fused<") + dtype_name(dtype) + ">", 24.0 * px, px * (8.0 + 4.0 * C + C * e),
                     split_tail ? launch_warp_fused(frame2, f.flow, f.in16, B, C, H, W, 8, 0, feat_dtype, s)
                                : launch_warp_fused(frame2, f.flow, f.fu0, B, C, H, W, P.fps, mid, feat_dtype, s));
@@ -660,26 +743,12 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
 
         // --- multi-attention fusion: num_blocks x ModulatedDeformConvPack, no activation (ema_vfi.py:136-138)
         for (int i = 0; i < P.nb; ++i) {
-            conv_work(P, P.off[i], B, H, W, 4.0, fl, by);
-            const double cf = mid + 3;
-            const bool fused = pack_fuses(i);
-            if (fused) {
-                // one launch for the whole pack (ema_vfi.py:54-60): offset_conv on the staged window, then the DCN;
-                // the input is read once and the offsets / masks never leave the registers
-                EMAVFI_STEP(rec, deform_name(P, P.dcn[i]) + " offset_conv+dcn_v2", fl + 2.0 * 9.0 * cf * cf * px,
-                            px * (2.0 * cf * e) + 9.0 * cf * (cf + 27.0) * e,
-                            run_deform(P, P.dcn[i], packed, x, P.fps, f.om, y, P.fps, P.fps, B, H, W, s, nullptr,
-                                       P.has_offh ? &P.offh[i] : &P.off[i],
-                                       i == 0 && split_tail ? f.in16 : nullptr, 8, -1, (i == 0 ? feat16 : f16_link(i - 1)) ? 1 : 0, f16_link(i) ? 1 : 0));
-            } else {
-                EMAVFI_STEP(rec, conv_name(P, P.off[i]) + " offset_conv", fl, by,
-                            run_conv(P, P.off[i], packed, x, P.fps, H, W, f.om, 32, 0, 32, EPI_OM, B, s));
-                EMAVFI_STEP(rec, deform_name(P, P.dcn[i]) + " dcn_v2", 2.0 * 9.0 * cf * cf * px,
-                            px * (2.0 * cf * e + 27.0 * 4.0) + 9.0 * cf * cf * e,
-                            run_deform(P, P.dcn[i], packed, x, P.fps, f.om, y, P.fps, P.fps, B, H, W, s));
-            }
+            if (const int rc = attention_block(P, i, packed, x, y, f.om, i == 0 && split_tail ? f.in16 : nullptr,
+                                               (i == 0 ? feat16 : pack_f16_link(P, i - 1)) ? 1 : 0, pack_f16_link(P, i) ? 1 : 0, B, H, W, s, rec);
+                rc != EMAVFI_OK)
+                return rc;
             if (!rec.dry && taps && taps[5 + i])
-                EMAVFI_TRY(launch_cl_to_nchw(y, taps[5 + i], B, mid + 3, H, W, P.fps, 0, f16_link(i) ? (int)EMAVFI_F16 : dtype, s), "tap fused");
+                EMAVFI_TRY(launch_cl_to_nchw(y, taps[5 + i], B, mid + 3, H, W, P.fps, 0, pack_f16_link(P, i) ? (int)EMAVFI_F16 : dtype, s), "tap fused");
             void *t = x; x = y; y = t;
         }
     }
@@ -688,10 +757,9 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
     conv_work(P, P.r0, B, H, W, e, fl, by);
     EMAVFI_STEP(rec, conv_name(P, P.r0) + " reconstruction.0", fl, by,
                 run_conv(P, P.r0, packed, x, P.fps, H, W, f.fA, P.p_mid, 0, P.p_mid, EPI_RELU, B, s));
-    // reconstruction.1 + .2 in one launch (conv_ring_tail.inl): .1's rows never leave the LDS.  EMAVFI_CONV_TAILFUSE=0 (read per forward): two
-    const char *tf = getenv("EMAVFI_CONV_TAILFUSE");
+    // reconstruction.1 + .2 in one launch (conv_ring_tail.inl): .1's rows never leave the LDS.  EMAVFI_CONV_TAILFUSE=0: two
     if (P.r1.mfma16 && P.r1.ck == 64 && P.r1.nf == 1 && P.r1.cout == 32 && P.r1.ring == 0 && P.r2.mfma16 && P.r2.ck == 32 && P.r2.nf == 1 && P.r2.cout <= 3 &&
-        !(tf && tf[0] == '0')) {
+        !(sw & SW_NO_TAILFUSE)) {
         double fl2, by2;
         conv_work(P, P.r1, B, H, W, e, fl, by);
         conv_work(P, P.r2, B, H, W, 4.0, fl2, by2);
@@ -711,6 +779,12 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
 }
 
 }  // namespace
+
+unsigned emavfi_switches()
+{
+    init_switches();
+    return g_switches.load(std::memory_order_relaxed);
+}
 
 extern "C" {
 
@@ -758,8 +832,11 @@ int emavfi_pack_weights(int in_channels, int mid_channels, int num_blocks, const
     if (packed_bytes < P.total) return fail(EMAVFI_E_WORKSPACE, "pack_weights: need %zu bytes, got %zu", P.total, packed_bytes);
     if (!aligned16(packed)) return fail(EMAVFI_E_ARG, "pack_weights: packed buffer must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
+    const BlobHeader hdr = expected_header(P, dtype);
     dtype = P.dtype;            // kernel storage type (EMAVFI_AMP16 -> EMAVFI_F16)
     const bool b16 = P.amp;     // autocast casts a convolution's bias to fp16 as well
+    // (the gaps between the 256-byte aligned layers are part of the checksummed payload: zero, not whatever the buffer held)
+    if (hipMemsetAsync(packed, 0, P.total, s) != hipSuccess) return fail(EMAVFI_E_LAUNCH, "pack: blob memset failed");
     EMAVFI_TRY(pack_layer(P.conv1, params, packed, dtype, s, b16), "pack conv1");
     for (int i = 0; i < P.nb; ++i) EMAVFI_TRY(pack_layer(P.blk[i], params, packed, dtype, s, b16), "pack feat block");
     EMAVFI_TRY(pack_layer(P.c0, params, packed, dtype, s, b16), "pack ctx0");
@@ -781,7 +858,55 @@ int emavfi_pack_weights(int in_channels, int mid_channels, int num_blocks, const
                                (const float *)params[P.m0.param], (const float *)params[P.m0.param + 1],
                                (float *)((char *)packed + P.ctx_off), P.mid, P.amp ? 1 : 0, s),
                "pack context");
-    if (hipMemsetAsync((char *)packed + P.zero_off, 0, 256, s) != hipSuccess) return fail(EMAVFI_E_LAUNCH, "pack: zero page memset failed");
+    EMAVFI_TRY(launch_blob_seal(packed, hdr, s), "pack: blob header");
+    return EMAVFI_OK;
+}
+
+int emavfi_layout_tag(void) { return (int)layout_tag_of(process_layout_env()); }
+
+int emavfi_debug_switches(int and_mask, int or_mask)
+{
+    init_switches();
+    unsigned old = g_switches.load(std::memory_order_relaxed), want;
+    do want = (old & (unsigned)and_mask) | (unsigned)or_mask;
+    while (!g_switches.compare_exchange_weak(old, want, std::memory_order_relaxed));
+    return (int)old;
+}
+
+int emavfi_packed_check(int in_channels, int mid_channels, int num_blocks, int dtype, const void *packed, size_t packed_bytes)
+{
+    Plan P;
+    if (!build_plan(P, in_channels, mid_channels, num_blocks, dtype)) return fail(EMAVFI_E_UNSUPPORTED, "%s", P.why);
+    if (!packed) return fail(EMAVFI_E_ARG, "packed_check: null pointer");
+    if (packed_bytes < P.total) return fail(EMAVFI_E_ARG, "packed_check: blob has %zu bytes, this model / dtype needs %zu", packed_bytes, P.total);
+    // device memory is copied to the host (this entry synchronises: it is for the moment a blob arrives - from a file, another rank,
+    // another process -, not for the per-frame path); anything HIP does not know as device memory is read in place
+    std::vector<unsigned char> host;
+    const unsigned char *bytes = (const unsigned char *)packed;
+    hipPointerAttribute_t attr{};
+    const bool on_device = hipPointerGetAttributes(&attr, packed) == hipSuccess && (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged);
+    (void)hipGetLastError();   // (a plain host pointer makes hipPointerGetAttributes fail: not an error of this call)
+    if (on_device) {
+        host.resize(P.total);
+        if (hipMemcpy(host.data(), packed, P.total, hipMemcpyDeviceToHost) != hipSuccess) return fail(EMAVFI_E_LAUNCH, "packed_check: device-to-host copy failed");
+        bytes = host.data();
+    }
+    BlobHeader got;
+    memcpy(&got, bytes, sizeof got);
+    const BlobHeader want = expected_header(P, dtype);
+    if (memcmp(got.magic, want.magic, 8) != 0) return fail(EMAVFI_E_ARG, "packed_check: no EMAVFIPK header (a blob of a library older than 0.4.0, or not a blob)");
+    if (got.version != want.version) return fail(EMAVFI_E_ARG, "packed_check: blob packed by library version %u, this is %u: re-pack", got.version, want.version);
+    if (got.in_ch != want.in_ch || got.mid != want.mid || got.nb != want.nb)
+        return fail(EMAVFI_E_ARG, "packed_check: blob is for EMA_VFI(%u, %u, %u), not (%d, %d, %d)", got.in_ch, got.mid, got.nb, in_channels, mid_channels, num_blocks);
+    if (got.dtype != want.dtype) return fail(EMAVFI_E_ARG, "packed_check: blob was packed for dtype %u, asked for %d", got.dtype, dtype);
+    if (got.layout_tag != want.layout_tag)
+        return fail(EMAVFI_E_ARG, "packed_check: blob was packed under layout switches 0x%x, this process runs 0x%x (EMAVFI_CONV_MFMA16 / _RING / _S2RING / _S2_CK64 / EMAVFI_PACK_F16_CHAIN / EMAVFI_NO_FUSED_OFFSET)",
+                    got.layout_tag, want.layout_tag);
+    if (got.header_bytes != want.header_bytes || got.total_bytes != want.total_bytes)
+        return fail(EMAVFI_E_ARG, "packed_check: blob size fields (%u, %llu) do not match this build's layout (%u, %llu)", got.header_bytes,
+                    (unsigned long long)got.total_bytes, want.header_bytes, (unsigned long long)want.total_bytes);
+    const uint64_t sum = blob_checksum_host(bytes + kBlobHeaderBytes, P.total - kBlobHeaderBytes);
+    if (sum != got.checksum) return fail(EMAVFI_E_ARG, "packed_check: payload checksum %016llx, header says %016llx (corrupted blob)", (unsigned long long)sum, (unsigned long long)got.checksum);
     return EMAVFI_OK;
 }
 
@@ -796,23 +921,23 @@ size_t emavfi_workspace_bytes(int in_channels, int mid_channels, int num_blocks,
     return ws.used;
 }
 
-int emavfi_forward(int in_channels, int mid_channels, int num_blocks, const void *packed, const float *frame1,
+int emavfi_forward(int in_channels, int mid_channels, int num_blocks, const void *packed, size_t packed_bytes, const float *frame1,
                    const float *frame2, float *out, void *workspace, size_t workspace_bytes, int B, int H, int W, int dtype,
                    float *const *taps, void *stream)
 {
     Recorder rec;
-    return forward_impl(in_channels, mid_channels, num_blocks, packed, frame1, frame2, out, workspace, workspace_bytes, B, H, W,
+    return forward_impl(in_channels, mid_channels, num_blocks, packed, packed_bytes, frame1, frame2, out, workspace, workspace_bytes, B, H, W,
                         dtype, taps, stream, rec);
 }
 
-int emavfi_forward_profiled(int in_channels, int mid_channels, int num_blocks, const void *packed, const float *frame1,
+int emavfi_forward_profiled(int in_channels, int mid_channels, int num_blocks, const void *packed, size_t packed_bytes, const float *frame1,
                             const float *frame2, float *out, void *workspace, size_t workspace_bytes, int B, int H, int W,
                             int dtype, void *const *events, int n_events, void *stream)
 {
     if (!events || n_events < 2) return fail(EMAVFI_E_ARG, "forward_profiled: events array required");
     Recorder rec;
     rec.events = events; rec.n_events = n_events;
-    return forward_impl(in_channels, mid_channels, num_blocks, packed, frame1, frame2, out, workspace, workspace_bytes, B, H, W,
+    return forward_impl(in_channels, mid_channels, num_blocks, packed, packed_bytes, frame1, frame2, out, workspace, workspace_bytes, B, H, W,
                         dtype, nullptr, stream, rec);
 }
 
@@ -822,7 +947,7 @@ int emavfi_forward_launches(int in_channels, int mid_channels, int num_blocks, i
     std::vector<LaunchRec> recs;
     Recorder rec;
     rec.recs = &recs; rec.dry = true;
-    const int rc = forward_impl(in_channels, mid_channels, num_blocks, nullptr, nullptr, nullptr, nullptr, nullptr, 0, B, H, W,
+    const int rc = forward_impl(in_channels, mid_channels, num_blocks, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, B, H, W,
                                 dtype, nullptr, nullptr, rec);
     if (rc != EMAVFI_OK) return rc;
     const int n = (int)recs.size();
@@ -998,6 +1123,100 @@ int emavfi_deform_conv2d(const float *x, const float *offset, const float *mask,
     EMAVFI_TRY(launch_om_from_nchw(offset, mask, om, B, H, W, s), "deform offsets");
     EMAVFI_TRY(run_deform(P, L, workspace, xcl, L.ck, om, ycl, ops, ops, B, H, W, s, zpage), "deform_conv2d");
     EMAVFI_TRY(launch_cl_to_nchw(ycl, y, B, O, H, W, ops, 0, dtype, s), "deform layout out");
+    return EMAVFI_OK;
+}
+
+// ---- ModulatedDeformConvPack.forward (ema_vfi.py:53-60) as ONE stage-level entry, routed through attention_block() - i.e. exactly as
+// block i of emavfi_forward runs it: in the 16-bit modes at the reference width the one-launch kernel deform_pack3_kernel<T, FUSE_OFF = true>
+// (offset_conv on the staged window, fast sigmoid, geometry, taps, fix-up), in fp32 conv3x3(EPI_OM) + the fp32 LDS-window DCN, under
+// EMAVFI_AMP16 the fp16 offset_conv + fp32 DCN pair.  The model is EMA_VFI(3, C - 3, 1): the reference only ever builds this pack at
+// mid_channels + 3 channels (ema_vfi.py:97).
+static int mdcn_plan(Plan &P, int C, int dtype, int flags, bool &split, int &in_f16, int &out_f16)
+{
+    if (C < 11 || !build_plan(P, 3, C - 3, 1, dtype))
+        return fail(EMAVFI_E_UNSUPPORTED, "mdcn: C = %d is not mid_channels + 3 of a supported model (%s)", C, C < 11 ? "C < 11" : P.why);
+    if (flags & ~(EMAVFI_MDCN_IN_F16 | EMAVFI_MDCN_OUT_F16 | EMAVFI_MDCN_SPLIT_TAIL)) return fail(EMAVFI_E_ARG, "mdcn: unknown flag bits 0x%x", flags);
+    split = (flags & EMAVFI_MDCN_SPLIT_TAIL) != 0;
+    in_f16 = (flags & EMAVFI_MDCN_IN_F16) ? 1 : 0;
+    out_f16 = (flags & EMAVFI_MDCN_OUT_F16) ? 1 : 0;
+    const bool one_launch = pack_fuses(P, 0) && P.dcn[0].pack3 != 0;
+    if ((in_f16 || out_f16) && !(one_launch && P.dtype == EMAVFI_BF16 && !P.amp))
+        return fail(EMAVFI_E_UNSUPPORTED, "mdcn: the f16 hand-off flags belong to the bf16 one-launch pack (C = 65..67)");
+    if (split && !(pack_fuses(P, 0) && P.fpad - P.mid == 16)) return fail(EMAVFI_E_UNSUPPORTED, "mdcn: the split tail belongs to the one-launch pack");
+    return EMAVFI_OK;
+}
+
+struct MdcnBuffers { void *blob, *xcl, *tail, *ycl; float *om, *xF, *yF; };
+static void mdcn_carve(const Plan &P, Workspace &ws, MdcnBuffers &m, int B, int H, int W, bool split)
+{
+    const size_t px = (size_t)B * H * W;
+    m.blob = ws.take(P.total);
+    m.xcl = ws.take(px * P.fps * P.esize);
+    m.tail = split ? ws.take(px * 8 * P.esize) : nullptr;
+    m.ycl = ws.take(px * P.fps * P.esize);
+    m.om = (float *)ws.take(px * 32 * sizeof(float));
+    m.xF = m.yF = nullptr;
+    if (P.amp) {
+        m.xF = (float *)ws.take(px * P.fpad * sizeof(float));
+        m.yF = (float *)ws.take(px * P.fpad * sizeof(float));
+    }
+}
+
+size_t emavfi_mdcn_workspace_bytes(int B, int C, int H, int W, int dtype, int flags)
+{
+    Plan P;
+    bool split; int in_f16, out_f16;
+    if (mdcn_plan(P, C, dtype, flags, split, in_f16, out_f16) != EMAVFI_OK) return 0;
+    if (B < 1 || H < 1 || W < 1) { fail(EMAVFI_E_ARG, "mdcn: B, H, W must be >= 1"); return 0; }
+    Workspace ws{nullptr, 0, 0};
+    MdcnBuffers m;
+    mdcn_carve(P, ws, m, B, H, W, split);
+    return ws.used;
+}
+
+int emavfi_mdcn(const float *x, const float *offset_weight, const float *offset_bias, const float *dcn_weight, const float *dcn_bias, float *y,
+                int B, int C, int H, int W, int dtype, int flags, void *workspace, size_t workspace_bytes, void *stream)
+{
+    Plan P;
+    bool split; int in_f16, out_f16;
+    if (const int rc = mdcn_plan(P, C, dtype, flags, split, in_f16, out_f16); rc != EMAVFI_OK) return rc;
+    if (!x || !offset_weight || !offset_bias || !dcn_weight || !y || !workspace) return fail(EMAVFI_E_ARG, "mdcn: null pointer");
+    if (B < 1 || H < 1 || W < 1) return fail(EMAVFI_E_ARG, "mdcn: B, H, W must be >= 1");
+    if (!aligned16(x) || !aligned16(y) || !aligned16(workspace)) return fail(EMAVFI_E_ARG, "mdcn: pointers must be 16-byte aligned");
+    if ((size_t)B * H * W >= ((size_t)1 << 31) || (size_t)H * W >= ((size_t)1 << 24)) return fail(EMAVFI_E_ARG, "mdcn: B*H*W must be < 2^31 and H*W < 2^24");
+    if ((size_t)H * W * P.fpad * (P.amp ? sizeof(float) : (size_t)P.esize) >= ((size_t)1 << 32)) return fail(EMAVFI_E_ARG, "mdcn: one sample's activation plane must be < 4 GiB");
+    Workspace ws{(char *)workspace, workspace_bytes, 0};
+    MdcnBuffers m;
+    mdcn_carve(P, ws, m, B, H, W, split);
+    if (ws.used > workspace_bytes) return fail(EMAVFI_E_WORKSPACE, "mdcn: workspace needs %zu bytes, got %zu", ws.used, workspace_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    const int kd = P.dtype, mid = P.mid;   // kernel storage type
+    // pack the two layers exactly as emavfi_pack_weights packs attention_blocks.0 (both offset_conv copies where the plan has them)
+    std::vector<const void *> params((size_t)emavfi_param_count(1), nullptr);
+    params[P.off[0].param] = offset_weight; params[P.off[0].param + 1] = offset_bias;
+    params[P.dcn[0].param] = dcn_weight; params[P.dcn[0].param + 1] = dcn_bias;
+    if (hipMemsetAsync(m.blob, 0, P.total, s) != hipSuccess) return fail(EMAVFI_E_LAUNCH, "mdcn: blob memset failed");
+    EMAVFI_TRY(pack_layer(P.off[0], params.data(), m.blob, kd, s, P.amp), "mdcn pack offset_conv");
+    if (P.has_offh) EMAVFI_TRY(pack_layer(P.offh[0], params.data(), m.blob, kd, s), "mdcn pack offset_conv (f16 fragments)");
+    EMAVFI_TRY(pack_layer(P.dcn[0], params.data(), m.blob, kd, s), "mdcn pack dcn_v2");
+    if (P.amp) EMAVFI_TRY(pack_layer(P.dcn32[0], params.data(), m.blob, EMAVFI_F32, s), "mdcn pack dcn_v2 (fp32 master weights)");
+    Recorder rec;
+    if (P.amp) {
+        EMAVFI_TRY(launch_nchw_to_cl(x, m.xF, B, C, H, W, P.fpad, EMAVFI_F32, s), "mdcn layout in (fp32)");
+        EMAVFI_TRY(launch_nchw_to_cl(x, m.xcl, B, C, H, W, P.fps, EMAVFI_F16, s), "mdcn layout in (fp16 rounding)");
+        if (const int rc = attention_block_amp(P, 0, m.blob, m.xcl, m.xF, m.yF, m.om, B, H, W, s, rec); rc != EMAVFI_OK) return rc;
+        EMAVFI_TRY(launch_cl_to_nchw(m.yF, y, B, C, H, W, P.fpad, 0, EMAVFI_F32, s), "mdcn layout out");
+        return EMAVFI_OK;
+    }
+    const int xdt = in_f16 ? (int)EMAVFI_F16 : kd, ydt = out_f16 ? (int)EMAVFI_F16 : kd;
+    if (split) {   // the first pack's input form: channels 0..mid-1 in the fusion pixels, channels mid.. in the compact 8-channel buffer
+        EMAVFI_TRY(launch_nchw_to_cl_sub(x, m.xcl, B, C, 0, mid, H, W, P.fps, xdt, s), "mdcn layout in");
+        EMAVFI_TRY(launch_nchw_to_cl_sub(x, m.tail, B, C, mid, C - mid, H, W, 8, xdt, s), "mdcn layout in (tail)");
+    } else {
+        EMAVFI_TRY(launch_nchw_to_cl(x, m.xcl, B, C, H, W, P.fps, xdt, s), "mdcn layout in");
+    }
+    if (const int rc = attention_block(P, 0, m.blob, m.xcl, m.ycl, m.om, m.tail, in_f16, out_f16, B, H, W, s, rec); rc != EMAVFI_OK) return rc;
+    EMAVFI_TRY(launch_cl_to_nchw(m.ycl, y, B, C, H, W, P.fps, 0, ydt, s), "mdcn layout out");
     return EMAVFI_OK;
 }
 

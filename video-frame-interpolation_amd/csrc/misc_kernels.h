@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <stddef.h>
+#include <stdint.h>
 
 struct PackDesc {
     int cout, cin_raw, cin_off, cin_take;  // raw OIHW tensor: take input channels [cin_off, cin_off + cin_take)
@@ -19,6 +20,34 @@ struct PackDesc {
                                            // 3 = deform_f32w.inl (fp32 elements, the fp32 DCN on an LDS window)
 };
 
+// The packed weight blob is self-describing: its first 256 bytes hold this header, the payload
+// (what build_plan lays out) follows.  include/emavfi.h documents the same layout for callers that move blobs around.
+struct BlobHeader {
+    char magic[8];                                                // "EMAVFIPK"
+    uint32_t version, header_bytes;                               // EMAVFI_VERSION of the packing library; 256
+    uint32_t in_ch, mid, nb, dtype;                               // the model and the REQUESTED dtype (EMAVFI_AMP16 is a layout of its own)
+    uint32_t layout_tag, reserved;                                // emavfi_layout_tag() of the packing process
+    uint64_t total_bytes;                                         // header + payload
+    uint64_t checksum;                                            // blob_checksum() of the payload
+    uint64_t reserved2;
+};
+static_assert(sizeof(BlobHeader) == 64, "blob header layout");
+constexpr unsigned kBlobHeaderBytes = 256;
+// order-independent position-weighted sum over the payload's 32-bit words: sum (w[i] + 0x9E3779B9) * (2 i + 1) mod 2^64
+inline uint64_t blob_checksum_host(const void *payload, size_t bytes)
+{
+    const uint32_t *w = (const uint32_t *)payload;
+    uint64_t s = 0;
+    for (size_t i = 0; i < bytes / 4; ++i) s += ((uint64_t)w[i] + 0x9E3779B9ull) * (2 * (uint64_t)i + 1);
+    return s;
+}
+// forward-time guard: the context kernel compares the blob's header with what the call expects and turns a mismatch into NaN
+// (ctx and the bias table -> flow -> every later stage): the forward cannot return an error for device-resident bytes without
+// synchronising, but it must not produce plausible garbage either
+struct BlobGuard { const BlobHeader *hdr; BlobHeader expect; };
+// writes the header (pack time) and adds the payload checksum into it
+int launch_blob_seal(void *blob, const BlobHeader &h, hipStream_t s);
+
 int launch_pack_conv(const float *w, const float *bias, void *wp, float *bp, const PackDesc &d, int dtype, hipStream_t s);
 int launch_pack_ctx(const float *lin_w, const float *lin_b, const float *w9, const float *b9, float *dst, int m, int round16,
                     hipStream_t s);
@@ -26,11 +55,13 @@ int launch_pack_ctx(const float *lin_w, const float *lin_b, const float *w9, con
 int launch_convert_cl(const void *src, void *dst, size_t npx, int ps_src, int ps_dst, int c0, int nc, int widen, hipStream_t s);
 int launch_pack_input(const float *f1, const float *f2, void *dst, int B, int C, int H, int W, int cpad, int dtype, hipStream_t s);
 int launch_nchw_to_cl(const float *src, void *dst, int B, int C, int H, int W, int ps, int dtype, hipStream_t s);
+// channels [c0, c0 + ctake) of an NCHW tensor with C channels -> channels 0.. of ps-channel pixels (the rest zero)
+int launch_nchw_to_cl_sub(const float *src, void *dst, int B, int C, int c0, int ctake, int H, int W, int ps, int dtype, hipStream_t s);
 int launch_cl_to_nchw(const void *src, float *dst, int B, int C, int H, int W, int ps, int coff, int dtype, hipStream_t s);
 int launch_om_from_nchw(const float *off, const float *msk, float *om, int B, int H, int W, hipStream_t s);
 int launch_pool_partial(const void *src, float *part, int B, int npix, int cp, int ps, int nparts, int dtype, hipStream_t s);
 int launch_ctx_finish(const float *part, const float *ctxw, float *ctx_out, float *table, int B, int m, int cp, int nparts,
-                      int npix, int coutpad, int round16, hipStream_t s);
+                      int npix, int coutpad, int round16, const BlobGuard &guard, hipStream_t s);
 int launch_warp_nchw(const float *frame2, const float *flow, float *out, int B, int C, int H, int W, hipStream_t s);
 int launch_warp_fused(const float *frame2, const float *flow, void *dst, int B, int C, int H, int W, int ps, int coff, int dtype,
                       hipStream_t s);

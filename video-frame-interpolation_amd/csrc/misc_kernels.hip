@@ -4,6 +4,7 @@
 #include "misc_kernels.h"
 #include <atomic>
 #include <type_traits>
+#include <cstddef>
 
 int device_cu_count()
 {
@@ -275,13 +276,13 @@ int launch_pack_input(const float *f1, const float *f2, void *dst, int B, int C,
 }
 
 template <typename T>
-__global__ void nchw_to_cl_kernel(const float *__restrict__ src, T *__restrict__ dst, int B, int C, int H, int W, int ps)
+__global__ void nchw_to_cl_kernel(const float *__restrict__ src, T *__restrict__ dst, int B, int C, int c0, int ctake, int H, int W, int ps)
 {
     const size_t plane = (size_t)H * W, total = (size_t)B * plane;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t b = i / plane, pix = i - b * plane;
         T *o = dst + i * ps;
-        for (int c = 0; c < ps; ++c) o[c] = (T)(c < C ? src[(b * C + c) * plane + pix] : 0.0f);
+        for (int c = 0; c < ps; ++c) o[c] = (T)(c < ctake ? src[(b * C + c0 + c) * plane + pix] : 0.0f);
     }
 }
 template <typename T>
@@ -294,13 +295,17 @@ __global__ void cl_to_nchw_kernel(const T *__restrict__ src, float *__restrict__
         for (int c = 0; c < C; ++c) dst[(b * C + c) * plane + pix] = (float)o[c];
     }
 }
-int launch_nchw_to_cl(const float *src, void *dst, int B, int C, int H, int W, int ps, int dtype, hipStream_t s)
+int launch_nchw_to_cl_sub(const float *src, void *dst, int B, int C, int c0, int ctake, int H, int W, int ps, int dtype, hipStream_t s)
 {
     const int grid = (int)std::min<size_t>(((size_t)B * H * W + 255) / 256, 65535 * 4);
-    if (dtype == 0) nchw_to_cl_kernel<float><<<grid, 256, 0, s>>>(src, (float *)dst, B, C, H, W, ps);
-    else if (dtype == 2) nchw_to_cl_kernel<half_t><<<grid, 256, 0, s>>>(src, (half_t *)dst, B, C, H, W, ps);
-    else nchw_to_cl_kernel<bf16_t><<<grid, 256, 0, s>>>(src, (bf16_t *)dst, B, C, H, W, ps);
+    if (dtype == 0) nchw_to_cl_kernel<float><<<grid, 256, 0, s>>>(src, (float *)dst, B, C, c0, ctake, H, W, ps);
+    else if (dtype == 2) nchw_to_cl_kernel<half_t><<<grid, 256, 0, s>>>(src, (half_t *)dst, B, C, c0, ctake, H, W, ps);
+    else nchw_to_cl_kernel<bf16_t><<<grid, 256, 0, s>>>(src, (bf16_t *)dst, B, C, c0, ctake, H, W, ps);
     return (int)hipGetLastError();
+}
+int launch_nchw_to_cl(const float *src, void *dst, int B, int C, int H, int W, int ps, int dtype, hipStream_t s)
+{
+    return launch_nchw_to_cl_sub(src, dst, B, C, 0, C, H, W, ps, dtype, s);
 }
 int launch_cl_to_nchw(const void *src, float *dst, int B, int C, int H, int W, int ps, int coff, int dtype, hipStream_t s)
 {
@@ -427,10 +432,18 @@ int launch_pool_partial(const void *src, float *part, int B, int npix, int cp, i
 // cls = ym*4 + xm; bit0 of ym: row y-1 exists, bit1: row y+1 exists (same for xm / columns).
 __global__ __launch_bounds__(256) void ctx_finish_kernel(const float *__restrict__ part, const float *__restrict__ ctxw,
                                                          float *__restrict__ ctx_out, float *__restrict__ table,
-                                                         int m, int cp, int nparts, int npix, int coutpad, int round16)
+                                                         int m, int cp, int nparts, int npix, int coutpad, int round16, const BlobGuard guard)
 {
+    // the blob's header against what this call expects (misc_kernels.h, BlobGuard): a foreign blob poisons ctx and the bias table
+    bool foreign = false;
+    if (guard.hdr) {
+        const uint32_t *got = (const uint32_t *)guard.hdr, *want = (const uint32_t *)&guard.expect;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) foreign |= got[i] != want[i];   // magic, version, header_bytes, in, mid, nb, dtype, layout_tag
+    }
+    const float poison = foreign ? __builtin_nanf("") : 0.0f;
     // round16 (EMAVFI_AMP16): the pooled mean and the Linear output are fp16 tensors under autocast
-    const auto rq = [round16](float v) { return round16 ? (float)(half_t)v : v; };
+    const auto rq = [round16, poison](float v) { return (round16 ? (float)(half_t)v : v) + poison; };
     extern __shared__ float sm[];
     float *mean = sm, *ctx = sm + 4 * m, *tsum = ctx + m;  // tsum [m][9]
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -504,10 +517,45 @@ __global__ __launch_bounds__(256) void ctx_finish_kernel(const float *__restrict
     }
 }
 int launch_ctx_finish(const float *part, const float *ctxw, float *ctx_out, float *table, int B, int m, int cp, int nparts,
-                      int npix, int coutpad, int round16, hipStream_t s)
+                      int npix, int coutpad, int round16, const BlobGuard &guard, hipStream_t s)
 {
     const size_t sh = (size_t)(4 * m + m + 9 * m) * sizeof(float);
-    ctx_finish_kernel<<<B, 256, sh, s>>>(part, ctxw, ctx_out, table, m, cp, nparts, npix, coutpad, round16);
+    ctx_finish_kernel<<<B, 256, sh, s>>>(part, ctxw, ctx_out, table, m, cp, nparts, npix, coutpad, round16, guard);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Blob header (misc_kernels.h, BlobHeader): written behind the pack kernels on the same stream, then the payload's checksum is
+// added into it.  Integer addition commutes, so the atomics leave a deterministic value.
+// ------------------------------------------------------------------------------------------
+__global__ void blob_header_kernel(BlobHeader *dst, const BlobHeader h)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) *dst = h;
+    // (the rest of the 256 header bytes is zeroed by the host-side memset in front of this launch)
+}
+__global__ __launch_bounds__(256) void blob_checksum_kernel(const uint32_t *__restrict__ payload, size_t nwords, unsigned long long *sum)
+{
+    unsigned long long a = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x)
+        a += ((unsigned long long)payload[i] + 0x9E3779B9ull) * (2ull * i + 1ull);
+    __shared__ unsigned long long part[256];
+    part[threadIdx.x] = a;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) part[threadIdx.x] += part[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(sum, part[0]);
+}
+int launch_blob_seal(void *blob, const BlobHeader &h, hipStream_t s)
+{
+    if (hipMemsetAsync(blob, 0, kBlobHeaderBytes, s) != hipSuccess) return (int)hipGetLastError();
+    BlobHeader w = h;
+    w.checksum = 0;
+    blob_header_kernel<<<1, 64, 0, s>>>((BlobHeader *)blob, w);
+    const size_t nwords = (size_t)(h.total_bytes - kBlobHeaderBytes) / 4;
+    blob_checksum_kernel<<<64, 256, 0, s>>>((const uint32_t *)((const char *)blob + kBlobHeaderBytes), nwords,
+                                            (unsigned long long *)((char *)blob + offsetof(BlobHeader, checksum)));
     return (int)hipGetLastError();
 }
 

@@ -13,6 +13,9 @@ from ctypes import c_int, c_size_t, c_void_p, c_char_p, POINTER
 
 F32, BF16, F16, AMP16 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_TANH01 = 0, 1, 2
+MDCN_IN_F16, MDCN_OUT_F16, MDCN_SPLIT_TAIL = 1, 2, 4
+# emavfi_debug_switches bits (include/emavfi.h)
+SW_NO_CONV_FIRST, SW_NO_FIRSTRING, SW_NO_HEAD, SW_NO_TAILFUSE, SW_NO_CONV_LIGHT, SW_NO_PERSISTENT_CONV, SW_NO_RING2 = 1, 2, 4, 8, 16, 32, 64
 DTYPES = {"fp32": F32, "f32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16,
           "fp16": F16, "f16": F16, "float16": F16, "half": F16,
           # the reference's forward under torch.cuda.amp.autocast(), op policy restated (include/emavfi.h, EMAVFI_AMP16)
@@ -30,9 +33,11 @@ _PROTOTYPES = {
     "emavfi_packed_bytes": (c_size_t, [c_int] * 4),
     "emavfi_pack_weights": (c_int, [c_int] * 3 + [POINTER(c_void_p), c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "emavfi_workspace_bytes": (c_size_t, [c_int] * 7),
-    "emavfi_forward": (c_int, [c_int] * 3 + [c_void_p] * 5 + [c_size_t] + [c_int] * 4 + [POINTER(c_void_p), c_void_p]),
+    "emavfi_layout_tag": (c_int, []),
+    "emavfi_packed_check": (c_int, [c_int] * 4 + [c_void_p, c_size_t]),
+    "emavfi_forward": (c_int, [c_int] * 3 + [c_void_p, c_size_t] + [c_void_p] * 4 + [c_size_t] + [c_int] * 4 + [POINTER(c_void_p), c_void_p]),
     "emavfi_forward_launches": (c_int, [c_int] * 7 + [c_char_p, c_size_t, POINTER(ctypes.c_double), POINTER(ctypes.c_double), c_int]),
-    "emavfi_forward_profiled": (c_int, [c_int] * 3 + [c_void_p] * 5 + [c_size_t] + [c_int] * 4 + [POINTER(c_void_p), c_int, c_void_p]),
+    "emavfi_forward_profiled": (c_int, [c_int] * 3 + [c_void_p, c_size_t] + [c_void_p] * 4 + [c_size_t] + [c_int] * 4 + [POINTER(c_void_p), c_int, c_void_p]),
     "emavfi_warp": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
     "emavfi_preprocess_u8": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [POINTER(ctypes.c_float), POINTER(ctypes.c_float), c_void_p]),
     "emavfi_postprocess_u8": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [POINTER(ctypes.c_double), POINTER(ctypes.c_double), c_int, c_void_p]),
@@ -40,6 +45,9 @@ _PROTOTYPES = {
     "emavfi_conv3x3": (c_int, [c_void_p] * 4 + [c_int] * 8 + [c_void_p, c_size_t, c_void_p]),
     "emavfi_deform_conv2d_workspace_bytes": (c_size_t, [c_int] * 6),
     "emavfi_deform_conv2d": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
+    "emavfi_mdcn_workspace_bytes": (c_size_t, [c_int] * 6),
+    "emavfi_mdcn": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
+    "emavfi_debug_switches": (c_int, [c_int, c_int]),
 }
 SYMBOLS = tuple(_PROTOTYPES)
 
@@ -82,9 +90,23 @@ def fingerprint() -> str:
 
 
 def layout_switches() -> str:
-    """Diagnostic environment switches the PACKED LAYOUT depends on (csrc/emavfi_api.hip, conv_geometry): a blob packed under one
-    setting must not be run under another, so the setting is part of the in-memory and on-disk cache keys of the packed weights."""
-    return "|".join(f"{k}={os.environ.get(k, '')}" for k in ("EMAVFI_CONV_MFMA16", "EMAVFI_CONV_S2_CK64", "EMAVFI_CONV_RING", "EMAVFI_CONV_S2RING", "EMAVFI_PACK_F16_CHAIN", "EMAVFI_NO_FUSED_OFFSET"))
+    """The process-wide switches the PACKED LAYOUT depends on, as the LIBRARY latched them at first use (emavfi_layout_tag(),
+    include/emavfi.h) - not os.environ, which may have changed since (two sources of truth).  Part of the in-memory and
+    on-disk cache keys of the packed weights; the blob header carries the same tag and emavfi_packed_check compares it."""
+    return f"layout_tag={load().emavfi_layout_tag()}"
+
+
+def packed_check(in_channels, mid_channels, num_blocks, dt, blob) -> None:
+    """emavfi_packed_check on a uint8 tensor (device or host): header fields and payload checksum; RuntimeError names the mismatch.
+    Synchronises - call when a blob ARRIVES (cache file, broadcast, load_packed_weights), never per frame."""
+    if not blob.is_contiguous():
+        raise ValueError("packed_check: contiguous uint8 tensor expected")
+    check(load().emavfi_packed_check(in_channels, mid_channels, num_blocks, dt, blob.data_ptr(), blob.numel()), "emavfi_packed_check")
+
+
+def debug_switches(and_mask=-1, or_mask=0) -> int:
+    """Test hook (include/emavfi.h, emavfi_debug_switches): returns the previous switch word."""
+    return load().emavfi_debug_switches(and_mask, or_mask)
 
 
 def last_error() -> str:
@@ -230,6 +252,29 @@ def deform_conv2d(x, offset, mask, weight, bias, dtype="fp32"):
     with torch.cuda.device(x.device):
         check(L.emavfi_deform_conv2d(x.data_ptr(), off.data_ptr(), msk.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(),
                                      B, C, O, H, W, dt, ws.data_ptr(), ws.numel(), _stream()), "emavfi_deform_conv2d")
+    return y
+
+
+def mdcn(x, offset_weight, offset_bias, dcn_weight, dcn_bias, dtype="fp32", flags=0):
+    """ModulatedDeformConvPack.forward (reference ema_vfi.py:53-60) as ONE stage, routed as a block of the forward is
+    (include/emavfi.h, emavfi_mdcn): the one-launch kernel in the 16-bit modes at the reference width."""
+    import torch
+    _require_cuda(x, offset_weight, offset_bias, dcn_weight, dcn_bias)
+    dt = dtype_code(dtype)
+    x, ow, ob, dw = _f32c(x), _f32c(offset_weight), _f32c(offset_bias), _f32c(dcn_weight)
+    db = _f32c(dcn_bias) if dcn_bias is not None else None
+    B, C, H, W = x.shape
+    if tuple(ow.shape) != (27, C, 3, 3) or tuple(ob.shape) != (27,) or tuple(dw.shape) != (C, C, 3, 3) or (db is not None and tuple(db.shape) != (C,)):
+        raise ValueError(f"mdcn: offset_conv [27,{C},3,3] + [27] and dcn_v2 [{C},{C},3,3] + [{C}] expected")
+    L = load()
+    n = L.emavfi_mdcn_workspace_bytes(B, C, H, W, dt, flags)
+    if n == 0:
+        raise RuntimeError(f"emavfi_mdcn: {last_error()}")
+    ws = workspace(n, x.device)
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        check(L.emavfi_mdcn(x.data_ptr(), ow.data_ptr(), ob.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None, y.data_ptr(),
+                            B, C, H, W, dt, flags, ws.data_ptr(), ws.numel(), _stream()), "emavfi_mdcn")
     return y
 
 

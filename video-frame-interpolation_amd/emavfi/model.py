@@ -9,8 +9,11 @@ checkpoints load with ``strict=True``) and call signatures as the reference:
   ``forward(frame1, frame2)`` and ``warp(frame2, feature, flow)``  (ema_vfi.py:63-171)
 
 The modules below only HOLD parameters (``nn.Conv2d`` gives the reference's
-initialisation and state_dict keys for free); every operator on the forward
-path executes in ``libemavfi.so``.  Inference only.  There is no CPU or
+initialisation and state_dict keys for free); every operator of the model's
+arithmetic executes in ``libemavfi.so``.  What torch still does around a call:
+contiguity / dtype normalisation of the inputs (no-ops for the fp32 contiguous
+frames the reference passes) and, under ``amp16`` only, the final cast of the
+fp32-stored, fp16-valued frame to an fp16 tensor.  Inference only.  There is no CPU or
 PyTorch fallback: CPU tensors or a missing library raise ``RuntimeError``.
 """
 from __future__ import annotations
@@ -83,11 +86,11 @@ class ModulatedDeformConvPack(nn.Module):
         self.dcn_v2 = DeformConv2d(self.in_channels, self.out_channels, kernel_size=kernel_size, stride=stride,
                                    padding=padding, dilation=dilation, bias=bias)
 
-    def forward(self, x, dtype="fp32"):
-        raw = _lib.conv3x3(x, self.offset_conv.weight, self.offset_conv.bias, dtype=dtype)
-        offset_static, mask, offset_dynamic = torch.chunk(raw, 3, dim=1)
-        offset = torch.cat((offset_static, offset_dynamic), dim=1)
-        return self.dcn_v2(x, offset, torch.sigmoid(mask), dtype=dtype)
+    def forward(self, x, dtype="fp32", flags=0):
+        """ema_vfi.py:53-60 through the stage-level entry emavfi_mdcn: offset_conv, the chunk / cat / sigmoid routing and dcn_v2 run
+        exactly as one attention block of EMA_VFI.forward does (16-bit modes at 67 channels: ONE kernel launch)."""
+        return _lib.mdcn(x, self.offset_conv.weight, self.offset_conv.bias, self.dcn_v2.weight, self.dcn_v2.bias, dtype=dtype,
+                         flags=flags).to(x.dtype)
 
 
 class EMA_VFI(nn.Module):
@@ -198,6 +201,11 @@ class EMA_VFI(nn.Module):
         # process start, inference.py:69): state_dict bytes + dtype + model shape + the library build
         path = self._cache_path(params, dt, nbytes)
         blob = self._cache_read(path, nbytes, device)
+        if blob is not None:
+            try:   # the header says what the file IS (version, model, dtype, layout tag, checksum): a foreign file is re-packed, never run
+                _lib.packed_check(self.in_channels, self.mid_channels, self.num_blocks, dt, blob)
+            except RuntimeError:
+                blob = None
         if blob is None:
             blob = torch.empty(nbytes, dtype=torch.uint8, device=device)
             arr = (c_void_p * n)(*[p.data_ptr() for p in params])
@@ -267,6 +275,8 @@ class EMA_VFI(nn.Module):
         nbytes = _lib.load().emavfi_packed_bytes(self.in_channels, self.mid_channels, self.num_blocks, dt)
         if blob.dtype != torch.uint8 or blob.numel() != nbytes:
             raise ValueError(f"load_packed_weights: a uint8 blob of {nbytes} bytes is expected for this model / dtype")
+        # the blob's header must say this model, this dtype, this library version and this process's layout switches
+        _lib.packed_check(self.in_channels, self.mid_channels, self.num_blocks, dt, blob)
         if params_are_source:
             self._packed[dt] = (self._weights_key(blob.device), blob)
             return
@@ -322,12 +332,12 @@ class EMA_VFI(nn.Module):
             taps_arg = cast((c_void_p * len(ptrs))(*ptrs), POINTER(c_void_p))
         with torch.cuda.device(dev):
             if _events is not None:  # bench.py: (ctypes array of hipEvent_t, count) bracketing every launch
-                _lib.check(L.emavfi_forward_profiled(C, self.mid_channels, self.num_blocks, packed.data_ptr(), f1.data_ptr(),
+                _lib.check(L.emavfi_forward_profiled(C, self.mid_channels, self.num_blocks, packed.data_ptr(), packed.numel(), f1.data_ptr(),
                                                      f2.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, dt,
                                                      cast(_events[0], POINTER(c_void_p)), _events[1], _lib._stream()),
                            "emavfi_forward_profiled")
             else:
-                _lib.check(L.emavfi_forward(C, self.mid_channels, self.num_blocks, packed.data_ptr(), f1.data_ptr(),
+                _lib.check(L.emavfi_forward(C, self.mid_channels, self.num_blocks, packed.data_ptr(), packed.numel(), f1.data_ptr(),
                                             f2.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, dt, taps_arg,
                                             _lib._stream()), "emavfi_forward")
         # under autocast the reference's reconstruction tail is fp16, so its frame is an fp16 tensor (the values computed
