@@ -30,6 +30,67 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "video-frame-interpolation_amd"))
 sys.path.insert(0, ROOT)
 
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="frame pairs per GPU (configs[2]: 8)")
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"],
+                    help="bf16 = BASELINE configs[2]; fp16 = the autocast arithmetic of the reference; fp32 = parity mode")
+    ap.add_argument("--cpu-reps", type=int, default=3, help="timed CPU-oracle forwards of one full frame (0 = skip the CPU baseline)")
+    ap.add_argument("--cpu-rows", type=int, default=None, help="deprecated: 0 = skip the CPU baseline")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (fp32 / fp16 / 256x256 / warp / CPU)")
+    ap.add_argument("--no-events", action="store_true", help="time the plain entry point (no per-launch events)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="no GPU: exercise launch, rendezvous, the weight-blob broadcast, barrier / MAX timing and the JSON relay with a "
+                         "stand-in step (CPU test of the N > 1 plumbing; `value` is null)")
+    args = ap.parse_args()
+    if args.cpu_rows == 0:
+        args.cpu_reps = 0
+    return args
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks ourselves.  The parent touches neither
+    torch nor the GPU (a process that has initialised HIP must not exec, and a fresh child per rank is what torchrun gives anyway):
+    it runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>` as a
+    CHILD process, relays rank 0's single JSON line on stdout and exits with the child's code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)   # stderr passes through
+    line = None
+    for out in proc.stdout:
+        out = out.rstrip("\n")
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        elif out:
+            print(out, file=sys.stderr, flush=True)   # anything else a rank printed is diagnostics, not the result
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        print("bench.py: the ranks exited without a result line", file=sys.stderr)
+        rc = 1
+    sys.exit(rc)
+
+
+ARGS = None
+if __name__ == "__main__":
+    ARGS = parse_args()
+    if ARGS.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(ARGS)
+
 import torch  # noqa: E402
 
 PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}   # dense MFMA TFLOP/s (MI355X_MICROARCH.md, chip-level table)
@@ -97,9 +158,10 @@ def kernel_source_sha():
 
 
 def cpu_baseline(sd, height, width, reps, dev=None):
-    """The oracle (CPU restatement, kind "port") per SURVEY.md section 8(d): fp32, B = 1, one warm-up + `reps` timed
-    forwards, median - at 256x256 and on one full frame of the benchmarked size.  The full frame then goes through the HIP
-    path in all three arithmetic modes for the accuracy fields."""
+    """The oracle (CPU restatement, kind "port") per SURVEY.md section 8(d): fp32, ONE full-size warm-up + `reps` (default 3) timed
+    forwards, median - one 1280x720 pair (B = 1: the unit `value` counts), one 256x256 pair, and BASELINE configs[1]'s batch of 16
+    256x256 pairs.  About 70 s of CPU work on the GPU box's 16-core share; the whole default bench stays within a few minutes.
+    The full frame then goes through the HIP path in all three arithmetic modes for the accuracy fields."""
     from emavfi import synth
     from oracle import emavfi_oracle as oracle
     # the GPU box exposes every host core but this job's share is 16 (gpurun process guard)
@@ -107,23 +169,21 @@ def cpu_baseline(sd, height, width, reps, dev=None):
     torch.set_num_threads(threads)
     cpu_sd = {k: v.float().cpu() for k, v in sd.items()}
 
-    def timed(f1, f2, n, budget_s):
-        oracle.forward(cpu_sd, f1[:, :, :min(64, f1.shape[2])], f2[:, :, :min(64, f2.shape[2])])  # warm-up (pools, allocator)
-        ts, ref = [], None
+    def timed(f1, f2, n):
+        ref = oracle.forward(cpu_sd, f1, f2)  # full-size warm-up (thread pool, allocator, page faults of every intermediate)
+        ts = []
         for _ in range(n):
             t0 = time.perf_counter()
             ref = oracle.forward(cpu_sd, f1, f2)
             ts.append(time.perf_counter() - t0)
-            if sum(ts) > budget_s:   # keep the default bench run within a few minutes on a slow host
-                break
         return ts, ref
 
     s1, s2 = synth.synthetic_frames(7, 1, 256, 256, "natural")
-    t256, _ = timed(s1, s2, reps, 10.0)
+    t256, _ = timed(s1, s2, reps)
+    b1, b2 = synth.synthetic_frames(8, 16, 256, 256, "natural")
+    t256b, _ = timed(b1, b2, reps)
     f1, f2 = synth.synthetic_frames(7, 1, height, width, "natural")
-    # one timed full frame when it takes more than 10 s (a 720p frame is ~17 s on the GPU box's 16 cores): the default run
-    # has the 1080p and streaming legs to pay for and must stay under ~90 s; three at 256x256 above
-    tfull, ref = timed(f1, f2, reps, 10.0)
+    tfull, ref = timed(f1, f2, reps)
     accuracy = None
     if dev is not None:
         import math
@@ -139,12 +199,15 @@ def cpu_baseline(sd, height, width, reps, dev=None):
                               "psnr_db": round(99.0 if mse == 0 else 10.0 * math.log10(1.0 / mse), 2)}
     cpu_baseline.accuracy = accuracy
     med = statistics.median(tfull)
+    m256b = statistics.median(t256b)
     return {"value": round(1.0 / med, 5), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"1 pair {width}x{height} (one full frame of the benchmarked size), fp32, oracle.forward: 1 warm-up + "
+            "sample": f"1 pair {width}x{height} (one full frame of the benchmarked size), fp32, oracle.forward: 1 full-size warm-up + "
                       f"{len(tfull)} timed, median {med:.2f} s (all: {', '.join(f'{t:.2f}' for t in tfull)}); "
                       "restated deform conv, not torchvision's C++ kernel",
             "also_256x256": {"value": round(1.0 / statistics.median(t256), 3), "unit": "frames/s",
                              "median_s": round(statistics.median(t256), 4), "timed": len(t256)},
+            "also_config1_b16_256x256": {"value": round(16.0 / m256b, 3), "unit": "frames/s", "median_s": round(m256b, 3), "timed": len(t256b),
+                                         "sample": "BASELINE configs[1]: one batch of 16 pairs 256x256"},
             "gflops": round(FLOP_PER_PX * height * width / med / 1e9, 1),
             "cpu_model": cpu_model_name(), "torch": torch.__version__}
 
@@ -286,29 +349,120 @@ def board_under_load(model, a1, a2, seconds=2.0):
     return out
 
 
+def per_kernel_table(hip, ev, launches, steps, dtype):
+    """Aggregate the HIP events recorded around every launch of `steps` forwards: per-kernel table (sorted by device time) and the
+    roofline object of the dominant kernel - `achieved` = ALGORITHMIC flops (bytes) per launch / average launch duration."""
+    nl = len(launches)
+    agg = {}
+    for i in range(steps):
+        for j, (name, fl, by) in enumerate(launches):
+            k = name.split(" ")[0]
+            a = agg.setdefault(k, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0})
+            base = 2 * (nl * i + j)
+            a["ms"] += hip.elapsed_ms(ev[base], ev[base + 1])
+            a["flops"] += fl
+            a["bytes"] += by
+            a["n"] += 1
+    total_ms = sum(a["ms"] for a in agg.values())
+    table = []
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+        table.append({"kernel": k, "launches_per_step": a["n"] // steps, "avg_us": round(a["ms"] / a["n"] * 1e3, 1),
+                      "share": round(a["ms"] / total_ms, 4),
+                      "tflops": round(a["flops"] / (a["ms"] * 1e-3) / 1e12, 2) if a["flops"] else 0.0,
+                      "gbs": round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1)})
+    dom = table[0]
+    a = agg[dom["kernel"]]
+    is_mfma = a["flops"] / max(a["bytes"], 1.0) > PEAK[dtype] * 1e12 / (PEAK_HBM_GBS * 1e9)
+    if is_mfma:
+        roof = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"], "peak": PEAK[dtype], "unit": "TFLOP/s",
+                "frac": round(dom["tflops"] / PEAK[dtype], 4), "avg_launch_us": dom["avg_us"], "share_of_device_time": dom["share"],
+                "algorithmic_flops_per_launch": a["flops"] / a["n"]}
+    else:
+        roof = {"kernel": dom["kernel"], "bound": "hbm", "achieved": dom["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(dom["gbs"] / PEAK_HBM_GBS, 4), "avg_launch_us": dom["avg_us"], "share_of_device_time": dom["share"],
+                "algorithmic_bytes_per_launch": a["bytes"] / a["n"]}
+    return table, roof, agg, total_ms
+
+
+def stored_traffic(kernel, fname="traffic.json"):
+    """PMC HBM bytes per launch of `kernel` from profiles/<fname> (measured with tools/profile_round.sh on the builder's box,
+    stamped with the sha of the kernel sources it was measured on: refused when the sources have changed since)."""
+    tpath = os.path.join(ROOT, "profiles", fname)
+    if not os.path.exists(tpath):
+        return None, f"profiles/{fname} missing"
+    tj = json.load(open(tpath))
+    if tj.get("_kernel_source_sha") != kernel_source_sha():
+        return None, f"profiles/{fname} was measured on other kernel sources: refused as stale"
+    return tj.get(kernel), f"PMC FETCH_SIZE x2 + WRITE_SIZE, {tj.get('_measured', '')}"
+
+
+def profiled_mode(hip, sd, dev, dtype, B, H, W, steps):
+    """One arithmetic mode timed with per-launch events (the side legs: exact fp32 at the benchmarked size and at BASELINE
+    configs[1]): frames/s, the per-kernel table and the roofline object of ITS dominant kernel."""
+    from emavfi import EMA_VFI, lib, synth
+    alt = EMA_VFI(compute_dtype=dtype).to(dev).eval()
+    alt.load_state_dict(sd, strict=True)
+    a1, a2 = synth.fast_frames(300, B, H, W, device=dev)
+    launches = lib.forward_launches(3, 64, 3, B, H, W, dtype)
+    nl = len(launches)
+    ev = hip.events(2 * nl * steps)
+    with torch.no_grad():
+        for _ in range(2):
+            alt(a1, a2)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(steps):
+            off = ctypes.cast(ctypes.addressof(ev) + 2 * nl * i * ctypes.sizeof(ctypes.c_void_p), ctypes.c_void_p)
+            alt(a1, a2, _events=(off, 2 * nl))
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t1
+    table, roof, _, total_ms = per_kernel_table(hip, ev, launches, steps, dtype)
+    hip.destroy(ev)
+    roof["traffic"], roof["traffic_source"] = stored_traffic(roof["kernel"], f"traffic_{dtype}_{B}x{H}x{W}.json")
+    return {"value": round(B * steps / el, 2), "unit": "frames/s", "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,
+            "pairs_per_step": B, "height": H, "width": W, "dtype": dtype, "roofline": roof, "kernels": table[:6],
+            "device_ms_per_step_sum_of_kernels": round(total_ms / steps, 3)}
+
+
+def rehearse(args, rank, world):
+    """--rehearse: the N > 1 plumbing without a GPU (CPU test, gloo): rendezvous, broadcast of a blob-sized buffer from rank 0,
+    barrier + MAX-over-ranks timing around K stand-in steps, the rank census, ONE JSON line on rank 0.  `value` is null."""
+    from emavfi import dist as vdist
+    backend = os.environ.get("EMAVFI_DIST_BACKEND", "gloo")
+    vdist.init(backend, None)
+    g = torch.Generator().manual_seed(1)
+    blob = torch.randint(0, 256, (3 << 20,), dtype=torch.uint8, generator=g) if rank == 0 else torch.zeros(3 << 20, dtype=torch.uint8)
+    vdist.broadcast_packed(blob, 0)
+    want = torch.randint(0, 256, (3 << 20,), dtype=torch.uint8, generator=torch.Generator().manual_seed(1))
+    assert torch.equal(blob, want), "broadcast did not deliver rank 0's bytes"
+    vdist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))
+    vdist.barrier()
+    mine = time.perf_counter() - t0
+    elapsed = vdist.max_over_ranks(mine, None)
+    seen = vdist.all_gather_floats([float(rank), mine / args.steps * 1e3], None)
+    if rank == 0:
+        print(json.dumps({"metric": "interpolated_frames_per_sec_720p_2x", "value": None, "unit": "frames/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "rehearsal": True, "backend": backend,
+                          "ranks_seen": sorted(int(r[0]) for r in seen), "ms_per_step_per_rank": [round(r[1], 3) for r in seen]}), flush=True)
+    if world > 1:
+        vdist.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="frame pairs per GPU (configs[2]: 8)")
-    ap.add_argument("--height", type=int, default=720)
-    ap.add_argument("--width", type=int, default=1280)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"],
-                    help="bf16 = BASELINE configs[2]; fp16 = the autocast arithmetic of the reference; fp32 = parity mode")
-    ap.add_argument("--cpu-reps", type=int, default=3, help="timed CPU-oracle forwards of one full frame (0 = skip the CPU baseline)")
-    ap.add_argument("--cpu-rows", type=int, default=None, help="deprecated: 0 = skip the CPU baseline")
-    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (fp32 / fp16 / 256x256 / warp / CPU)")
-    ap.add_argument("--no-events", action="store_true", help="time the plain entry point (no per-launch events)")
-    args = ap.parse_args()
-    if args.cpu_rows == 0:
-        args.cpu_reps = 0
+    args = ARGS if ARGS is not None else parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.rehearse:
+        return rehearse(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
     # one process per GPU; the modulo only matters for rehearsals with more ranks than GPUs
@@ -322,12 +476,12 @@ def main():
     vdist.init(backend, dev)
 
     B, H, W = args.batch, args.height, args.width
-    dt = lib.dtype_code(args.dtype)
     model = EMA_VFI(compute_dtype=args.dtype).to(dev).eval()
     sd = synth.synthetic_state_dict(seed=0)
     if rank == 0:
         model.load_state_dict(sd, strict=True)
-    # the path's one collective: RCCL broadcast of the packed weights over xGMI (no-op at N=1)
+    # the path's one collective: RCCL broadcast of the packed weights over xGMI (no-op at N=1); the receiving ranks verify the
+    # blob's header and checksum (emavfi_packed_check) when they install it
     vdist.share_model_weights(model, args.dtype, dev)
 
     f1, f2 = synth.fast_frames(100 + rank, B, H, W, device=dev)
@@ -355,10 +509,14 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(i)
+    torch.cuda.synchronize()
+    mine = time.perf_counter() - t0       # this rank's own K steps (reported per rank)
     fence()
     elapsed = time.perf_counter() - t0
     elapsed = vdist.max_over_ranks(elapsed, dev)
     assert torch.isfinite(out).all()
+    # the rank census over the benchmark's own backend (RCCL when it is "nccl"): which ranks took part, and each one's step time
+    census = vdist.all_gather_floats([float(rank), mine / args.steps * 1e3, float(local_dev)], dev)
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -373,60 +531,35 @@ def main():
                                       "EMA_VFI(3,64,3), synthetic non-degenerate weights",
                           "pairs_per_gpu": B, "height": H, "width": W, "parallelism": f"replica-dp{world}",
                           "collectives": f"one {backend} broadcast of packed weights before timing" if world > 1 else "none"},
+               "backend": backend if world > 1 else None,
+               "ranks_seen": sorted(int(r[0]) for r in census),
+               "ms_per_step_per_rank": [round(r[1], 3) for r in sorted(census)],
+               "device_per_rank": [int(r[2]) for r in sorted(census)],
                "frames_per_sec_per_gpu": round(value / world, 2),
                "forward_passes_per_sec": round(value, 2),
                "whole_forward": {"tflops_algorithmic": round(FLOP_PER_PX * B * H * W / (ms_step * 1e-3) / 1e12, 2),
                                  "frac_of_mfma_peak": round(FLOP_PER_PX * B * H * W / (ms_step * 1e-3) / 1e12 / PEAK[args.dtype], 4),
                                  "flop_per_px": FLOP_PER_PX}}
         if use_events:
-            agg = {}
-            for i in range(args.steps):
-                for j, (name, fl, by) in enumerate(launches):
-                    k = name.split(" ")[0]
-                    a = agg.setdefault(k, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0})
-                    base = 2 * (nl * i + j)
-                    a["ms"] += hip.elapsed_ms(ev[base], ev[base + 1])
-                    a["flops"] += fl
-                    a["bytes"] += by
-                    a["n"] += 1
-            total_ms = sum(a["ms"] for a in agg.values())
-            table = []
-            for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
-                table.append({"kernel": k, "launches_per_step": a["n"] // args.steps, "avg_us": round(a["ms"] / a["n"] * 1e3, 1),
-                              "share": round(a["ms"] / total_ms, 4),
-                              "tflops": round(a["flops"] / (a["ms"] * 1e-3) / 1e12, 2) if a["flops"] else 0.0,
-                              "gbs": round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1)})
-            dom = table[0]
-            a = agg[dom["kernel"]]
-            is_mfma = a["flops"] / max(a["bytes"], 1.0) > PEAK[args.dtype] * 1e12 / (PEAK_HBM_GBS * 1e9)
-            traffic, traffic_note = None, "profiles/traffic.json missing"
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
-                tj = json.load(open(tpath))
-                if tj.get("_kernel_source_sha") == kernel_source_sha():
-                    traffic, traffic_note = tj.get(dom["kernel"]), f"PMC FETCH_SIZE x2 + WRITE_SIZE, {tj.get('_measured', '')}"
-                else:
-                    traffic_note = "profiles/traffic.json was measured on other kernel sources: refused as stale"
-            if is_mfma:
-                res["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"], "peak": PEAK[args.dtype],
-                                   "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK[args.dtype], 4), "traffic": traffic,
-                                   "traffic_source": traffic_note, "avg_launch_us": dom["avg_us"], "share_of_device_time": dom["share"],
-                                   "algorithmic_flops_per_launch": a["flops"] / a["n"]}
-            else:
-                res["roofline"] = {"kernel": dom["kernel"], "bound": "hbm", "achieved": dom["gbs"], "peak": PEAK_HBM_GBS,
-                                   "unit": "GB/s", "frac": round(dom["gbs"] / PEAK_HBM_GBS, 4), "traffic": traffic,
-                                   "traffic_source": traffic_note, "avg_launch_us": dom["avg_us"], "share_of_device_time": dom["share"],
-                                   "algorithmic_bytes_per_launch": a["bytes"] / a["n"]}
+            table, roof, agg, total_ms = per_kernel_table(hip, ev, launches, args.steps, args.dtype)
+            traffic, traffic_note = stored_traffic(roof["kernel"])
+            res["roofline"] = dict(roof, traffic=traffic, traffic_source=traffic_note)
             res["kernels"] = table
             res["device_ms_per_step_sum_of_kernels"] = round(total_ms / args.steps, 3)
-            # the warp kernel the forward actually runs (row W inside the timed region): 8 B flow + 12 B frame2 read, C
-            # channels of the storage type written per pixel
+            # the warp kernel the forward actually runs (row W inside the timed region).  Two accountings, both printed: the
+            # ALGORITHMIC bytes (8 B flow + 12 B frame2 read + C channels of the storage type written = 26 B/px in the 16-bit modes)
+            # and the bytes the layout forces it to move (the three channels leave as one 16-byte slot of the first pack's window
+            # DMA: 8 + 12 + 16 = 36 B/px)
             wk = [t for t in table if t["kernel"].startswith("warp_fused")]
             if wk:
                 wa = agg[wk[0]["kernel"]]
+                px = B * H * W
+                moved = (36.0 if args.dtype != "fp32" else 32.0) * px
                 res["roofline_warp_in_forward"] = {"kernel": wk[0]["kernel"], "bound": "hbm", "achieved": wk[0]["gbs"], "peak": PEAK_HBM_GBS,
                                                    "unit": "GB/s", "frac": round(wk[0]["gbs"] / PEAK_HBM_GBS, 4), "avg_launch_us": wk[0]["avg_us"],
-                                                   "algorithmic_bytes_per_launch": wa["bytes"] / wa["n"]}
+                                                   "algorithmic_bytes_per_launch": wa["bytes"] / wa["n"],
+                                                   "layout_bytes_per_launch": moved,
+                                                   "frac_on_layout_bytes": round(moved / (wk[0]["avg_us"] * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)}
         if world == 1 and not args.no_extras:
             def timed_alt(dtype, b, h, w, steps):
                 alt = EMA_VFI(compute_dtype=dtype).to(dev).eval()
@@ -452,10 +585,13 @@ def main():
             # what the reference's torch.cuda.amp.autocast() computes on a GPU (inference.py:159), op policy restated:
             # fp16 convolutions, fp32 grid_sample and fp32 deform_conv2d on an fp32 fusion tensor (EMAVFI_AMP16)
             res["also_amp16_autocast_policy"] = timed_alt("amp16", B, H, W, max(3, args.steps // 2))
-            if args.dtype != "fp32":  # the parity mode (exact fp32 MFMA; the only mode north_star's 1e-3 bound applies to)
-                res["also_fp32_exact"] = timed_alt("fp32", B, H, W, max(3, args.steps // 4))
-            # BASELINE.json configs[1]: batch 16 of 256x256 pairs
-            res["config1_256"] = {"fp32": timed_alt("fp32", 16, 256, 256, args.steps), "bf16": timed_alt("bf16", 16, 256, 256, 4 * args.steps)}
+            if args.dtype != "fp32":  # the parity mode (exact fp32 MFMA; the only mode north_star's 1e-3 bound applies to): with ITS roofline
+                res["also_fp32_exact"] = profiled_mode(hip, sd, dev, "fp32", B, H, W, max(3, args.steps // 4))
+                res["roofline_fp32"] = dict(res["also_fp32_exact"]["roofline"], workload=f"B={B} x {W}x{H}, exact fp32")
+            # BASELINE.json configs[1]: batch 16 of 256x256 pairs, fp32 (with its roofline) and bf16
+            c1 = profiled_mode(hip, sd, dev, "fp32", 16, 256, 256, args.steps)
+            res["config1_256"] = {"fp32": c1, "bf16": timed_alt("bf16", 16, 256, 256, 4 * args.steps)}
+            res["roofline_fp32_config1"] = dict(c1["roofline"], workload="BASELINE configs[1]: B=16 x 256x256, exact fp32")
             if args.dtype == "bf16" and (H, W) == (720, 1280):   # the harness legs (PCIe-inclusive; BASELINE configs[4] size)
                 res.update(stream_legs(sd, dev, B, H, W))
             if args.cpu_reps > 0:

@@ -77,7 +77,8 @@ def test_bench_json_contract():
     assert "traffic_source" in rf     # PMC bytes are refused when profiles/traffic.json was measured on other kernel sources
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb and cb["unit"] == "frames/s"
-    assert cb["cpu_model"] and cb["also_256x256"]["value"] > 0 and "1 warm-up" in cb["sample"]
+    assert cb["cpu_model"] and cb["also_256x256"]["value"] > 0 and "1 full-size warm-up + 2 timed" in cb["sample"]
+    assert cb["also_config1_b16_256x256"]["value"] > 0
     assert r["accuracy_vs_cpu_oracle"]["fp32"]["max_abs"] <= 1e-3
     assert r["accuracy_vs_cpu_oracle"]["fp16"]["psnr_db"] >= r["accuracy_vs_cpu_oracle"]["bf16"]["psnr_db"]
     # reported beside `value`, never instead of it: the other arithmetic modes at the same size, BASELINE configs[1]
@@ -85,10 +86,36 @@ def test_bench_json_contract():
     for k in ("also_fp16_fast", "also_amp16_autocast_policy", "also_fp32_exact"):
         assert r[k]["value"] > 0 and r[k]["height"] == 96, k
     assert r["config1_256"]["fp32"]["value"] > 0 and r["config1_256"]["bf16"]["pairs_per_step"] == 16
+    # the exact-fp32 mode (the one north_star's 1e-3 bound is about) with ITS dominant kernel's roofline, at both sizes
+    for k in ("roofline_fp32", "roofline_fp32_config1"):
+        rr = r[k]
+        assert rr["bound"] in ("hbm", "mfma") and rr["peak"] in (157.3, 8000.0) and abs(rr["frac"] - rr["achieved"] / rr["peak"]) < 1e-3 and "workload" in rr
+    assert r["ranks_seen"] == [0] and len(r["ms_per_step_per_rank"]) == 1
+    wf = r["roofline_warp_in_forward"]
+    assert wf["layout_bytes_per_launch"] > wf["algorithmic_bytes_per_launch"] and wf["frac_on_layout_bytes"] > wf["frac"]
     assert r["roofline_warp_in_forward"]["bound"] == "hbm" and r["roofline_warp_in_forward"]["kernel"].startswith("warp_fused")
     # package power / clocks while the forward runs back to back ({} if rocm-smi is not usable on the box)
     bl = r["board_under_load"]
     assert isinstance(bl, dict) and (not bl or (bl["samples"] >= 1 and bl.get("sclk_mhz", 1) > 0))
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_the_way_the_driver_calls_it():
+    """`python bench.py --gpus 2 ...` (no torchrun environment): the parent launches the ranks itself.  Two ranks share this box's
+    one GPU over gloo (RCCL refuses two ranks on one device; EMAVFI_DIST_BACKEND selects the backend, the driver's node uses the
+    default "nccl"): rank 1 runs from the blob rank 0 broadcast (verified by emavfi_packed_check on arrival)."""
+    env = dict(os.environ, EMAVFI_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "1",
+                          "--height", "96", "--width", "128"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["ranks_seen"] == [0, 1] and len(r["ms_per_step_per_rank"]) == 2 and r["backend"] == "gloo"
+    assert r["value"] > 0 and abs(r["value"] - 2 * 1 * 2 / (r["ms_per_step"] * 2e-3)) / r["value"] < 0.02   # whole-job frames / MAX time
+    assert "roofline" in r and "cpu_baseline" not in r        # the CPU baseline is rank 0's at N = 1 only
 
 
 @pytest.mark.gpu

@@ -55,3 +55,48 @@ def test_world_size_2_gloo(tmp_path):
     res = [torch.load(tmp_path / f"r{r}.pt") for r in range(2)]
     assert [r["span"] for r in res] == [(0, 32), (32, 64)]
     assert all(r["max"] == 2.0 for r in res)
+
+
+def _run_bench(argv, env=None, timeout=300):
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    full_env = dict(os.environ, **(env or {}))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        full_env.pop(k, None)
+    out = subprocess.run([sys.executable] + argv, cwd=root, capture_output=True, text=True, timeout=timeout, env=full_env)
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    return out, lines, (json.loads(lines[-1]) if lines and lines[-1].startswith("{") else None)
+
+
+def test_bench_launches_its_own_ranks_the_way_the_driver_calls_it():
+    """`python bench.py --gpus N` (no torchrun environment) used to exit at argument checking.  The parent now
+    starts `python -m torch.distributed.run ... bench.py` as a child before it imports torch, relays rank 0's ONE JSON line and the
+    child's exit code.  --rehearse swaps the GPU step for a stand-in (this box has no GPU) and keeps everything else: rendezvous on
+    127.0.0.1, the blob broadcast, barrier + MAX timing, the rank census over the backend (gloo here, RCCL on the node)."""
+    out, lines, res = _run_bench(["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--rehearse"], {"EMAVFI_DIST_BACKEND": "gloo"})
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert len(lines) == 1, lines                       # exactly one line on stdout: rank 0's
+    assert res["n_gpus"] == 2 and res["ranks_seen"] == [0, 1] and len(res["ms_per_step_per_rank"]) == 2
+    assert res["steps"] == 3 and res["warmup"] == 1 and res["rehearsal"] is True and res["value"] is None
+    assert res["ms_per_step"] >= max(res["ms_per_step_per_rank"]) - 1e-3      # MAX over ranks, barrier included
+    # the torchrun form of the contract still works, unchanged
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out, lines, res = _run_bench(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                  "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "0", "--rehearse"],
+                                 {"EMAVFI_DIST_BACKEND": "gloo"})
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert res is not None and res["ranks_seen"] == [0, 1]
+
+
+def test_bench_relays_a_failing_rank_as_its_exit_code():
+    out, lines, res = _run_bench(["bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0", "--rehearse"], {"EMAVFI_DIST_BACKEND": "no-such-backend"})
+    assert out.returncode != 0 and res is None
+    if not torch.cuda.is_available():
+        # N = 1 never launches anything: without a GPU it fails loudly (no CPU fallback of the product path)
+        out, lines, res = _run_bench(["bench.py", "--steps", "1", "--warmup", "0", "--no-extras"])
+        assert out.returncode != 0 and "MI355X" in out.stderr

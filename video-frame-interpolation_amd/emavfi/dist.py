@@ -77,6 +77,19 @@ def max_over_ranks(value: float, device=None) -> float:
     return float(t.item())
 
 
+def all_gather_floats(values, device=None):
+    """All-gather a short list of host floats over the initialised backend (device tensors over RCCL when it is "nccl"): one row
+    per rank, in rank order.  bench.py's rank census - which ranks the collective backend actually saw, and each one's step time."""
+    row = [float(v) for v in values]
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return [row]
+    on_cpu = device is None or dist.get_backend() == "gloo"
+    t = torch.tensor(row, dtype=torch.float64, device="cpu" if on_cpu else device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [[float(x) for x in o.cpu()] for o in out]
+
+
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
