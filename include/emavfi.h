@@ -32,8 +32,9 @@
  *    exactly inside f16's normal range, keep 11 instead of 8 significant bits
  *    through the bilinear blend, lose trailing bits below 6.1e-5 and SATURATE
  *    at +-65504 (v_cvt_pkrtz; no infinities are produced) - contracts bf16-
- *    rounded weights stored as f16, and hands the tensor between two
- *    consecutive packs on as f16 bit patterns.  Since round 3 the feature map
+ *    rounded weights stored as f16 (weights below 6.1e-5 in magnitude are f16
+ *    subnormals there: absolute error <= 3e-8 each), and hands the tensor
+ *    between two consecutive packs on as f16 bit patterns.  Since round 3 the feature map
  *    that enters the fusion stage (`feat`, and the warped frame beside it) is
  *    itself stored as f16 in this mode, saturating the same way, and its two
  *    other readers (context_encoding.0, motion_estimation.0) contract it with

@@ -19,6 +19,13 @@ Outputs (data only - inputs and expected outputs):
   large_checks.npz        mid=64: sampled pixels + per-stage statistics at 256x256 (B=2)
                           and 1280x720 (B=1); weights/inputs are regenerated from
                           emavfi.synth by whoever replays it
+  large_1080.npz          the same at 1920x1080 (B=1; BASELINE configs[4]'s size) - `large1080`
+  amp_mid8_23x37.npz, amp_mid64_40x56.npz
+                          the reference's forward under torch.autocast("cpu", dtype=torch.float16) - `amp`: the only way
+                          the reference's autocast path (inference.py:159, a CUDA autocast) can EXECUTE in this container.
+                          The DCN stand-in is wrapped the way torchvision wraps deform_conv2d for autocast (every argument cast
+                          to float, autocast disabled inside, result cast back to the input's dtype).  Every module's output
+                          dtype is recorded next to its values.
 """
 import os
 import sys
@@ -176,6 +183,95 @@ def large():
     np.savez_compressed(os.path.join(OUT, "large_checks.npz"), **arrays)
 
 
+def large1080():
+    """1920x1080 (BASELINE configs[4]'s frame size): the reference forward on CPU, ~1-2 minutes and ~10 GB here."""
+    arrays = {}
+    sd = synth.synthetic_state_dict(seed=0)
+    tag, B, H, W, kind, seed = "1080", 1, 1080, 1920, "natural", 4
+    f1, f2 = synth.synthetic_frames(seed, B, H, W, kind)
+    t0 = time.time()
+    taps = run_reference(sd, f1, f2, 64)
+    print(f"  large {tag}: reference forward {time.time() - t0:.1f}s, flow range "
+          f"[{taps['flow'].min():.2f}, {taps['flow'].max():.2f}] out [{taps['out'].min():.3f},{taps['out'].max():.3f}]")
+    arrays[f"{tag}.meta"] = np.array([B, H, W, seed, 0], dtype=np.int64)
+    for k in ("feat", "ctx", "flow", "warped", "fused_0", "fused_1", "fused_2", "out"):
+        v = taps[k].contiguous().view(-1)
+        pos = sample_positions(seed, f"sample.{tag}.{k}", v.numel(), min(4096, v.numel()))
+        arrays[f"{tag}.pos.{k}"] = pos
+        arrays[f"{tag}.val.{k}"] = v[torch.from_numpy(pos)].numpy()
+        arrays[f"{tag}.stats.{k}"] = stage_stats(taps[k])
+    np.savez_compressed(os.path.join(OUT, "large_1080.npz"), **arrays)
+
+
+class DeformConv2dAutocastStandIn(DeformConv2dStandIn):
+    """torchvision registers an Autocast kernel for deform_conv2d (torchvision/csrc/ops/autocast/deform_conv2d_kernel.cpp, restated):
+    autocast is switched off inside, input / weight / offset / mask / bias are cast to float, the op runs in fp32 and the result is
+    cast `.to(input.scalar_type())`.  The same wrapper around the stand-in operator."""
+
+    def forward(self, x, offset, mask):
+        with torch.autocast("cpu", enabled=False):
+            out = oracle.deform_conv2d(x.float(), offset.float(), mask.float(), self.weight.float(),
+                                       None if self.bias is None else self.bias.float())
+        return out.to(x.dtype)
+
+
+def amp(name, mid, B, H, W, kind, seed):
+    """The reference's own forward under CPU autocast (float16): values and dtypes of every stage."""
+    sd = synth.synthetic_state_dict(seed=seed, mid_channels=mid)
+    f1, f2 = synth.synthetic_frames(seed, B, H, W, kind)
+    saved = ref.DeformConv2d
+    ref.DeformConv2d = DeformConv2dAutocastStandIn
+    try:
+        model = ref.EMA_VFI(in_channels=3, mid_channels=mid, num_blocks=3)
+    finally:
+        ref.DeformConv2d = saved
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    taps, dtypes = {}, {}
+
+    def hook(name_):
+        def fn(_m, _i, o):
+            taps[name_] = o.detach().clone()
+        return fn
+
+    def dtype_hook(name_):
+        def fn(_m, _i, o):
+            dtypes[name_] = str(o.dtype).replace("torch.", "")
+        return fn
+
+    model.feat_ext_blocks.register_forward_hook(hook("feat"))
+    model.context_encoding.register_forward_hook(hook("ctx"))
+    model.context_encoding[3].register_forward_hook(hook("pooled"))
+    model.motion_estimation.register_forward_hook(hook("flow"))
+    for i, blk in enumerate(model.attention_blocks):
+        blk.register_forward_hook(hook(f"fused_{i}"))
+        blk.offset_conv.register_forward_hook(hook(f"raw_{i}"))
+    for n, m in model.named_modules():
+        if n:
+            m.register_forward_hook(dtype_hook(n))
+    orig_warp = model.warp
+
+    def warp_spy(frame2, feature, flow):
+        out = orig_warp(frame2, feature, flow)
+        taps["warped"] = out.detach().clone()
+        dtypes["warp"] = str(out.dtype).replace("torch.", "")
+        return out
+
+    model.warp = warp_spy
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.float16):
+        taps["out"] = model(f1, f2).detach().clone()
+    dtypes["out"] = str(taps["out"].dtype).replace("torch.", "")
+    arrays = {"meta": np.array([mid, B, H, W, seed, 0 if kind == "natural" else 1], dtype=np.int64),
+              "dtypes": np.array(sorted(f"{k}={v}" for k, v in dtypes.items()))}
+    for k, v in taps.items():
+        arrays["tap." + k] = v.float().numpy()      # fp16 values are exact in fp32
+        arrays["dtype." + k] = np.array(str(v.dtype).replace("torch.", ""))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
+    print(f"  {name}: out {taps['out'].dtype} range [{float(taps['out'].min()):.3f}, {float(taps['out'].max()):.3f}], "
+          f"flow [{float(taps['flow'].min()):.2f}, {float(taps['flow'].max()):.2f}]; fp32 stages: "
+          f"{sorted(k for k, v in taps.items() if v.dtype == torch.float32)}")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count())
@@ -193,4 +289,9 @@ if __name__ == "__main__":
         cfg1()
     if "large" in which:
         large()
+    if "large1080" in which:
+        large1080()
+    if "amp" in which:
+        amp("amp_mid8_23x37", 8, 2, 23, 37, "stress", 12)
+        amp("amp_mid64_40x56", 64, 1, 40, 56, "natural", 13)
     print("golden vectors written to", OUT)

@@ -39,6 +39,13 @@ def storage_round(t, dtype, as_f16=False):
     return t.half().float()
 
 
+def weight_round(t, dtype):
+    """What the kernel contracts: the 16-bit rounding of the weight - and, in a bf16 model, THAT value stored as f16 (the packs
+    contract f16 on chip: exact inside f16's normal range, fewer bits below 6.1e-5: include/emavfi.h)."""
+    r = storage_round(t, dtype)
+    return r.half().float() if dtype == "bf16" else r
+
+
 def tap_columns(x, offset, shift=(0.0, 0.0)):
     """bilin(x, sampling position of tap k) for the nine taps, [9][B,C,H,W] - the oracle's own sampler (unmasked)."""
     B, C, H, W = x.shape
@@ -131,7 +138,7 @@ def run_and_gate(dtype, case, flags=0, label=""):
     in_f16 = bool(flags & lib.MDCN_IN_F16)
     out_f16 = bool(flags & lib.MDCN_OUT_F16)
     xs = storage_round(x, dtype, as_f16=in_f16)
-    ows, dws = storage_round(ow, dtype), storage_round(dw, dtype)      # a bf16 model's weights are bf16 values (stored as f16 in the pack)
+    ows, dws = weight_round(ow, dtype), weight_round(dw, dtype)      # a bf16 model's weights are bf16 values stored as f16 in the pack
     store_eps = 0.0 if dtype == "fp32" else (2.0 ** -11 if (dtype == "fp16" or out_f16) else 2.0 ** -8)
     got = lib.mdcn(xs.to(DEV), ows.to(DEV), ob.to(DEV), dws.to(DEV), db.to(DEV), dtype=dtype, flags=flags).cpu()
     ref, hard, sigma = error_model(xs, ows, ob, dws, db, store_eps)

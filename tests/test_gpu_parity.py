@@ -209,11 +209,11 @@ def test_forward_config1_rubberwhale():
     assert out.min().item() >= 0.0 and out.max().item() <= 1.0
 
 
-@pytest.mark.parametrize("tag", ["256", "256s", "720"])
+@pytest.mark.parametrize("tag", ["256", "256s", "720", "1080"])
 def test_forward_large_samples_vs_reference_run(tag):
-    """mid=64 at 256x256 (natural, stress) and 1280x720: sampled pixels of every stage recorded
-    from the reference's forward (tests/golden/large_checks.npz)."""
-    g = load_golden("large_checks.npz")
+    """mid=64 at 256x256 (natural, stress), 1280x720 and 1920x1080 (BASELINE configs[4]'s frame size): sampled pixels of every
+    stage recorded from the reference's forward (tests/golden/large_checks.npz, large_1080.npz)."""
+    g = load_golden("large_1080.npz" if tag == "1080" else "large_checks.npz")
     B, H, W, seed, kind = (int(v) for v in g[f"{tag}.meta"])
     f1, f2 = synth.synthetic_frames(seed, B, H, W, "stress" if kind else "natural")
     m = make_model(synth.synthetic_state_dict(seed=0))
@@ -296,27 +296,29 @@ def test_forward_bf16_psnr():
     assert p >= 52.0 and err <= 2.5e-2
 
 
+@pytest.mark.parametrize("tag", ["720", "1080"])
 @pytest.mark.parametrize("dtype,min_psnr,max_abs", [("bf16", 50.0, 3e-2), ("fp16", 65.0, 6e-3)])
-def test_forward_720p_16bit_vs_reference_run(dtype, min_psnr, max_abs):
-    """The headline arithmetic at the headline size: the 1280x720 pixels sampled from the REFERENCE's own fp32 run
-    (tests/golden/large_checks.npz) replayed in bf16 and fp16.  PSNR over the 4096 sampled output pixels and their
-    max-abs error; bounds follow from the storage precision (bf16: 8 significant bits, fp16: 11), not from the oracle."""
-    g = load_golden("large_checks.npz")
-    B, H, W, seed, kind = (int(v) for v in g["720.meta"])
+def test_forward_720p_16bit_vs_reference_run(dtype, min_psnr, max_abs, tag):
+    """The headline arithmetic at the headline size - and at 1920x1080, BASELINE configs[4]'s frame size -: the pixels sampled from
+    the REFERENCE's own fp32 run (tests/golden/large_checks.npz, large_1080.npz) replayed in bf16 and fp16.  PSNR over the 4096
+    sampled output pixels and their max-abs error; bounds follow from the storage precision (bf16: 8 significant bits, fp16: 11),
+    not from the oracle."""
+    g = load_golden("large_1080.npz" if tag == "1080" else "large_checks.npz")
+    B, H, W, seed, kind = (int(v) for v in g[f"{tag}.meta"])
     f1, f2 = synth.synthetic_frames(seed, B, H, W, "stress" if kind else "natural")
     m = make_model(synth.synthetic_state_dict(seed=0), dtype=dtype)
     with torch.no_grad():
         out, taps = m(f1.to(DEV), f2.to(DEV), return_taps=True)
-    got = out.contiguous().view(-1).cpu()[torch.from_numpy(g["720.pos.out"])]
-    ref = torch.from_numpy(g["720.val.out"])
+    got = out.contiguous().view(-1).cpu()[torch.from_numpy(g[f"{tag}.pos.out"])]
+    ref = torch.from_numpy(g[f"{tag}.val.out"])
     p, err = psnr(got, ref), (got - ref).abs().max().item()
-    print(f"{dtype} 1280x720 vs reference-run samples: PSNR {p:.1f} dB, max-abs {err:.3e}")
+    print(f"{dtype} {W}x{H} vs reference-run samples: PSNR {p:.1f} dB, max-abs {err:.3e}")
     assert p >= min_psnr and err <= max_abs
     # intermediate stages stay within the storage type's relative precision of the reference run
     tol = {"bf16": 4e-2, "fp16": 5e-3}[dtype]
     for k in ("feat", "flow", "fused_2"):
-        gk = taps[k].contiguous().view(-1).cpu()[torch.from_numpy(g[f"720.pos.{k}"])]
-        rk = torch.from_numpy(g[f"720.val.{k}"])
+        gk = taps[k].contiguous().view(-1).cpu()[torch.from_numpy(g[f"{tag}.pos.{k}"])]
+        rk = torch.from_numpy(g[f"{tag}.val.{k}"])
         assert (gk - rk).abs().max().item() <= tol * max(1.0, rk.abs().max().item()), k
 
 

@@ -624,8 +624,10 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
         // flipped by the parity tests through emavfi_debug_switches)
         if (P.conv1.first6 && !(sw & SW_NO_CONV_FIRST)) {
             // cat(frame1, frame2) + conv + ReLU in one launch, straight from the NCHW fp32 frames (ema_vfi.py:112-113)
-            FirstParams fp{frame1, frame2, f.fA, (const char *)packed + P.conv1.w_off + P.conv1.w_bytes,
-                           (const float *)((const char *)packed + P.conv1.b_off), P.p_mid, H, W, B, 1};
+            // (the enumeration-only pass has no blob: no arithmetic on its null pointer - found by the UBSan build, tests/host/host_check.cpp)
+            const char *blob = (const char *)packed;
+            FirstParams fp{frame1, frame2, f.fA, blob ? blob + P.conv1.w_off + P.conv1.w_bytes : nullptr,
+                           blob ? (const float *)(blob + P.conv1.b_off) : nullptr, P.p_mid, H, W, B, 1};
             if (P.nb >= 1 && P.blk[0].ring == 2 && !(sw & SW_NO_FIRSTRING)) {
                 // ... and feat_ext_blocks.conv_block_0 + ReLU behind it in the SAME launch (conv_ring_first.inl): feat_ext_conv1's
                 // tensor exists only as an LDS ring.  EMAVFI_CONV_FIRSTRING=0 (read per call): two launches
