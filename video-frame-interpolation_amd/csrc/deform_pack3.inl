@@ -32,6 +32,11 @@
 #ifndef EMAVFI_P3_ABL
 #define EMAVFI_P3_ABL 0
 #endif
+// measurement build: request 100 KiB of LDS per workgroup = ONE workgroup (one wave per SIMD) per CU - what a wave's phases cost
+// without a partner on its SIMD
+#ifndef EMAVFI_P3_ONE_WG
+#define EMAVFI_P3_ONE_WG 0
+#endif
 struct Pack3 {
     static constexpr int R = 2, TROWS = 16, TCOLS = 16, WAVES = 4, THREADS = 256;
     static constexpr int TR = TROWS + 3 + 2 * R, TC = TCOLS + 3 + 2 * R;                 // 23 x 23 window pixels
@@ -644,10 +649,11 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
 template <typename TS, bool FUSE_OFF> static int launch_deform_pack3(const DeformParams &p, hipStream_t s)
 {
     using C = Pack3;
+    constexpr int LDS_REQ = EMAVFI_P3_ONE_WG ? 100 * 1024 : C::LDS_BYTES;
     static PerDeviceOnce once;   // (the library is re-entrant and serves several devices per process)
-    if (const hipError_t e_ = set_lds_limit(once, reinterpret_cast<const void *>(&deform_pack3_kernel<TS, FUSE_OFF>), C::LDS_BYTES); e_ != hipSuccess) return (int)e_;
+    if (const hipError_t e_ = set_lds_limit(once, reinterpret_cast<const void *>(&deform_pack3_kernel<TS, FUSE_OFF>), LDS_REQ); e_ != hipSuccess) return (int)e_;
     const long long nwg = (long long)((p.W + C::TCOLS - 1) / C::TCOLS) * ((p.H + C::TROWS - 1) / C::TROWS) * p.B;
     if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    deform_pack3_kernel<TS, FUSE_OFF><<<(unsigned)nwg, C::THREADS, C::LDS_BYTES, s>>>(p);
+    deform_pack3_kernel<TS, FUSE_OFF><<<(unsigned)nwg, C::THREADS, LDS_REQ, s>>>(p);
     return (int)hipGetLastError();
 }
