@@ -218,8 +218,7 @@ int emavfi_mdcn(const float *x, const float *offset_weight, const float *offset_
 /* Test hook: the A/B switches of the launch sequence (EMAVFI_CONV_FIRST / _FIRSTRING / _HEAD / _TAILFUSE / _LIGHT / _RING2 = 0,
  * EMAVFI_NO_PERSISTENT_CONV) are read from the environment ONCE per process into one word; this replaces it by
  * (word & and_mask) | or_mask and returns the previous value (bits: 1 no conv_first, 2 no fused first two layers, 4 no fused flow
- * head, 8 no fused reconstruction tail, 16 no planar-head kernel, 32 no persistent conv, 64 no two-layer ring fusions, 128 the fused
- * pack as round 3's launch - EMAVFI_PACK4=0).  None of
+ * head, 8 no fused reconstruction tail, 16 no planar-head kernel, 32 no persistent conv, 64 no two-layer ring fusions).  None of
  * them changes the packed layout.  Not for production callers. */
 int emavfi_debug_switches(int and_mask, int or_mask);
 

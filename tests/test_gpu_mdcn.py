@@ -224,34 +224,6 @@ def test_other_routes_of_the_stage_entry(dtype, C):
         assert (got - ref).abs().max().item() <= (3e-2 if dtype == "bf16" else 4e-3) * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-def test_pack4_equals_pack3(dtype):
-    """Round 4's launch structure of the fused pack (csrc/deform_pack4.inl: one persistent 8-wave workgroup per CU whose two halves
-    run the same phase loop two barrier slots apart) against round 3's (deform_pack3.inl: one 4-wave workgroup per tile,
-    EMAVFI_PACK4=0): the same arithmetic operation for operation, so the results must be BIT-IDENTICAL - ragged sizes, an odd number
-    of tiles (the last pair has one tile), fewer pairs than CUs, more than one iteration per workgroup, the fix-up loop, every flag."""
-    old = lib.debug_switches()
-    try:
-        cases = [(make_case(21, 2, 67, 75, 131), 0), (make_case(22, 1, 67, 16, 16), 0), (make_case(23, 1, 67, 17, 33), 0),
-                 (make_case(24, 3, 67, 200, 330), 0),                                   # 3 * 13 * 21 = 819 tiles: two iterations, odd count
-                 (make_case(25, 1, 67, 40, 64, far_taps=(2, 5, 8), far=7.0), 0),
-                 (make_case(26, 2, 67, 37, 53), lib.MDCN_SPLIT_TAIL)]
-        if dtype == "bf16":
-            cases += [(make_case(27, 2, 67, 37, 53), lib.MDCN_SPLIT_TAIL | lib.MDCN_IN_F16 | lib.MDCN_OUT_F16), (make_case(28, 1, 67, 90, 70), lib.MDCN_IN_F16)]
-        for case, flags in cases:
-            args = [t.to(DEV) for t in case]
-            lib.debug_switches(~lib.SW_NO_PACK4, lib.SW_NO_PACK4)
-            want = lib.mdcn(*args, dtype=dtype, flags=flags).clone()
-            lib.debug_switches(~lib.SW_NO_PACK4, 0)
-            got = lib.mdcn(*args, dtype=dtype, flags=flags).clone()
-            again = lib.mdcn(*args, dtype=dtype, flags=flags)
-            assert torch.isfinite(got).all()
-            assert torch.equal(got, again)
-            assert torch.equal(got, want), f"{tuple(case[0].shape)} flags {flags}: {int((got != want).sum())} of {got.numel()} differ, max {(got - want).abs().max().item():.3e}"
-    finally:
-        lib.debug_switches(0, old)
-
-
 def test_module_forward_is_the_stage_entry():
     """emavfi.ModulatedDeformConvPack.forward (the mirror of ema_vfi.py:53-60) runs emavfi_mdcn: one launch in the 16-bit modes."""
     m = ModulatedDeformConvPack(67, 67).to(DEV)

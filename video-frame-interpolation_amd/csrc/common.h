@@ -242,7 +242,6 @@ enum {
     SW_NO_CONV_LIGHT = 16,       // EMAVFI_CONV_LIGHT=0: planar heads on conv3x3_persist16_kernel
     SW_NO_PERSISTENT_CONV = 32,  // EMAVFI_NO_PERSISTENT_CONV: tile-per-workgroup kernel where the persistent one is the default
     SW_NO_RING2 = 64,            // EMAVFI_CONV_RING2=0: conv_block_1 + conv_block_2 / motion_estimation.0 + .1 + .2 as separate launches
-    SW_NO_PACK4 = 128,           // EMAVFI_PACK4=0: the fused pack as deform_pack3's launch (two independent workgroups per CU)
 };
 unsigned emavfi_switches();
 

@@ -1,5 +1,5 @@
 #include <cstdlib>
-#include "deform_pack4.inl"
+#include "deform_pack3.inl"
 
 bool deform16_can_fuse_offset_conv(int ck, int nf, int cin_real, int off_ck, int off_nf)
 {

@@ -1,2 +1,2 @@
-#include "deform_pack4.inl"
+#include "deform_pack3.inl"
 int launch_deform_f16(const DeformParams &p, hipStream_t s) { return launch_deform16<half_t>(p, s); }

@@ -91,7 +91,6 @@ __device__ __forceinline__ OmTap load_om(const float *__restrict__ om, int tap, 
 }
 
 template <typename TS, bool FUSE_OFF> static int launch_deform_pack3(const DeformParams &p, hipStream_t s);
-template <typename TS> static int launch_deform_pack4(const DeformParams &p, hipStream_t s);
 
 // 16-bit dtypes: the reference width runs the one-launch LDS-window kernel (deform_pack3.inl; weights in its layout, host:
 // deform_pack3_shape), every other width the global-gather kernel of deform.inl
@@ -99,9 +98,6 @@ template <typename TS> static int launch_deform16(const DeformParams &p, hipStre
 {
     if (p.pack3) {
         if (!deform_pack3_shape(p.ck, p.nf, p.cin_real, p.cout_real)) return -2;
-        // the fused pack: round 4's phase-paired persistent kernel (deform_pack4.inl); EMAVFI_PACK4=0 keeps deform_pack3's launch
-        // (same arithmetic, bit-identical results: A/B and parity test)
-        if (p.off_w && !(emavfi_switches() & SW_NO_PACK4)) return launch_deform_pack4<TS>(p, s);
         return p.off_w ? launch_deform_pack3<TS, true>(p, s) : launch_deform_pack3<TS, false>(p, s);
     }
     if (p.off_w) return -1;  // the host only asks for fusion after deform16_can_fuse_offset_conv()

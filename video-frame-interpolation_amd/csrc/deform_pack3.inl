@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
             for (int q = 0; q < 2; ++q) a[q] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d[2][q]), bcast_half<0>(wb), a[q]);
             PACK3_PIN(a);
             // ---- MFMA 2 | blend ops 10..15, then the weight fragments of the next k-group (behind the MFMAs that read wq[(kg+1)&1])
-            mma_kg(acc[pm][2], w3_prev, xf_prev);
+            if (!(EMAVFI_P3_ABL & 64)) mma_kg(acc[pm][2], w3_prev, xf_prev);   // (ablation bit 6: no third-fragment MFMA in the tap loop - results wrong in channels 64..66 only)
 #pragma unroll
             for (int q = 2; q < 4; ++q) a[q] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d[2][q]), bcast_half<0>(wb), a[q]);
 #pragma unroll

@@ -42,7 +42,6 @@ void init_switches()
         if (off("EMAVFI_CONV_TAILFUSE")) v |= SW_NO_TAILFUSE;
         if (off("EMAVFI_CONV_LIGHT")) v |= SW_NO_CONV_LIGHT;
         if (off("EMAVFI_CONV_RING2")) v |= SW_NO_RING2;
-        if (off("EMAVFI_PACK4")) v |= SW_NO_PACK4;
         if (getenv("EMAVFI_NO_PERSISTENT_CONV") != nullptr) v |= SW_NO_PERSISTENT_CONV;
         g_switches.store(v, std::memory_order_relaxed);
     });
