@@ -11,7 +11,7 @@ import torch
 from conftest import ROOT
 from emavfi import EMA_VFI, ModulatedDeformConvPack, lib, synth
 
-RING2 = False   # the two-layer ring fusions (conv_block_1+2, motion_estimation.0+.1+.2) are not in the default plan yet
+RING2 = 1       # launches the two-layer ring fusions remove from the default bf16 plan (conv_block_1 + conv_block_2)
 
 
 def header_symbols():
@@ -323,7 +323,7 @@ def test_switch_word_is_latched_and_settable():
     L = lib.load()
     old = lib.debug_switches()
     try:
-        assert L.emavfi_forward_launches(3, 64, 3, 1, 64, 64, lib.BF16, None, 0, None, None, 0) == 16 - (2 if RING2 else 0)
+        assert L.emavfi_forward_launches(3, 64, 3, 1, 64, 64, lib.BF16, None, 0, None, None, 0) == 16 - RING2
         lib.debug_switches(~lib.SW_NO_HEAD, lib.SW_NO_HEAD)
         os.environ["EMAVFI_CONV_HEAD"] = "1"            # the environment is not consulted again
         try:
@@ -331,7 +331,7 @@ def test_switch_word_is_latched_and_settable():
             n = L.emavfi_forward_launches(3, 64, 3, 1, 64, 64, lib.BF16, None, 0, None, None, 0)
         finally:
             del os.environ["EMAVFI_CONV_HEAD"]
-        assert n > 16 - (2 if RING2 else 0)
+        assert n > 16 - RING2
     finally:
         lib.debug_switches(0, old)
     assert lib.debug_switches() == old

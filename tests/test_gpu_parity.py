@@ -613,6 +613,32 @@ def test_fused_first_two_layers_equal_the_two_launch_path(dtype, shape, switch):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(2, 75, 131), (1, 1, 7), (1, 2, 62), (1, 3, 63), (1, 4, 61), (1, 17, 124), (3, 40, 125), (1, 360, 640), (8, 90, 187)])
+def test_fused_block_pair_equals_the_two_launch_path(dtype, shape, switch):
+    """16-bit modes at mid_channels 64 run feat_ext_blocks.conv_block_1 + conv_block_2 (64 -> 64 -> 64, both + ReLU) as ONE launch
+    (csrc/conv_ring2.inl): an eight-wave workgroup whose waves 0-3 compute conv_block_1's rows into an LDS ring (rounded to the storage
+    type, zero outside the image) and whose waves 4-7 compute conv_block_2 from that ring two rows behind.  EMAVFI_CONV_RING2=0 runs
+    the ring kernel twice.  Both stages repeat the unfused kernel's arithmetic operation for operation, so `feat` and the frame must
+    be BIT-IDENTICAL.  Widths around the 62-column strip pitch, one- to four-row images (fewer rows than the two-row lag), several
+    segments per strip, more strips than workgroups."""
+    B, H, W = shape
+    sd = synth.synthetic_state_dict(seed=8)
+    f1, f2 = (t.to(DEV) for t in synth.synthetic_frames(34, B, H, W, "natural"))
+    feats, outs = [], []
+    for flag in ("1", "0"):
+        switch(lib.SW_NO_RING2, flag == "0")
+        m = make_model(sd, dtype=dtype)
+        with torch.no_grad():
+            out, taps = m(f1, f2, return_taps=True)
+        feats.append(taps["feat"].clone()); outs.append(out.clone())
+        names = [n for n, _, _ in lib.forward_launches(3, 64, 3, B, H, W, dtype)]
+        assert sum(n.startswith("conv3x3+conv3x3") for n in names) == int(flag)
+    assert torch.isfinite(feats[0]).all()
+    assert torch.equal(feats[0], feats[1]), f"feat: {int((feats[0] != feats[1]).sum())} of {feats[0].numel()} differ, max {(feats[0] - feats[1]).abs().max().item():.3e}"
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("shape", [(2, 75, 131), (1, 1, 7), (1, 2, 62), (1, 3, 63), (1, 17, 124), (3, 40, 125), (1, 360, 640)])
 def test_fused_reconstruction_tail_equals_the_two_launch_path(dtype, shape, switch):
     """16-bit modes at mid_channels 64 run reconstruction.1 + .2 (64 -> 32 + ReLU, 32 -> 3 + tanh, (t + 1) / 2) as ONE launch

@@ -185,6 +185,8 @@ struct ConvParams {
     int mfma16;          // weights packed for v_mfma_f32_16x16x32 (conv3x3_persist16_kernel): [tap][k32][cout16 block][lane][16 B]
     int ring;            // weights in registers, input rows through an LDS ring: 1 = conv3x3_s2ring_kernel (64 -> 128 at stride 2, context_encoding.0),
                          // 2 = conv3x3_ring_kernel (64 -> 64), 3 = the same with the im2col tail (65..67 -> 64: reconstruction.0)
+    const void *w2;          // conv_ring2.inl (ring == 2, both layers 64 -> 64): a SECOND conv_block behind this one in the same launch - its packed
+    const float *bias2;      // weights (ring layout) and bias; `out*` / cstore / out_alt / out_fill then describe the second layer's output
     const void *head_w;      // conv_ring.inl, ring == 2 only: fuse a 64 -> nplanes (<= 2) planar head (its weights in the 16x16x32 packing,
     const float *head_bias;  // its bias) behind this layer: `out` is not written, `out_planar` gets the head (round16 applies)
     int out_alt;             // ring kernels (64 -> 64, 64 -> 128 stride 2), channels-last epilogue: store the OTHER 16-bit type (a bf16 kernel writes

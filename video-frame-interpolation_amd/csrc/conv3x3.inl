@@ -736,6 +736,7 @@ template <typename T, int CK, int NF, int NB> static int launch_conv_persist16(c
 
 #include "conv_light.inl"
 #include "conv_ring.inl"
+#include "conv_ring2.inl"
 #include "conv_ring_tail.inl"
 
 // weights packed for the 16x16x32 shape (ConvParams::mfma16): 64 -> 64 (four blocks), 64 -> 32 (two), 64 / 32 -> planes (one)
@@ -978,7 +979,7 @@ template <typename T> static int launch_conv16(const ConvParams &p, hipStream_t 
 {
     if (p.mfma16) return launch_conv_mfma16<T>(p, s);
     if (p.ring == 1) return launch_conv_s2ring<T>(p, s);
-    if (p.ring >= 2) return launch_conv_ring<T>(p, s);
+    if (p.ring >= 2) return p.w2 ? launch_conv_ring2<T>(p, s) : launch_conv_ring<T>(p, s);
     if (!no_persistent && p.stride == 1 && p.nchunk == 1 && p.npass == 1) {
         // measured at B=8 x 720p in bf16 (us per launch, tile-per-workgroup -> persistent): 64->64 670 -> 644,
         // 64->32 / 64->2 414 -> 370, 67->27 685 -> 557.  NOT used where it loses: 67->64 with 4 waves

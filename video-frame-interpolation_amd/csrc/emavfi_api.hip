@@ -340,12 +340,16 @@ bool build_plan(Plan &P, int in_ch, int mid, int nb, int dtype)
 int run_conv(const Plan &P, const Layer &L, const void *packed, const void *in, int in_ps, int Hin, int Win, void *out,
              int out_ps, int out_coff, int cstore, int epi, int B, hipStream_t s, const float *bias_table = nullptr,
              float *planar = nullptr, int nplanes = 0, const void *zeros = nullptr, const Layer *head = nullptr,
-             const FirstParams *first = nullptr, int epi2 = 0, int out_alt = 0)
+             const FirstParams *first = nullptr, int epi2 = 0, int out_alt = 0, const Layer *second = nullptr)
 {
     ConvParams c{};
+    if (second) {   // conv_ring2.inl: `second` runs behind L in the same launch; out / out_ps / cstore / out_alt are ITS output's
+        c.w2 = (const char *)packed + second->w_off;
+        c.bias2 = (const float *)((const char *)packed + second->b_off);
+    }
     c.epi2 = epi2;
     c.out_alt = out_alt;
-    c.out_fill = (L.ring == 2 && !head && !first && out && out_coff == 0 && cstore == 64 && (size_t)out_ps * P.esize == 144) ? 1 : 0;
+    c.out_fill = (L.ring == 2 && !head && !first && out && out_coff == 0 && cstore == 64 && (size_t)out_ps * P.esize == 144) ? 1 : 0;   // (also the fused pair's second layer)
     if (head) {   // conv_ring.inl / conv_ring_tail.inl: L's rows stay in LDS, the planar head `head` is computed from them (planar / nplanes are the head's)
         c.head_w = (const char *)packed + head->w_off;
         c.head_bias = (const float *)((const char *)packed + head->b_off);
@@ -651,12 +655,27 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
         }
     }
     for (int i = first_blk; i < P.nb; ++i) {
-        const bool last = i == P.nb - 1;  // the last block writes feat straight into the fusion buffer
+        // two consecutive conv_blocks as ONE launch (conv_ring2.inl): the tensor between them exists only as an LDS ring.
+        // EMAVFI_CONV_RING2=0: one launch each
+        const bool pair = i + 1 < P.nb && P.blk[i].ring == 2 && P.blk[i + 1].ring == 2 && !P.blk[i].f16_of_bf16 && !P.blk[i + 1].f16_of_bf16 && !(sw & SW_NO_RING2);
+        const int j = pair ? i + 1 : i;   // the layer whose output leaves the launch
+        const bool last = j == P.nb - 1;  // the last block writes feat straight into the fusion buffer
         void *dst = last ? f.fu0 : nxt;
         conv_work(P, P.blk[i], B, H, W, e, fl, by);
-        EMAVFI_STEP(rec, conv_name(P, P.blk[i]) + " feat_ext_blocks", fl, by,
-                    run_conv(P, P.blk[i], packed, cur, P.p_mid, H, W, dst, last ? P.fps : P.p_mid, 0, P.p_mid, EPI_RELU, B, s, nullptr, nullptr, 0, nullptr,
-                             nullptr, nullptr, 0, last && feat16 ? 1 : 0));
+        if (pair) {
+            double fl2, by2;
+            conv_work(P, P.blk[j], B, H, W, e, fl2, by2);
+            const double mid_bytes = (double)B * H * W * mid * e;   // the intermediate tensor is neither written nor read
+            EMAVFI_STEP(rec, "conv3x3+conv3x3<" + std::string(dtype_name(dtype)) + ",64->64->64> feat_ext_blocks." + std::to_string(i) + "+" + std::to_string(j),
+                        fl + fl2, by + by2 - 2 * mid_bytes,
+                        run_conv(P, P.blk[i], packed, cur, P.p_mid, H, W, dst, last ? P.fps : P.p_mid, 0, P.p_mid, EPI_RELU, B, s, nullptr, nullptr, 0, nullptr,
+                                 nullptr, nullptr, 0, last && feat16 ? 1 : 0, &P.blk[j]));
+            i = j;
+        } else {
+            EMAVFI_STEP(rec, conv_name(P, P.blk[i]) + " feat_ext_blocks", fl, by,
+                        run_conv(P, P.blk[i], packed, cur, P.p_mid, H, W, dst, last ? P.fps : P.p_mid, 0, P.p_mid, EPI_RELU, B, s, nullptr, nullptr, 0, nullptr,
+                                 nullptr, nullptr, 0, last && feat16 ? 1 : 0));
+        }
         if (!last) { void *t = cur; cur = nxt; nxt = t; }
     }
     if (!rec.dry && taps && taps[0]) EMAVFI_TRY(launch_cl_to_nchw(f.fu0, taps[0], B, mid, H, W, P.fps, 0, feat_dtype, s), "tap feat");
