@@ -29,6 +29,9 @@ def label(k):
         return "deform<bf16,ck=80,nf=3>"
     if "deform_f32w_kernel" in k:
         return "deform<f32,ck=80,nf=3>"
+    m = re.match(r"_Z13deform_kernelI(DF16b|DF16_|f)Li(\d+)ELi(\d+)E", k)
+    if m:
+        return f"deform<{ {'DF16b': 'bf16', 'DF16_': 'f16', 'f': 'f32'}[m.group(1)] },ck={m.group(2)},nf={m.group(3)}>"
     m = re.match(r"_Z17conv_first_kernelI(DF16b|DF16_)", k)
     if m:
         return f"conv_first<{'bf16' if m.group(1) == 'DF16b' else 'f16'},6->64>"
@@ -47,6 +50,11 @@ def label(k):
     if "conv3x3_ring_kernel<" in k:   # rocprofv3 garbles the demangling of instances with a `true` argument; the bench runs bf16;
         lds = int(k.rsplit("|lds=", 1)[1]) if "|lds=" in k else 0   # HEAD: two rings, 81 424 B; TAIL: 74 752 B
         return "conv3x3+head<bf16,64->64->2>" if lds > 78000 else "conv3x3<bf16,ck=80,nf=2,s=1>"
+    m = re.match(r"_Z20conv3x3_ring2_kernelI(DF16b|DF16_)", k)
+    if m:  # conv_block_1 + conv_block_2 in one launch (csrc/conv_ring2.inl)
+        return f"conv3x3+conv3x3<{'bf16' if m.group(1) == 'DF16b' else 'f16'},64->64->64>"
+    if "conv3x3_ring2_kernel<" in k:   # (garbled demangling of the instance with ALT = true; the bench runs bf16)
+        return "conv3x3+conv3x3<bf16,64->64->64>"
     m = re.match(r"_Z23conv3x3_ringtail_kernelI(DF16b|DF16_)", k)
     if m:  # reconstruction.1 + .2 in one launch (csrc/conv_ring_tail.inl)
         return f"conv3x3+tail<{'bf16' if m.group(1) == 'DF16b' else 'f16'},64->32->3>"
@@ -59,11 +67,14 @@ def label(k):
     m = re.match(r"_Z14conv3x3_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)EEv", k)
     if m:
         return f"conv3x3<{'bf16' if m.group(1) == 'DF16b' else 'f32'},ck={m.group(2)},nf={m.group(3)},s={m.group(4)}>"
+    m = re.search(r"conv3x3_kernel<(float|__bf16|_Float16), (\d+), (\d+), (\d+)>", k)   # demangled form (instances without bool arguments)
+    if m:
+        return f"conv3x3<{ {'float': 'f32', '__bf16': 'bf16', '_Float16': 'f16'}[m.group(1)] },ck={m.group(2)},nf={m.group(3)},s={m.group(4)}>"
     m = re.match(r"_Z22conv3x3_persist_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi\d+EEv", k)
     if m:  # persistent variant serves the same layers (stride 1) as the tile-per-workgroup kernel
         return f"conv3x3<{'bf16' if m.group(1) == 'DF16b' else 'f32'},ck={m.group(2)},nf={m.group(3)},s=1>"
     if "warp_tiled_kernel" in k:
-        return "warp_tiled<3,nchw fp32> (emavfi_warp)" if "void>" in k else "warp_fused<bf16>"
+        return "warp_tiled<3,nchw fp32> (emavfi_warp)" if "void>" in k else ("warp_fused<f32>" if "float" in k else "warp_fused<bf16>")
     if "pack_input_kernel" in k:
         return "pack_input"
     if "pool_partial_kernel" in k:
@@ -89,7 +100,7 @@ for lab in sorted(fl, key=lambda k: -sum(fl[k])):
     print(f"{lab:42s} n={len(fl[lab]):3d} read {rd / 1e6:9.1f} MB  write {wr / 1e6:8.1f} MB  total {(rd + wr) / 1e6:9.1f} MB")
 tag = sys.argv[4] if len(sys.argv) > 4 else "rXX"
 json.dump({"method": __doc__, "kernels": out}, open(sys.argv[3] + f"{tag}_pmc_traffic_detail.json", "w"), indent=1)
-if "--install" in sys.argv:
+if "--install" in sys.argv or any(a.startswith("--install-as=") for a in sys.argv):
     import datetime, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
@@ -106,4 +117,8 @@ if "--install" in sys.argv:
     t = {k: v["hbm_bytes_per_launch"] for k, v in out.items()}
     t["_kernel_source_sha"] = h.hexdigest()[:16]
     t["_measured"] = f"{tag}, {datetime.date.today().isoformat()}, profiles/{tag}_pmc_traffic_detail.json"
-    json.dump(t, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
+    name = "traffic.json"
+    for a in sys.argv:
+        if a.startswith("--install-as="):
+            name = a.split("=", 1)[1]
+    json.dump(t, open(os.path.join(root, "profiles", name), "w"), indent=1)
