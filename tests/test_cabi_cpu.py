@@ -217,6 +217,69 @@ def test_ring_kernels_issue_a_fixed_number_of_vmem_instructions_per_step(tmp_pat
     assert len(seen) == 10, sorted(seen)
 
 
+def _loops_of(body):
+    """[(addr, text)] of a disassembled function and its backward-branch loops [(head address, branch address)]."""
+    import re
+    ins = []
+    for line in body.splitlines():
+        m = re.match(r"\s*(\S.*?)\s*//\s*([0-9A-Fa-f]{8,16}):", line)
+        if m:
+            ins.append((int(m.group(2), 16), m.group(1)))
+    loops = []
+    for addr, text in ins:
+        m = re.match(r"s_c?branch\w* (\d+)$", text)     # target = next instruction + simm16 dwords
+        if m:
+            off = int(m.group(1))
+            off = off - 65536 if off >= 32768 else off
+            if off < 0:
+                loops.append((addr + 4 + 4 * off, addr))
+    return ins, loops
+
+
+def test_ring_kernels_prime_their_rings_with_the_steady_state_pattern(tmp_path):
+    """the counted `s_waitcnt vmcnt(N)` of the ring kernels is only right if the PRIMING loop in front of the row loop issues
+    the same instruction pattern per iteration as a row step - NDMA global_load_lds + NSTORE (dropped) buffer stores - and nothing
+    else that counts.  Checked on the shipped code objects, per loop (backward branches of the disassembly): the row loop (the
+    innermost loop around the counted wait) and the priming loop (the last loop with LDS-DMA in front of it).  Round 4's two-layer
+    kernel (conv_ring2.inl) is covered too: its A-waves issue 3 DMA and wait vmcnt(3) (D = 3, no stores), its B-waves 3 stores, in the
+    same row loop.  The scheme relies on gfx9's single in-order vmcnt for loads, stores and LDS-DMA (a gfx10+ port with a separate
+    vscnt must not reuse it: csrc/conv_ring.inl)."""
+    import re
+    seen = {}
+    for dis in _device_disassembly(tmp_path):
+        for name, body in re.findall(r"<(_Z(?:19conv3x3_ring|20conv3x3_ring2|23conv3x3_ringtail)_kernel\w+)>:\n(.*?)(?=\n\n|\Z)", dis, re.S):
+            ins, loops = _loops_of(body)
+            waits = [a for a, t in ins if re.match(r"s_waitcnt vmcnt\(\d+\) lgkmcnt\(0\)", t) and "vmcnt(0)" not in t]
+            assert len(waits) == 1, (name, len(waits))
+            n = int(re.search(r"vmcnt\((\d+)\)", next(t for a, t in ins if a == waits[0])).group(1))
+            def bars(l):
+                return sum(t == "s_barrier" for a, t in ins if l[0] <= a <= l[1])
+            # the row loop: the widest loop around the counted wait with ONE s_barrier (the item loop around it has more; conv_ring2's row
+            # loop has one back edge per role - A-waves: 3 DMA, B-waves: 3 stores - so its narrower loops cover one role only)
+            row = max((l for l in loops if l[0] <= waits[0] <= l[1] and bars(l) == 1), key=lambda l: l[1] - l[0])
+            # the priming loop: the innermost loop with LDS-DMA in front of the row loop
+            prime = min((l for l in loops if l[1] < row[0] and any("global_load_lds" in t for a, t in ins if l[0] <= a <= l[1])), key=lambda l: l[1] - l[0])
+
+            def count(loop):
+                txt = [t for a, t in ins if loop[0] <= a <= loop[1]]
+                dma = sum("global_load_lds_dwordx4" in t for t in txt)
+                st = sum(t.startswith("buffer_store_dword") for t in txt)
+                other = sum(bool(re.match(r"(global_load_dword|global_store|buffer_load|flat_load|flat_store|scratch_)", t)) for t in txt)
+                return dma, st, other
+            m = re.search(r"ring_kernelI\w+?Lb(\d)ELb(\d)ELb(\d)E", name)
+            ring2, head = "ring2" in name, bool(m) and m.group(2) == "1"
+            want_row = (3, 3, 0) if ring2 else (3, 2 if head else 3, 0)
+            want_prime = (3, 0, 0) if ring2 else want_row
+            assert count(row) == want_row, (name, "row loop", count(row))
+            if ring2:   # both roles' contractions are in it: 2 x 36 MFMAs
+                assert sum("v_mfma" in t for a, t in ins if row[0] <= a <= row[1]) == 72, name
+            assert count(prime) == want_prime, (name, "priming loop", count(prime))
+            assert n == (3 if ring2 else 2 if head else 9), (name, n)
+            seen[name] = n
+    # ring: 8 instances (bf16 / f16 x {64 -> 64, ALT, TAIL, HEAD}); ringtail: 2; ring2: 4 (bf16 / f16 x ALT)
+    assert len(seen) == 14, sorted(seen)
+
+
 def test_packed_cache_file_carries_a_checksum(tmp_path):
     """ADVICE r2: the on-disk packed-weight cache trusted any file of the right size.  The file is now blob + sha256(blob);
     a flipped byte, a truncated file or a file of the old format is ignored (the caller re-packs and overwrites it)."""
