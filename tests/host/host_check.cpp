@@ -69,7 +69,7 @@ int main()
         std::vector<char> names(128 * (size_t)n);
         std::vector<double> fl((size_t)n), by((size_t)n);
         CHECK(emavfi_forward_launches(3, 64, 3, 2, 96, 128, dt, names.data(), names.size(), fl.data(), by.data(), n) == n);
-        CHECK(strlen(names.data()) > 100 && by[0] > 0 && fl[n - 1] > 0 && by[n - 1] > 0);
+        CHECK(strlen(names.data()) > 100 && by[0] > 0 && fl[n - 2] > 0 && by[n - 1] > 0);   // (the last launch is the blob guard: no flops)
         CHECK(emavfi_forward_launches(3, 64, 3, 2, 96, 128, dt, names.data(), 40, fl.data(), by.data(), n) == EMAVFI_E_ARG);
         CHECK(emavfi_forward_launches(3, 64, 3, 2, 96, 128, dt, names.data(), names.size(), fl.data(), by.data(), n - 1) == EMAVFI_E_ARG);
         CHECK(emavfi_forward_launches(3, 64, 3, 2, 96, 128, dt, nullptr, 0, nullptr, by.data(), n) == n);

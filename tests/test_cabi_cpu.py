@@ -386,7 +386,7 @@ def test_switch_word_is_latched_and_settable():
     L = lib.load()
     old = lib.debug_switches()
     try:
-        assert L.emavfi_forward_launches(3, 64, 3, 1, 64, 64, lib.BF16, None, 0, None, None, 0) == 16 - RING2
+        assert L.emavfi_forward_launches(3, 64, 3, 1, 64, 64, lib.BF16, None, 0, None, None, 0) == 17 - RING2
         lib.debug_switches(~lib.SW_NO_HEAD, lib.SW_NO_HEAD)
         os.environ["EMAVFI_CONV_HEAD"] = "1"            # the environment is not consulted again
         try:
@@ -394,7 +394,7 @@ def test_switch_word_is_latched_and_settable():
             n = L.emavfi_forward_launches(3, 64, 3, 1, 64, 64, lib.BF16, None, 0, None, None, 0)
         finally:
             del os.environ["EMAVFI_CONV_HEAD"]
-        assert n > 16 - RING2
+        assert n > 17 - RING2
     finally:
         lib.debug_switches(0, old)
     assert lib.debug_switches() == old

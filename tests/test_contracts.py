@@ -19,15 +19,16 @@ def test_forward_launch_enumeration_matches_survey_flops():
     names = [n for n, _, _ in launches]
     # bf16 at the reference width: each ModulatedDeformConvPack (offset_conv + dcn_v2) is ONE launch (23 - 3),
     # cat(frame1, frame2) + feat_ext_conv1 + conv_block_0 is one launch (no pack_input, no conv_block_0: - 2) and so is
-    # motion_estimation.1 + .2 (- 1), reconstruction.1 + .2 (- 1) and, since round 4, conv_block_1 + conv_block_2 (- 1)
-    assert len(launches) == 15 and sum(n.startswith("conv3x3+conv3x3<bf16,64->64->64>") for n in names) == 1 and sum("+head" in n for n in names) == 1 and names[0].startswith("conv_first+conv3x3<bf16,6->64->64>") and names[-1].startswith("conv3x3+tail<bf16,64->32->3>")
+    # motion_estimation.1 + .2 (- 1), reconstruction.1 + .2 (- 1) and, since round 4, conv_block_1 + conv_block_2 (- 1); + the
+    # blob-header guard as the last launch (round 4)
+    assert len(launches) == 16 and sum(n.startswith("conv3x3+conv3x3<bf16,64->64->64>") for n in names) == 1 and sum("+head" in n for n in names) == 1 and names[0].startswith("conv_first+conv3x3<bf16,6->64->64>") and names[-2].startswith("conv3x3+tail<bf16,64->32->3>") and names[-1] == "blob_guard"
     assert sum(n.startswith("deform<") and n.endswith("offset_conv+dcn_v2") for n in names) == 3
     per_px = sum(f for _, f, _ in launches) / (B * H * W)
     assert abs(per_px - (1054908 - 2 * 36864 + 24)) < 1.0
     assert all(b > 0 for _, _, b in launches)
     # fp32 keeps the two launches per pack; labels and byte counts differ, the flop total does not
     l32 = lib.forward_launches(3, 64, 3, B, H, W, "fp32")
-    assert len(l32) == 23 and sum(n.startswith("deform<") for n, _, _ in l32) == 3
+    assert len(l32) == 24 and sum(n.startswith("deform<") for n, _, _ in l32) == 3
     assert abs(sum(f for _, f, _ in l32) - sum(f for _, f, _ in launches)) < 1.0
     assert all("f32" in n for n, _, _ in l32 if "<" in n)
 
@@ -49,8 +50,8 @@ def test_size_limits_are_argument_errors_not_crashes():
     fake = ctypes.c_void_p(256)
     rc = L.emavfi_conv3x3(fake, fake, fake, fake, 1, 64, 64, 32768, 32768, 1, 0, lib.BF16, fake, 0, None)
     assert rc == -1 and "4 GiB" in lib.last_error()
-    assert L.emavfi_forward_launches(3, 64, 3, 1, 64, 64, lib.BF16, None, 0, None, None, 0) == 15
-    assert L.emavfi_forward_launches(3, 64, 3, 1, 64, 64, lib.F32, None, 0, None, None, 0) == 23
+    assert L.emavfi_forward_launches(3, 64, 3, 1, 64, 64, lib.BF16, None, 0, None, None, 0) == 16
+    assert L.emavfi_forward_launches(3, 64, 3, 1, 64, 64, lib.F32, None, 0, None, None, 0) == 24
     assert L.emavfi_forward_launches(3, 7, 3, 1, 64, 64, lib.BF16, None, 0, None, None, 0) == -2
 
 

@@ -17,7 +17,8 @@ The gates are derived from the kernel's rounding model, not tuned (u = 2^-11, th
   * the contraction is exact-product fp32 MFMA: n * 2^-24 * sum|terms| again;
   * the result is rounded once to the storage type: bf16 2^-8, f16 2^-11 relative (round to nearest: half a unit in the last place).
 HARD bound (must hold for every element): the sum of those worst cases.  STATISTICAL gate (tight): the same terms as standard
-deviations (independent roundings) - the normalised error z = err / sigma must have rms <= 1.5 and max <= 8."""
+deviations (independent roundings) - the normalised error z = err / sigma must have rms <= 1.0 and max <= 6 (measured: rms
+0.46-0.66, max <= 3.5 over all cases)."""
 import math
 
 import pytest
@@ -150,7 +151,7 @@ def run_and_gate(dtype, case, flags=0, label=""):
     print(f"{label or dtype}: max err {err.max().item():.3e} (|y| <= {ref.abs().max().item():.3g}); err / hard bound max {ratio:.3f}; z rms {zr:.3f} max {zm:.2f}")
     assert ratio <= 1.0, f"{label}: an element exceeds the worst-case bound of the rounding model ({ratio:.3f}x)"
     if dtype != "fp32":
-        assert zr <= 1.5 and zm <= 8.0, f"{label}: error distribution wider than the rounding model (z rms {zr:.3f}, max {zm:.2f})"
+        assert zr <= 1.0 and zm <= 6.0, f"{label}: error distribution wider than the rounding model (z rms {zr:.3f}, max {zm:.2f})"
     return got, ref
 
 

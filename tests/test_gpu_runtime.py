@@ -291,3 +291,49 @@ def test_packed_blob_is_cached_on_disk_by_content(tmp_path, monkeypatch):
         assert len(calls) == 5 and torch.equal(a, c)
         make_model(sd, mid=8, dtype="bf16")(f1, f2)
         assert len(calls) == 5
+
+
+def test_foreign_blob_is_refused_or_poisoned():
+    """VERDICT r3 item 8 / ADVICE r3: the packed blob carries a header (magic, library version, model, dtype, layout tag, size, payload
+    checksum).  emavfi_packed_check names what is wrong with a foreign blob (a code, after a device-to-host copy); emavfi_forward, which
+    must not synchronise, refuses a buffer that is too short and otherwise compares the header ON THE DEVICE: a blob of another dtype
+    (same size: only the header can tell) or without a header yields an all-NaN frame, never plausible garbage."""
+    import ctypes
+    L = lib.load()
+    sd = synth.synthetic_state_dict(seed=0)
+    blobs = {}
+    for mode in ("bf16", "fp16"):
+        m = EMA_VFI(compute_dtype=mode).to(DEV).eval()
+        m.load_state_dict(sd, strict=True)
+        blobs[mode] = m.packed_weights(lib.dtype_code(mode), torch.device(DEV)).clone()
+        lib.packed_check(3, 64, 3, lib.dtype_code(mode), blobs[mode])                     # what pack_weights wrote verifies
+    assert blobs["bf16"].numel() == blobs["fp16"].numel()
+    with pytest.raises(RuntimeError, match="dtype"):
+        lib.packed_check(3, 64, 3, lib.BF16, blobs["fp16"])
+    bad = blobs["bf16"].clone()
+    bad[123456] ^= 0x20
+    with pytest.raises(RuntimeError, match="checksum"):
+        lib.packed_check(3, 64, 3, lib.BF16, bad)
+    with pytest.raises(RuntimeError, match="dtype"):                                      # installing a foreign blob is refused
+        EMA_VFI(compute_dtype="bf16").to(DEV).load_packed_weights("bf16", blobs["fp16"])
+    headerless = blobs["bf16"].clone()
+    headerless[:256] = 0
+    f1, f2 = (t.to(DEV) for t in synth.synthetic_frames(3, 1, 48, 64, "natural"))
+    ws = torch.empty(L.emavfi_workspace_bytes(3, 64, 3, 1, 48, 64, lib.BF16), dtype=torch.uint8, device=DEV)
+    out = torch.empty_like(f1)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def forward(blob, nbytes=None):
+        rc = L.emavfi_forward(3, 64, 3, blob.data_ptr(), blob.numel() if nbytes is None else nbytes, f1.data_ptr(), f2.data_ptr(), out.data_ptr(),
+                              ws.data_ptr(), ws.numel(), 1, 48, 64, lib.BF16, None, stream)
+        torch.cuda.synchronize()
+        return rc, out.clone()
+    rc, good = forward(blobs["bf16"])
+    assert rc == 0 and torch.isfinite(good).all() and good.min() >= 0 and good.max() <= 1
+    rc, _ = forward(blobs["bf16"], nbytes=blobs["bf16"].numel() - 256)
+    assert rc == -1 and "packed blob has" in lib.last_error()
+    for name, blob in (("another dtype's blob", blobs["fp16"]), ("a blob without a header", headerless)):
+        rc, got = forward(blob)
+        assert rc == 0 and torch.isnan(got).all(), name
+    rc, again = forward(blobs["bf16"])                                                    # (a corrupted payload byte is the checksum's business:
+    assert rc == 0 and torch.equal(again, good)                                           #  emavfi_packed_check, above)

@@ -607,9 +607,9 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
     }
     hipStream_t s = (hipStream_t)stream;
     const unsigned sw = emavfi_switches();
-    // the header of the blob is compared ON THE DEVICE with what this call expects (ctx_finish_kernel): a blob of another version /
-    // model / dtype / layout-switch setting turns the context vector - and with it the flow, the warp and the frame - into NaN
-    // instead of plausible garbage.  emavfi_packed_check() is the (synchronising) entry that returns a code for it.
+    // the header of the blob is compared ON THE DEVICE with what this call expects (the forward's last launch, blob_guard_kernel): a
+    // blob of another version / model / dtype / layout-switch setting yields an all-NaN frame instead of plausible garbage.
+    // emavfi_packed_check() is the (synchronising) entry that returns a code for it.
     BlobGuard guard{rec.dry ? nullptr : (const BlobHeader *)packed, expected_header(P, requested_dtype)};
     const int mid = P.mid, C = P.in_ch;
     const double px = (double)B * H * W, e = P.esize;
@@ -695,7 +695,7 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
                 launch_pool_partial(f.c3, f.part, B, f.H4 * f.W4, f.p4, f.p4, f.nparts, dtype, s));
     EMAVFI_STEP(rec, "context_linear_fold", 0, (double)B * f.nparts * 4 * mid * 4,
                 launch_ctx_finish(f.part, (const float *)((const char *)packed + P.ctx_off), f.ctx, f.table, B, mid, f.p4,
-                                  f.nparts, f.H4 * f.W4, P.m0.coutpad, P.amp ? 1 : 0, guard, s));
+                                  f.nparts, f.H4 * f.W4, P.m0.coutpad, P.amp ? 1 : 0, s));
     if (!rec.dry && taps && taps[1])
         if (hipMemcpyAsync(taps[1], f.ctx, (size_t)B * mid * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
             return fail(EMAVFI_E_LAUNCH, "tap ctx copy failed");
@@ -796,6 +796,7 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
         EMAVFI_STEP(rec, conv_name(P, P.r2) + " reconstruction.2(tanh)", fl, by,
                     run_conv(P, P.r2, packed, f.fB, f.p_half, H, W, nullptr, 0, 0, 0, EPI_PLANAR_TANH01, B, s, nullptr, out, C));
     }
+    EMAVFI_STEP(rec, "blob_guard", 0, 64.0, launch_blob_guard(guard, out, npx * (size_t)C, s));
     return EMAVFI_OK;
 }
 

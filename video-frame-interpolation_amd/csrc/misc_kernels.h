@@ -41,10 +41,10 @@ inline uint64_t blob_checksum_host(const void *payload, size_t bytes)
     for (size_t i = 0; i < bytes / 4; ++i) s += ((uint64_t)w[i] + 0x9E3779B9ull) * (2 * (uint64_t)i + 1);
     return s;
 }
-// forward-time guard: the context kernel compares the blob's header with what the call expects and turns a mismatch into NaN
-// (ctx and the bias table -> flow -> every later stage): the forward cannot return an error for device-resident bytes without
-// synchronising, but it must not produce plausible garbage either
+// forward-time guard: the forward's last launch compares the blob's header with what the call expects and overwrites the frame
+// with NaN on a mismatch (misc_kernels.hip, blob_guard_kernel)
 struct BlobGuard { const BlobHeader *hdr; BlobHeader expect; };
+int launch_blob_guard(const BlobGuard &guard, float *out, size_t n, hipStream_t s);
 // writes the header (pack time) and adds the payload checksum into it
 int launch_blob_seal(void *blob, const BlobHeader &h, hipStream_t s);
 
@@ -61,7 +61,7 @@ int launch_cl_to_nchw(const void *src, float *dst, int B, int C, int H, int W, i
 int launch_om_from_nchw(const float *off, const float *msk, float *om, int B, int H, int W, hipStream_t s);
 int launch_pool_partial(const void *src, float *part, int B, int npix, int cp, int ps, int nparts, int dtype, hipStream_t s);
 int launch_ctx_finish(const float *part, const float *ctxw, float *ctx_out, float *table, int B, int m, int cp, int nparts,
-                      int npix, int coutpad, int round16, const BlobGuard &guard, hipStream_t s);
+                      int npix, int coutpad, int round16, hipStream_t s);
 int launch_warp_nchw(const float *frame2, const float *flow, float *out, int B, int C, int H, int W, hipStream_t s);
 int launch_warp_fused(const float *frame2, const float *flow, void *dst, int B, int C, int H, int W, int ps, int coff, int dtype,
                       hipStream_t s);

@@ -432,18 +432,10 @@ int launch_pool_partial(const void *src, float *part, int B, int npix, int cp, i
 // cls = ym*4 + xm; bit0 of ym: row y-1 exists, bit1: row y+1 exists (same for xm / columns).
 __global__ __launch_bounds__(256) void ctx_finish_kernel(const float *__restrict__ part, const float *__restrict__ ctxw,
                                                          float *__restrict__ ctx_out, float *__restrict__ table,
-                                                         int m, int cp, int nparts, int npix, int coutpad, int round16, const BlobGuard guard)
+                                                         int m, int cp, int nparts, int npix, int coutpad, int round16)
 {
-    // the blob's header against what this call expects (misc_kernels.h, BlobGuard): a foreign blob poisons ctx and the bias table
-    bool foreign = false;
-    if (guard.hdr) {
-        const uint32_t *got = (const uint32_t *)guard.hdr, *want = (const uint32_t *)&guard.expect;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) foreign |= got[i] != want[i];   // magic, version, header_bytes, in, mid, nb, dtype, layout_tag
-    }
-    const float poison = foreign ? __builtin_nanf("") : 0.0f;
     // round16 (EMAVFI_AMP16): the pooled mean and the Linear output are fp16 tensors under autocast
-    const auto rq = [round16, poison](float v) { return (round16 ? (float)(half_t)v : v) + poison; };
+    const auto rq = [round16](float v) { return round16 ? (float)(half_t)v : v; };
     extern __shared__ float sm[];
     float *mean = sm, *ctx = sm + 4 * m, *tsum = ctx + m;  // tsum [m][9]
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -517,10 +509,31 @@ __global__ __launch_bounds__(256) void ctx_finish_kernel(const float *__restrict
     }
 }
 int launch_ctx_finish(const float *part, const float *ctxw, float *ctx_out, float *table, int B, int m, int cp, int nparts,
-                      int npix, int coutpad, int round16, const BlobGuard &guard, hipStream_t s)
+                      int npix, int coutpad, int round16, hipStream_t s)
 {
     const size_t sh = (size_t)(4 * m + m + 9 * m) * sizeof(float);
-    ctx_finish_kernel<<<B, 256, sh, s>>>(part, ctxw, ctx_out, table, m, cp, nparts, npix, coutpad, round16, guard);
+    ctx_finish_kernel<<<B, 256, sh, s>>>(part, ctxw, ctx_out, table, m, cp, nparts, npix, coutpad, round16);
+    return (int)hipGetLastError();
+}
+
+// The forward's LAST launch: the blob's header against what the call expects (misc_kernels.h, BlobGuard).  A match costs one
+// 36-byte compare per thread of a 64-workgroup grid; a foreign blob (another library version / model / dtype / layout-switch
+// setting, or no header at all) overwrites the frame with NaN - the forward cannot return a code for device-resident bytes
+// without synchronising, but it must not hand back plausible garbage either.  (Not through the arithmetic: ReLU - v_max_f32 -
+// turns a poisoned activation into 0.)
+__global__ __launch_bounds__(256) void blob_guard_kernel(const BlobGuard guard, float *__restrict__ out, size_t n)
+{
+    const uint32_t *got = (const uint32_t *)guard.hdr, *want = (const uint32_t *)&guard.expect;
+    bool foreign = false;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) foreign |= got[i] != want[i];   // magic, version, header_bytes, in, mid, nb, dtype, layout_tag
+    if (!foreign) return;
+    const float poison = __builtin_nanf("");
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = poison;
+}
+int launch_blob_guard(const BlobGuard &guard, float *out, size_t n, hipStream_t s)
+{
+    blob_guard_kernel<<<64, 256, 0, s>>>(guard, out, n);
     return (int)hipGetLastError();
 }
 
