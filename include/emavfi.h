@@ -215,6 +215,21 @@ size_t emavfi_mdcn_workspace_bytes(int B, int C, int H, int W, int dtype, int fl
 int emavfi_mdcn(const float *x, const float *offset_weight, const float *offset_bias, const float *dcn_weight, const float *dcn_bias,
                 float *y, int B, int C, int H, int W, int dtype, int flags, void *workspace, size_t workspace_bytes, void *stream);
 
+/* context_encoding(feat) -> ctx, ema_vfi.py:79-86 (called at :120): conv stride 2 + ReLU, conv stride 2 + ReLU, conv + ReLU,
+ * AdaptiveAvgPool2d(1), Flatten, Linear.  feat [B,mid,H,W]; params = 8 device pointers in the Sequential's registration order:
+ * context_encoding.{0.0,1.0,2.0}.{weight,bias} ([2m,m,3,3] [2m] [4m,2m,3,3] [4m] [4m,4m,3,3] [4m]) and context_encoding.5.{weight [m,4m],
+ * bias [m]}; ctx [B,mid] fp32.
+ * reconstruction(fused) -> out, ema_vfi.py:102-107 (called at :144-146): conv + ReLU, conv + ReLU, conv, tanh, then (t + 1) / 2.
+ * fused [B,mid+3,H,W]; params = 6 device pointers: reconstruction.{0.0,1.0,2}.{weight,bias}; out [B,3,H,W] in [0,1].
+ * Both run the launches emavfi_forward runs for the stage (16-bit modes at mid_channels 64: the LDS-ring kernels, reconstruction.1 + .2
+ * as ONE launch), on EMA_VFI(3, mid_channels, 3)'s plan; storage rounding of the inputs as the forward's tensors have it. */
+size_t emavfi_context_workspace_bytes(int B, int mid_channels, int H, int W, int dtype);
+int emavfi_context(const float *feat, const float *const *params, float *ctx, int B, int mid_channels, int H, int W, int dtype,
+                   void *workspace, size_t workspace_bytes, void *stream);
+size_t emavfi_reconstruct_workspace_bytes(int B, int mid_channels, int H, int W, int dtype);
+int emavfi_reconstruct(const float *fused, const float *const *params, float *out, int B, int mid_channels, int H, int W, int dtype,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
 /* Test hook: the A/B switches of the launch sequence (EMAVFI_CONV_FIRST / _FIRSTRING / _HEAD / _TAILFUSE / _LIGHT / _RING2 = 0,
  * EMAVFI_NO_PERSISTENT_CONV) are read from the environment ONCE per process into one word; this replaces it by
  * (word & and_mask) | or_mask and returns the previous value (bits: 1 no conv_first, 2 no fused first two layers, 4 no fused flow

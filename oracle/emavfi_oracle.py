@@ -186,8 +186,9 @@ def forward(p: Params, frame1, frame2, num_blocks: int = 3, taps: Optional[dict]
 
 # --------------------------------------------------------------------------------------------------------------
 # The reference's forward under ``torch.cuda.amp.autocast()`` (float16), which is what ``inference.py:159`` runs on a
-# GPU.  Restated from PyTorch's published autocast op policy, NOT pinned by execution (the reference has never been
-# run on a GPU here): ``conv2d`` / ``linear`` are on the float16 list (inputs, weight AND bias are cast to fp16, the
+# GPU.  Restated from PyTorch's published autocast op policy; since round 4 PINNED BY EXECUTION of the reference's own forward under
+# torch.autocast("cpu", dtype=torch.float16) (tests/golden/make_golden.py amp; tests/test_oracle_golden.py: bit for bit at mid_channels 8) -
+# the reference has never been run on a GPU here, and for every op on this path the CPU and CUDA autocast lists agree: ``conv2d`` / ``linear`` are on the float16 list (inputs, weight AND bias are cast to fp16, the
 # products accumulate in fp32, the result is an fp16 tensor); ``grid_sampler``, ``torch.cat`` and the ``grid + flow``
 # add promote to the widest input - fp32 for all three here, because frame2, the pixel grid and ``warped`` are fp32
 # (ema_vfi.py:157-169, :134); element-wise ops without a list entry

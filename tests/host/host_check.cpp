@@ -126,6 +126,16 @@ int main()
     CHECK(emavfi_mdcn_workspace_bytes(1, 67, 32, 32, EMAVFI_F32, EMAVFI_MDCN_IN_F16) == 0 && emavfi_mdcn_workspace_bytes(1, 67, 32, 32, EMAVFI_BF16, 8) == 0);
     CHECK(emavfi_mdcn(nullptr, ff, ff, ff, ff, fo, 1, 67, 8, 8, EMAVFI_BF16, 0, fake, 0, nullptr) == EMAVFI_E_ARG);
     CHECK(emavfi_mdcn(ff, ff, ff, ff, nullptr, fo, 1, 67, 8, 8, EMAVFI_BF16, 0, fake, 16, nullptr) == EMAVFI_E_WORKSPACE);
+    for (int dt : dtypes) CHECK(emavfi_context_workspace_bytes(2, 64, 75, 131, dt) > 0 && emavfi_reconstruct_workspace_bytes(2, 8, 23, 37, dt) > 0);
+    CHECK(emavfi_context_workspace_bytes(1, 7, 32, 32, EMAVFI_BF16) == 0 && emavfi_reconstruct_workspace_bytes(0, 64, 32, 32, EMAVFI_BF16) == 0);
+    {
+        const float *eight[8] = {ff, ff, ff, ff, ff, ff, ff, nullptr};
+        CHECK(emavfi_context(ff, eight, fo, 1, 64, 16, 16, EMAVFI_BF16, fake, (size_t)1 << 40, nullptr) == EMAVFI_E_ARG && strstr(emavfi_last_error(), "params[7]"));
+        CHECK(emavfi_context(nullptr, eight, fo, 1, 64, 16, 16, EMAVFI_BF16, fake, 0, nullptr) == EMAVFI_E_ARG);
+        const float *six[6] = {ff, ff, ff, ff, ff, ff};
+        CHECK(emavfi_reconstruct(ff, six, fo, 1, 64, 16, 16, EMAVFI_BF16, fake, 16, nullptr) == EMAVFI_E_WORKSPACE);
+        CHECK(emavfi_reconstruct(ff, six, fo, 1, 64, 4096, 4096, EMAVFI_BF16, fake, 16, nullptr) == EMAVFI_E_ARG);
+    }
     CHECK(emavfi_pack_weights(3, 64, 3, nullptr, 40, fake, 1 << 20, EMAVFI_BF16, nullptr) == EMAVFI_E_ARG);
     std::vector<const void *> params(40, fake);
     CHECK(emavfi_pack_weights(3, 64, 3, params.data(), 39, fake, (size_t)1 << 30, EMAVFI_BF16, nullptr) == EMAVFI_E_ARG);

@@ -566,6 +566,61 @@ int attention_block_amp(const Plan &P, int i, const void *packed, const void *x1
     return EMAVFI_OK;
 }
 
+// ---- context_encoding (ema_vfi.py:79-86, called at :120) and reconstruction (ema_vfi.py:102-107, called at :144-146) as the forward
+// runs them; shared by forward_impl and the stage-level entries emavfi_context / emavfi_reconstruct
+int context_stage(const Plan &P, const void *packed, const void *feat_cl, const FwdBuffers &f, int B, int H, int W, hipStream_t s, Recorder &rec)
+{
+    const double e = P.esize;
+    const int mid = P.mid, dtype = P.dtype;
+    double fl, by;
+    conv_work(P, P.c0, B, H, W, e, fl, by);
+    EMAVFI_STEP(rec, conv_name(P, P.c0) + " context_encoding.0", fl, by,
+                run_conv(P, P.c0, packed, feat_cl, P.fps, H, W, f.c1, f.p2, 0, f.p2, EPI_RELU, B, s, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0,
+                         P.feat16 ? 1 : 0));
+    conv_work(P, P.c1, B, f.H2, f.W2, e, fl, by);
+    EMAVFI_STEP(rec, conv_name(P, P.c1) + " context_encoding.1", fl, by,
+                run_conv(P, P.c1, packed, f.c1, f.p2, f.H2, f.W2, f.c2, f.p4, 0, f.p4, EPI_RELU, B, s));
+    conv_work(P, P.c2, B, f.H4, f.W4, e, fl, by);
+    EMAVFI_STEP(rec, conv_name(P, P.c2) + " context_encoding.2", fl, by,
+                run_conv(P, P.c2, packed, f.c2, f.p4, f.H4, f.W4, f.c3, f.p4, 0, f.p4, EPI_RELU, B, s));
+    EMAVFI_STEP(rec, "avg_pool_partial", 0, (double)B * f.H4 * f.W4 * 4 * mid * e,
+                launch_pool_partial(f.c3, f.part, B, f.H4 * f.W4, f.p4, f.p4, f.nparts, dtype, s));
+    EMAVFI_STEP(rec, "context_linear_fold", 0, (double)B * f.nparts * 4 * mid * 4,
+                launch_ctx_finish(f.part, packed ? (const float *)((const char *)packed + P.ctx_off) : nullptr, f.ctx, f.table, B, mid, f.p4,
+                                  f.nparts, f.H4 * f.W4, P.m0.coutpad, P.amp ? 1 : 0, s));
+    return EMAVFI_OK;
+}
+
+int reconstruction_stage(const Plan &P, const void *packed, const void *x, const FwdBuffers &f, float *out, int B, int H, int W, hipStream_t s, Recorder &rec)
+{
+    const double e = P.esize;
+    const int C = P.in_ch;
+    const unsigned sw = emavfi_switches();
+    double fl, by;
+    conv_work(P, P.r0, B, H, W, e, fl, by);
+    EMAVFI_STEP(rec, conv_name(P, P.r0) + " reconstruction.0", fl, by,
+                run_conv(P, P.r0, packed, x, P.fps, H, W, f.fA, P.p_mid, 0, P.p_mid, EPI_RELU, B, s));
+    // reconstruction.1 + .2 in one launch (conv_ring_tail.inl): .1's rows never leave the LDS.  EMAVFI_CONV_TAILFUSE=0: two
+    if (P.r1.mfma16 && P.r1.ck == 64 && P.r1.nf == 1 && P.r1.cout == 32 && P.r1.ring == 0 && P.r2.mfma16 && P.r2.ck == 32 && P.r2.nf == 1 && P.r2.cout <= 3 &&
+        !(sw & SW_NO_TAILFUSE)) {
+        double fl2, by2;
+        conv_work(P, P.r1, B, H, W, e, fl, by);
+        conv_work(P, P.r2, B, H, W, 4.0, fl2, by2);
+        const double mid_bytes = (double)B * H * W * P.r1.cout * e;
+        EMAVFI_STEP(rec, "conv3x3+tail<" + std::string(dtype_name(P.dtype)) + ",64->32->" + std::to_string(P.r2.cout) + "> reconstruction.1+.2(tanh)",
+                    fl + fl2, by + by2 - 2 * mid_bytes,
+                    run_conv(P, P.r1, packed, f.fA, P.p_mid, H, W, nullptr, 0, 0, 0, EPI_RELU, B, s, nullptr, out, C, nullptr, &P.r2, nullptr, EPI_PLANAR_TANH01));
+    } else {
+        conv_work(P, P.r1, B, H, W, e, fl, by);
+        EMAVFI_STEP(rec, conv_name(P, P.r1) + " reconstruction.1", fl, by,
+                    run_conv(P, P.r1, packed, f.fA, P.p_mid, H, W, f.fB, f.p_half, 0, f.p_half, EPI_RELU, B, s));
+        conv_work(P, P.r2, B, H, W, 4.0, fl, by);
+        EMAVFI_STEP(rec, conv_name(P, P.r2) + " reconstruction.2(tanh)", fl, by,
+                    run_conv(P, P.r2, packed, f.fB, f.p_half, H, W, nullptr, 0, 0, 0, EPI_PLANAR_TANH01, B, s, nullptr, out, C));
+    }
+    return EMAVFI_OK;
+}
+
 BlobHeader expected_header(const Plan &P, int requested_dtype)
 {
     BlobHeader h{};
@@ -681,21 +736,7 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
     if (!rec.dry && taps && taps[0]) EMAVFI_TRY(launch_cl_to_nchw(f.fu0, taps[0], B, mid, H, W, P.fps, 0, feat_dtype, s), "tap feat");
 
     // --- context encoding (ema_vfi.py:120): two stride-2 convs, one conv, global mean, linear
-    conv_work(P, P.c0, B, H, W, e, fl, by);
-    EMAVFI_STEP(rec, conv_name(P, P.c0) + " context_encoding.0", fl, by,
-                run_conv(P, P.c0, packed, f.fu0, P.fps, H, W, f.c1, f.p2, 0, f.p2, EPI_RELU, B, s, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0,
-                         feat16 ? 1 : 0));
-    conv_work(P, P.c1, B, f.H2, f.W2, e, fl, by);
-    EMAVFI_STEP(rec, conv_name(P, P.c1) + " context_encoding.1", fl, by,
-                run_conv(P, P.c1, packed, f.c1, f.p2, f.H2, f.W2, f.c2, f.p4, 0, f.p4, EPI_RELU, B, s));
-    conv_work(P, P.c2, B, f.H4, f.W4, e, fl, by);
-    EMAVFI_STEP(rec, conv_name(P, P.c2) + " context_encoding.2", fl, by,
-                run_conv(P, P.c2, packed, f.c2, f.p4, f.H4, f.W4, f.c3, f.p4, 0, f.p4, EPI_RELU, B, s));
-    EMAVFI_STEP(rec, "avg_pool_partial", 0, (double)B * f.H4 * f.W4 * 4 * mid * e,
-                launch_pool_partial(f.c3, f.part, B, f.H4 * f.W4, f.p4, f.p4, f.nparts, dtype, s));
-    EMAVFI_STEP(rec, "context_linear_fold", 0, (double)B * f.nparts * 4 * mid * 4,
-                launch_ctx_finish(f.part, (const float *)((const char *)packed + P.ctx_off), f.ctx, f.table, B, mid, f.p4,
-                                  f.nparts, f.H4 * f.W4, P.m0.coutpad, P.amp ? 1 : 0, s));
+    if (const int rc = context_stage(P, packed, f.fu0, f, B, H, W, s, rec); rc != EMAVFI_OK) return rc;
     if (!rec.dry && taps && taps[1])
         if (hipMemcpyAsync(taps[1], f.ctx, (size_t)B * mid * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
             return fail(EMAVFI_E_LAUNCH, "tap ctx copy failed");
@@ -775,27 +816,7 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
     }
 
     // --- reconstruction (ema_vfi.py:144-146)
-    conv_work(P, P.r0, B, H, W, e, fl, by);
-    EMAVFI_STEP(rec, conv_name(P, P.r0) + " reconstruction.0", fl, by,
-                run_conv(P, P.r0, packed, x, P.fps, H, W, f.fA, P.p_mid, 0, P.p_mid, EPI_RELU, B, s));
-    // reconstruction.1 + .2 in one launch (conv_ring_tail.inl): .1's rows never leave the LDS.  EMAVFI_CONV_TAILFUSE=0: two
-    if (P.r1.mfma16 && P.r1.ck == 64 && P.r1.nf == 1 && P.r1.cout == 32 && P.r1.ring == 0 && P.r2.mfma16 && P.r2.ck == 32 && P.r2.nf == 1 && P.r2.cout <= 3 &&
-        !(sw & SW_NO_TAILFUSE)) {
-        double fl2, by2;
-        conv_work(P, P.r1, B, H, W, e, fl, by);
-        conv_work(P, P.r2, B, H, W, 4.0, fl2, by2);
-        const double mid_bytes = (double)B * H * W * P.r1.cout * e;
-        EMAVFI_STEP(rec, "conv3x3+tail<" + std::string(dtype_name(P.dtype)) + ",64->32->" + std::to_string(P.r2.cout) + "> reconstruction.1+.2(tanh)",
-                    fl + fl2, by + by2 - 2 * mid_bytes,
-                    run_conv(P, P.r1, packed, f.fA, P.p_mid, H, W, nullptr, 0, 0, 0, EPI_RELU, B, s, nullptr, out, C, nullptr, &P.r2, nullptr, EPI_PLANAR_TANH01));
-    } else {
-        conv_work(P, P.r1, B, H, W, e, fl, by);
-        EMAVFI_STEP(rec, conv_name(P, P.r1) + " reconstruction.1", fl, by,
-                    run_conv(P, P.r1, packed, f.fA, P.p_mid, H, W, f.fB, f.p_half, 0, f.p_half, EPI_RELU, B, s));
-        conv_work(P, P.r2, B, H, W, 4.0, fl, by);
-        EMAVFI_STEP(rec, conv_name(P, P.r2) + " reconstruction.2(tanh)", fl, by,
-                    run_conv(P, P.r2, packed, f.fB, f.p_half, H, W, nullptr, 0, 0, 0, EPI_PLANAR_TANH01, B, s, nullptr, out, C));
-    }
+    if (const int rc = reconstruction_stage(P, packed, x, f, out, B, H, W, s, rec); rc != EMAVFI_OK) return rc;
     EMAVFI_STEP(rec, "blob_guard", 0, 64.0, launch_blob_guard(guard, out, npx * (size_t)C, s));
     return EMAVFI_OK;
 }
@@ -1240,6 +1261,103 @@ int emavfi_mdcn(const float *x, const float *offset_weight, const float *offset_
     if (const int rc = attention_block(P, 0, m.blob, m.xcl, m.ycl, m.om, m.tail, in_f16, out_f16, B, H, W, s, rec); rc != EMAVFI_OK) return rc;
     EMAVFI_TRY(launch_cl_to_nchw(m.ycl, y, B, C, H, W, P.fps, 0, ydt, s), "mdcn layout out");
     return EMAVFI_OK;
+}
+
+// ---- context_encoding and reconstruction as stage-level entries (SURVEY 8b's proposed emavfi_context / emavfi_reconstruct): the model is
+// EMA_VFI(3, mid_channels, 3) - the stage does not depend on num_blocks -, the layers are packed and run exactly as emavfi_forward
+// packs and runs them (context_stage / reconstruction_stage above), the tensors cross the boundary as NCHW fp32.
+static int stage_plan(Plan &P, int mid, int dtype, int B, int H, int W, const char *what)
+{
+    if (!build_plan(P, 3, mid, 3, dtype)) return fail(EMAVFI_E_UNSUPPORTED, "%s: %s", what, P.why);
+    if (B < 1 || H < 1 || W < 1) return fail(EMAVFI_E_ARG, "%s: B, H, W must be >= 1", what);
+    if ((size_t)B * H * W >= ((size_t)1 << 31) || (size_t)H * W >= ((size_t)1 << 24) || (size_t)H * W * P.fpad * (P.amp ? sizeof(float) : (size_t)P.esize) >= ((size_t)1 << 32))
+        return fail(EMAVFI_E_ARG, "%s: B*H*W must be < 2^31, H*W < 2^24 and one sample's activation plane < 4 GiB", what);
+    return EMAVFI_OK;
+}
+struct StageBuffers { void *blob; float *zeros9; FwdBuffers f; };
+static void stage_carve(const Plan &P, Workspace &ws, StageBuffers &b, int B, int H, int W)
+{
+    b.blob = ws.take(P.total);
+    b.zeros9 = (float *)ws.take(((size_t)P.mid * 2 * P.mid * 9 + P.mid) * sizeof(float));   // a zero motion_estimation.0 for the context fold
+    carve_forward(P, ws, b.f, B, H, W);
+}
+
+size_t emavfi_context_workspace_bytes(int B, int mid_channels, int H, int W, int dtype)
+{
+    Plan P;
+    if (stage_plan(P, mid_channels, dtype, B, H, W, "context") != EMAVFI_OK) return 0;
+    Workspace ws{nullptr, 0, 0};
+    StageBuffers b;
+    stage_carve(P, ws, b, B, H, W);
+    return ws.used;
+}
+
+int emavfi_context(const float *feat, const float *const *params, float *ctx, int B, int mid_channels, int H, int W, int dtype,
+                   void *workspace, size_t workspace_bytes, void *stream)
+{
+    Plan P;
+    if (const int rc = stage_plan(P, mid_channels, dtype, B, H, W, "context"); rc != EMAVFI_OK) return rc;
+    if (!feat || !params || !ctx || !workspace) return fail(EMAVFI_E_ARG, "context: null pointer");
+    for (int i = 0; i < 8; ++i)
+        if (!params[i]) return fail(EMAVFI_E_ARG, "context: params[%d] is null", i);
+    if (!aligned16(feat) || !aligned16(workspace)) return fail(EMAVFI_E_ARG, "context: pointers must be 16-byte aligned");
+    Workspace ws{(char *)workspace, workspace_bytes, 0};
+    StageBuffers b;
+    stage_carve(P, ws, b, B, H, W);
+    if (ws.used > workspace_bytes) return fail(EMAVFI_E_WORKSPACE, "context: workspace needs %zu bytes, got %zu", ws.used, workspace_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    const int kd = P.dtype, mid = P.mid;
+    std::vector<const void *> all((size_t)emavfi_param_count(3), nullptr);
+    all[P.c0.param] = params[0]; all[P.c0.param + 1] = params[1];
+    all[P.c1.param] = params[2]; all[P.c1.param + 1] = params[3];
+    all[P.c2.param] = params[4]; all[P.c2.param + 1] = params[5];
+    if (hipMemsetAsync(b.blob, 0, P.total, s) != hipSuccess || hipMemsetAsync(b.zeros9, 0, ((size_t)mid * 2 * mid * 9 + mid) * sizeof(float), s) != hipSuccess)
+        return fail(EMAVFI_E_LAUNCH, "context: memset failed");
+    EMAVFI_TRY(pack_layer(P.c0, all.data(), b.blob, kd, s, P.amp), "context pack 0");
+    EMAVFI_TRY(pack_layer(P.c1, all.data(), b.blob, kd, s, P.amp), "context pack 1");
+    EMAVFI_TRY(pack_layer(P.c2, all.data(), b.blob, kd, s, P.amp), "context pack 2");
+    EMAVFI_TRY(launch_pack_ctx(params[6], params[7], b.zeros9, b.zeros9 + (size_t)mid * 2 * mid * 9, (float *)((char *)b.blob + P.ctx_off), mid, P.amp ? 1 : 0, s),
+               "context pack linear");
+    // `feat` as the forward stores it: channels 0..mid-1 of the fusion pixels, f16 in the bf16 model with the one-launch packs (Plan::feat16)
+    EMAVFI_TRY(launch_nchw_to_cl(feat, b.f.fu0, B, mid, H, W, P.fps, P.feat16 ? (int)EMAVFI_F16 : kd, s), "context layout in");
+    Recorder rec;
+    if (const int rc = context_stage(P, b.blob, b.f.fu0, b.f, B, H, W, s, rec); rc != EMAVFI_OK) return rc;
+    if (hipMemcpyAsync(ctx, b.f.ctx, (size_t)B * mid * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(EMAVFI_E_LAUNCH, "context: copy out failed");
+    return EMAVFI_OK;
+}
+
+size_t emavfi_reconstruct_workspace_bytes(int B, int mid_channels, int H, int W, int dtype)
+{
+    return emavfi_context_workspace_bytes(B, mid_channels, H, W, dtype);   // the same carving
+}
+
+int emavfi_reconstruct(const float *fused, const float *const *params, float *out, int B, int mid_channels, int H, int W, int dtype,
+                       void *workspace, size_t workspace_bytes, void *stream)
+{
+    Plan P;
+    if (const int rc = stage_plan(P, mid_channels, dtype, B, H, W, "reconstruct"); rc != EMAVFI_OK) return rc;
+    if (!fused || !params || !out || !workspace) return fail(EMAVFI_E_ARG, "reconstruct: null pointer");
+    for (int i = 0; i < 6; ++i)
+        if (!params[i]) return fail(EMAVFI_E_ARG, "reconstruct: params[%d] is null", i);
+    if (!aligned16(fused) || !aligned16(out) || !aligned16(workspace)) return fail(EMAVFI_E_ARG, "reconstruct: pointers must be 16-byte aligned");
+    Workspace ws{(char *)workspace, workspace_bytes, 0};
+    StageBuffers b;
+    stage_carve(P, ws, b, B, H, W);
+    if (ws.used > workspace_bytes) return fail(EMAVFI_E_WORKSPACE, "reconstruct: workspace needs %zu bytes, got %zu", ws.used, workspace_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    const int kd = P.dtype, mid = P.mid;
+    std::vector<const void *> all((size_t)emavfi_param_count(3), nullptr);
+    all[P.r0.param] = params[0]; all[P.r0.param + 1] = params[1];
+    all[P.r1.param] = params[2]; all[P.r1.param + 1] = params[3];
+    all[P.r2.param] = params[4]; all[P.r2.param + 1] = params[5];
+    if (hipMemsetAsync(b.blob, 0, P.total, s) != hipSuccess) return fail(EMAVFI_E_LAUNCH, "reconstruct: memset failed");
+    EMAVFI_TRY(pack_layer(P.r0, all.data(), b.blob, kd, s, P.amp), "reconstruct pack 0");
+    EMAVFI_TRY(pack_layer(P.r1, all.data(), b.blob, kd, s, P.amp), "reconstruct pack 1");
+    EMAVFI_TRY(pack_layer(P.r2, all.data(), b.blob, kd, s, P.amp), "reconstruct pack 2");
+    // the fusion tensor as the last attention block leaves it: mid + 3 channels in P.fps-channel pixels of the storage type
+    EMAVFI_TRY(launch_nchw_to_cl(fused, b.f.fu0, B, mid + 3, H, W, P.fps, kd, s), "reconstruct layout in");
+    Recorder rec;
+    return reconstruction_stage(P, b.blob, b.f.fu0, b.f, out, B, H, W, s, rec);
 }
 
 }  // extern "C"

@@ -47,6 +47,10 @@ _PROTOTYPES = {
     "emavfi_deform_conv2d": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
     "emavfi_mdcn_workspace_bytes": (c_size_t, [c_int] * 6),
     "emavfi_mdcn": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
+    "emavfi_context_workspace_bytes": (c_size_t, [c_int] * 5),
+    "emavfi_context": (c_int, [c_void_p, POINTER(c_void_p), c_void_p] + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
+    "emavfi_reconstruct_workspace_bytes": (c_size_t, [c_int] * 5),
+    "emavfi_reconstruct": (c_int, [c_void_p, POINTER(c_void_p), c_void_p] + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "emavfi_debug_switches": (c_int, [c_int, c_int]),
 }
 SYMBOLS = tuple(_PROTOTYPES)
@@ -276,6 +280,46 @@ def mdcn(x, offset_weight, offset_bias, dcn_weight, dcn_bias, dtype="fp32", flag
         check(L.emavfi_mdcn(x.data_ptr(), ow.data_ptr(), ob.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None, y.data_ptr(),
                             B, C, H, W, dt, flags, ws.data_ptr(), ws.numel(), _stream()), "emavfi_mdcn")
     return y
+
+
+def _stage(entry, ws_entry, x, params, out_shape, mid, dtype, what):
+    import torch
+    _require_cuda(x, *params)
+    dt = dtype_code(dtype)
+    x = _f32c(x)
+    ps = [_f32c(p) for p in params]
+    B, _, H, W = x.shape
+    L = load()
+    n = getattr(L, ws_entry)(B, mid, H, W, dt)
+    if n == 0:
+        raise RuntimeError(f"{what}: {last_error()}")
+    ws = workspace(n, x.device)
+    out = torch.empty(out_shape, device=x.device, dtype=torch.float32)
+    arr = (c_void_p * len(ps))(*[p.data_ptr() for p in ps])
+    with torch.cuda.device(x.device):
+        check(getattr(L, entry)(x.data_ptr(), ctypes.cast(arr, POINTER(c_void_p)), out.data_ptr(), B, mid, H, W, dt, ws.data_ptr(), ws.numel(), _stream()), what)
+    return out
+
+
+def context(feat, params, dtype="fp32"):
+    """context_encoding(feat) -> ctx [B, mid] (reference ema_vfi.py:79-86, :120); params: the 8 tensors of the Sequential in
+    registration order.  The launches the forward runs for the stage (include/emavfi.h, emavfi_context)."""
+    mid = feat.shape[1]
+    shapes = [(2 * mid, mid, 3, 3), (2 * mid,), (4 * mid, 2 * mid, 3, 3), (4 * mid,), (4 * mid, 4 * mid, 3, 3), (4 * mid,), (mid, 4 * mid), (mid,)]
+    if len(params) != 8 or [tuple(p.shape) for p in params] != shapes:
+        raise ValueError(f"context: 8 tensors of shapes {shapes} expected")
+    return _stage("emavfi_context", "emavfi_context_workspace_bytes", feat, params, (feat.shape[0], mid), mid, dtype, "emavfi_context")
+
+
+def reconstruct(fused, params, dtype="fp32"):
+    """reconstruction(fused) -> frame [B, 3, H, W] in [0, 1] (reference ema_vfi.py:102-107, :144-146); params: the 6 tensors of the
+    Sequential in registration order.  The launches the forward runs for the stage (include/emavfi.h, emavfi_reconstruct)."""
+    mid = fused.shape[1] - 3
+    shapes = [(mid, mid + 3, 3, 3), (mid,), (mid // 2, mid, 3, 3), (mid // 2,), (3, mid // 2, 3, 3), (3,)]
+    if len(params) != 6 or [tuple(p.shape) for p in params] != shapes:
+        raise ValueError(f"reconstruct: 6 tensors of shapes {shapes} expected")
+    return _stage("emavfi_reconstruct", "emavfi_reconstruct_workspace_bytes", fused, params, (fused.shape[0], 3, fused.shape[2], fused.shape[3]), mid, dtype,
+                  "emavfi_reconstruct")
 
 
 def forward_launches(in_channels, mid_channels, num_blocks, B, H, W, dtype):
