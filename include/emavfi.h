@@ -62,7 +62,7 @@
 extern "C" {
 #endif
 
-#define EMAVFI_VERSION 400 /* 0.4.0: the packed blob starts with a 256-byte self-describing header; emavfi_forward takes packed_bytes (round 4): re-pack */
+#define EMAVFI_VERSION 401 /* 0.4.1: context_encoding.1 / .2 re-packed for conv_wreg.inl; 0.4.0: the packed blob starts with a 256-byte self-describing header, emavfi_forward takes packed_bytes (round 4): re-pack */
 
 #define EMAVFI_F32 0
 #define EMAVFI_BF16 1

@@ -84,6 +84,8 @@ CONV_CASES = [  # (Cin, Cout, H, W, stride, act): one per reference layer shape 
     (256, 256, 9, 21, 1, 1), (64, 2, 19, 33, 1, 0), (67, 27, 16, 35, 1, 0), (67, 64, 17, 64, 1, 1),
     (64, 32, 8, 32, 1, 1), (32, 3, 21, 45, 1, 2), (8, 8, 23, 37, 1, 1), (8, 16, 23, 37, 2, 1),
     (11, 27, 5, 7, 1, 0), (35, 32, 12, 33, 1, 1), (3, 5, 1, 1, 1, 0), (16, 16, 1, 70, 1, 1), (16, 32, 70, 1, 2, 1),
+    # conv_wreg.inl (256 output channels, weights streamed into registers): several column tiles, ragged edges, 3 / 5 chunks, one-row images
+    (128, 256, 37, 131, 2, 1), (256, 256, 19, 67, 1, 1), (192, 250, 11, 40, 1, 0), (160, 256, 21, 30, 2, 0), (256, 256, 1, 33, 1, 1), (128, 256, 1, 5, 2, 1),
 ]
 
 

@@ -36,6 +36,7 @@
 #include "common.h"
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 
 // Source address of one 16-byte DMA piece: piece pc of input pixel (gy, gx) of the sample starting at gin, or the zero page when
 // the pixel lies outside the image (or `valid` is false).  32-bit offset arithmetic (a sample is < 4 GiB: checked at the API) and
@@ -973,12 +974,15 @@ template <typename T> static int launch_conv_any(const ConvParams &p, hipStream_
     return -2;  // no instantiation
 }
 
+#include "conv_wreg.inl"
+
 // 16-bit launcher (bf16 / f16): full-resolution single-chunk layers go to the persistent, weights-resident kernel
 // (CK, NF, waves): 64->64, 64->32 / 64->2, 67->27 of the mid_channels = 64 model.
 template <typename T> static int launch_conv16(const ConvParams &p, hipStream_t s, bool no_persistent)
 {
     if (p.mfma16) return launch_conv_mfma16<T>(p, s);
     if (p.ring == 1) return launch_conv_s2ring<T>(p, s);
+    if (p.ring == 4) return launch_conv_wreg<T>(p, s);
     if (p.ring >= 2) return p.w2 ? launch_conv_ring2<T>(p, s) : launch_conv_ring<T>(p, s);
     if (!no_persistent && p.stride == 1 && p.nchunk == 1 && p.npass == 1) {
         // measured at B=8 x 720p in bf16 (us per launch, tile-per-workgroup -> persistent): 64->64 670 -> 644,

@@ -88,11 +88,11 @@ struct Layer {
 // the two); only the stage-level entry emavfi_conv3x3, which packs and runs inside one call, reads them per call (the
 // parity tests compare kernels inside one process that way).  A blob packed by ANOTHER process under other switches is the
 // caller's responsibility: the Python binding keys its caches by them (emavfi/lib.py, layout_switches).
-struct LayoutEnv { bool m16_off, ring_off, s2ring_off, s2_ck64; };
+struct LayoutEnv { bool m16_off, ring_off, s2ring_off, s2_ck64, wreg_off; };
 LayoutEnv read_layout_env()
 {
     const auto off = [](const char *name) { const char *e = getenv(name); return e && e[0] == '0'; };
-    return LayoutEnv{off("EMAVFI_CONV_MFMA16"), off("EMAVFI_CONV_RING"), off("EMAVFI_CONV_S2RING"), getenv("EMAVFI_CONV_S2_CK64") != nullptr};
+    return LayoutEnv{off("EMAVFI_CONV_MFMA16"), off("EMAVFI_CONV_RING"), off("EMAVFI_CONV_S2RING"), getenv("EMAVFI_CONV_S2_CK64") != nullptr, off("EMAVFI_CONV_WREG")};
 }
 const LayoutEnv &process_layout_env()
 {
@@ -106,7 +106,7 @@ bool pack_f16_chain();
 unsigned layout_tag_of(const LayoutEnv &e)
 {
     return (e.m16_off ? 1u : 0u) | (e.ring_off ? 2u : 0u) | (e.s2ring_off ? 4u : 0u) | (e.s2_ck64 ? 8u : 0u) | (pack_f16_chain() ? 0u : 16u) |
-           (deform16_can_fuse_offset_conv(80, 3, 67, 80, 1) ? 0u : 32u);   // (EMAVFI_NO_FUSED_OFFSET, latched in deform_bf16.hip)
+           (deform16_can_fuse_offset_conv(80, 3, 67, 80, 1) ? 0u : 32u) | (e.wreg_off ? 64u : 0u);   // (EMAVFI_NO_FUSED_OFFSET, latched in deform_bf16.hip)
 }
 
 bool conv_geometry(Layer &L, int esize, const LayoutEnv &env)
@@ -137,6 +137,16 @@ bool conv_geometry(Layer &L, int esize, const LayoutEnv &env)
         L.ring = L.cin_take == 64 ? 2 : 3;
         L.ck = L.cin_pad; L.nchunk = 1; L.nf = 2; L.npass = 1; L.coutpad = 64;
         L.w_bytes = (size_t)9 * 4 * 2 * 1024 + (L.ring == 3 ? 3 * 2 * 1024 : 0);
+        L.mfma16 = false;
+        return true;
+    }
+    // 256 output channels from >= 128 inputs (context_encoding.1 / .2 at mid_channels 64): conv_wreg.inl - all eight output fragments in one
+    // pass, weights streamed into registers.  EMAVFI_CONV_WREG=0 keeps round 3's plans (changes the packing: set before packing)
+    if (esize == 2 && L.cout > 224 && L.cout <= 256 && L.cin_pad >= 128 && !env.wreg_off && !s2_ck64 &&
+        ((L.stride == 1 && L.cin_pad % 64 == 0) || (L.stride == 2 && L.cin_pad % 32 == 0))) {
+        L.ring = 4;
+        L.ck = L.stride == 1 ? 64 : 32; L.nchunk = L.cin_pad / L.ck; L.nf = 8; L.npass = 1; L.coutpad = 256;
+        L.w_bytes = (size_t)L.nchunk * 9 * (L.ck / 16) * 8 * 1024;
         L.mfma16 = false;
         return true;
     }
