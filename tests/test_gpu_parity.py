@@ -640,6 +640,34 @@ def test_fused_block_pair_equals_the_two_launch_path(dtype, shape, switch):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "amp16"])
+@pytest.mark.parametrize("shape", [(2, 75, 131), (1, 1, 7), (1, 4, 4), (1, 13, 129), (3, 40, 125), (1, 360, 640), (1, 509, 517)])
+def test_pool_fused_context_conv_equals_the_stored_tensor_path(dtype, shape, switch):
+    """16-bit modes at mid_channels 64: context_encoding.2 (csrc/conv_wreg.inl) does not store its output - AdaptiveAvgPool2d is its only
+    reader (ema_vfi.py:82-83) - but writes the per-channel sums of every 4 x 32 pixel tile, which avg_pool_partial and
+    context_linear_fold add in a fixed order.  EMAVFI_CONV_POOLFUSE=0 stores the tensor and pools it as before.  The same rounded
+    values are summed in another order: ctx agrees to fp32 summation error (amp16: to one fp16 unit of the mean / Linear output), the
+    frame to what that moves it.  Image sizes with partial tiles in both directions, fewer pixels than one tile, many tiles."""
+    B, H, W = shape
+    sd = synth.synthetic_state_dict(seed=5)
+    f1, f2 = (t.to(DEV) for t in synth.synthetic_frames(35, B, H, W, "natural"))
+    ctxs, outs = [], []
+    for flag in ("1", "0"):
+        switch(lib.SW_NO_POOLFUSE, flag == "0")
+        m = make_model(sd, dtype=dtype)
+        with torch.no_grad():
+            out, taps = m(f1, f2, return_taps=True)
+        ctxs.append(taps["ctx"].clone()); outs.append(out.clone())
+        names = [n for n, _, _ in lib.forward_launches(3, 64, 3, B, H, W, dtype)]
+        assert sum("pool (tile sums)" in n for n in names) == int(flag)
+    assert torch.isfinite(ctxs[0]).all()
+    scale = ctxs[1].abs().max().item()
+    err = (ctxs[0] - ctxs[1]).abs().max().item()
+    assert err <= (2e-3 if dtype == "amp16" else 2e-6) * max(scale, 1e-3), (err, scale)
+    # (a ctx that moves by 1e-7 flips a few storage-type roundings in motion_estimation.0: single pixels of the frame move by some units of bf16 / fp16)
+    assert (outs[0] - outs[1]).abs().max().item() <= {"bf16": 1.5e-2, "fp16": 2e-3, "amp16": 4e-3}[dtype]
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("shape", [(2, 75, 131), (1, 1, 7), (1, 2, 62), (1, 3, 63), (1, 17, 124), (3, 40, 125), (1, 360, 640)])
 def test_fused_reconstruction_tail_equals_the_two_launch_path(dtype, shape, switch):

@@ -184,7 +184,8 @@ struct ConvParams {
                          // sigmoid / tanh / (t+1)/2 round after every op, as fp16 tensors do under autocast
     int mfma16;          // weights packed for v_mfma_f32_16x16x32 (conv3x3_persist16_kernel): [tap][k32][cout16 block][lane][16 B]
     int ring;            // weights in registers, input rows through an LDS ring: 1 = conv3x3_s2ring_kernel (64 -> 128 at stride 2, context_encoding.0),
-                         // 2 = conv3x3_ring_kernel (64 -> 64), 3 = the same with the im2col tail (65..67 -> 64: reconstruction.0)
+                         // 2 = conv3x3_ring_kernel (64 -> 64), 3 = the same with the im2col tail (65..67 -> 64: reconstruction.0);
+                         // 4 = conv3x3_wreg_kernel (conv_wreg.inl: -> 256 channels, weights streamed into registers, input tile in LDS)
     const void *w2;          // conv_ring2.inl (ring == 2, both layers 64 -> 64): a SECOND conv_block behind this one in the same launch - its packed
     const float *bias2;      // weights (ring layout) and bias; `out*` / cstore / out_alt / out_fill then describe the second layer's output
     const void *head_w;      // conv_ring.inl, ring == 2 only: fuse a 64 -> nplanes (<= 2) planar head (its weights in the 16x16x32 packing,
@@ -197,6 +198,8 @@ struct ConvParams {
                              // the layer ~240 us at B = 8 x 720p; the bytes belong to nobody yet (the warp writes them later, or never)
     int epi2;                // conv_ring_tail.inl (64 -> 32 -> nplanes <= 3, this layer packed mfma16 with nf == 1): the head's epilogue
                              // (EPI_PLANAR or EPI_PLANAR_TANH01)
+    float *pool_part;    // conv_wreg.inl (ring == 4, 256 channels): do NOT store the layer's output, write the per-channel sums of every 4 x 32 pixel
+                         // tile instead: [B][tiles][256] floats (context_encoding.2 feeds AdaptiveAvgPool2d and nothing else)
     int in_pieces;       // 16-byte pieces of an input pixel (single-chunk layers) that exist in memory; 0 = all CK of them.
                          // Pieces beyond read as zeros: the 72-channel fusion buffers feed CK = 80 layers this way.
 };
@@ -244,6 +247,7 @@ enum {
     SW_NO_CONV_LIGHT = 16,       // EMAVFI_CONV_LIGHT=0: planar heads on conv3x3_persist16_kernel
     SW_NO_PERSISTENT_CONV = 32,  // EMAVFI_NO_PERSISTENT_CONV: tile-per-workgroup kernel where the persistent one is the default
     SW_NO_RING2 = 64,            // EMAVFI_CONV_RING2=0: conv_block_1 + conv_block_2 / motion_estimation.0 + .1 + .2 as separate launches
+    SW_NO_POOLFUSE = 128,        // EMAVFI_CONV_POOLFUSE=0: context_encoding.2 stores its output and avg_pool_partial reads it back
 };
 unsigned emavfi_switches();
 

@@ -42,6 +42,7 @@ void init_switches()
         if (off("EMAVFI_CONV_TAILFUSE")) v |= SW_NO_TAILFUSE;
         if (off("EMAVFI_CONV_LIGHT")) v |= SW_NO_CONV_LIGHT;
         if (off("EMAVFI_CONV_RING2")) v |= SW_NO_RING2;
+        if (off("EMAVFI_CONV_POOLFUSE")) v |= SW_NO_POOLFUSE;
         if (getenv("EMAVFI_NO_PERSISTENT_CONV") != nullptr) v |= SW_NO_PERSISTENT_CONV;
         g_switches.store(v, std::memory_order_relaxed);
     });
@@ -347,12 +348,16 @@ bool build_plan(Plan &P, int in_ch, int mid, int nb, int dtype)
     return true;
 }
 
+#if defined(EMAVFI_DEFORM_STAMPS) && EMAVFI_DEFORM_STAMPS
+unsigned long long *debug_stamp_buffer();
+#endif
 int run_conv(const Plan &P, const Layer &L, const void *packed, const void *in, int in_ps, int Hin, int Win, void *out,
              int out_ps, int out_coff, int cstore, int epi, int B, hipStream_t s, const float *bias_table = nullptr,
              float *planar = nullptr, int nplanes = 0, const void *zeros = nullptr, const Layer *head = nullptr,
-             const FirstParams *first = nullptr, int epi2 = 0, int out_alt = 0, const Layer *second = nullptr)
+             const FirstParams *first = nullptr, int epi2 = 0, int out_alt = 0, const Layer *second = nullptr, float *pool_part = nullptr)
 {
     ConvParams c{};
+    c.pool_part = pool_part;
     if (second) {   // conv_ring2.inl: `second` runs behind L in the same launch; out / out_ps / cstore / out_alt are ITS output's
         c.w2 = (const char *)packed + second->w_off;
         c.bias2 = (const float *)((const char *)packed + second->b_off);
@@ -378,6 +383,9 @@ int run_conv(const Plan &P, const Layer &L, const void *packed, const void *in, 
     c.B = B; c.nchunk = L.nchunk; c.npass = L.npass; c.cstore = cstore;
     c.epi = epi; c.nplanes = nplanes; c.bias_mode = bias_table ? 1 : 0;
     c.ck = L.ck; c.nf = L.nf; c.stride = L.stride; c.mfma16 = L.mfma16 ? 1 : 0; c.ring = L.ring;
+#if defined(EMAVFI_DEFORM_STAMPS) && EMAVFI_DEFORM_STAMPS
+    if (L.ring == 4 && !planar) c.out_planar = reinterpret_cast<float *>(debug_stamp_buffer());   // diagnostic build: conv_wreg.inl's stamps (tools/wreg_stamps.py)
+#endif
     if (first) return P.dtype == EMAVFI_F16 ? launch_conv_ringfirst_f16(*first, c, s) : launch_conv_ringfirst_bf16(*first, c, s);
     if (L.f16_of_bf16 && !L.deform) return launch_conv3x3_f16(c, s);   // feat16: f16 activations in, bf16-rounded weights stored as f16
     return P.dtype == EMAVFI_F32 ? launch_conv3x3_f32(c, s) : P.dtype == EMAVFI_F16 ? launch_conv3x3_f16(c, s) : launch_conv3x3_bf16(c, s);
@@ -443,6 +451,8 @@ struct FwdBuffers {
     void *in16, *fA, *fB, *fu0, *fu1, *c1, *c2, *c3;
     float *fuF0, *fuF1;  // amp: fp32 copies of the fusion tensor (input / output of the fp32 DCN)
     float *part, *ctx, *table, *flow, *om;
+    float *tpart;        // context_encoding.2 fused with the pool (conv_wreg.inl): per-tile channel sums [B][ntiles][p4]
+    int ntiles, nparts2; // ... and the partial sums avg_pool_partial reduces them to
     int nparts, H2, W2, H4, W4, p2, p4, p_half;
 };
 
@@ -462,6 +472,10 @@ void carve_forward(const Plan &P, Workspace &ws, FwdBuffers &f, int B, int H, in
     f.c2 = ws.take((size_t)B * npix4 * f.p4 * e);
     f.c3 = ws.take((size_t)B * npix4 * f.p4 * e);
     f.part = (float *)ws.take((size_t)B * f.nparts * f.p4 * sizeof(float));
+    f.ntiles = ((f.W4 + 31) / 32) * ((f.H4 + 3) / 4);   // conv_wreg_tiles()
+    f.nparts2 = f.ntiles >= 32 ? (f.ntiles / 16 < 32 ? f.ntiles / 16 : 32) : 1;
+    if (f.nparts2 > f.nparts) f.nparts2 = f.nparts;
+    f.tpart = P.c2.ring == 4 ? (float *)ws.take((size_t)B * f.ntiles * f.p4 * sizeof(float)) : nullptr;
     f.ctx = (float *)ws.take((size_t)B * P.mid * sizeof(float));
     f.table = (float *)ws.take((size_t)B * 16 * P.m0.coutpad * sizeof(float));
     f.flow = (float *)ws.take(px * 2 * sizeof(float));
@@ -591,13 +605,25 @@ int context_stage(const Plan &P, const void *packed, const void *feat_cl, const 
     EMAVFI_STEP(rec, conv_name(P, P.c1) + " context_encoding.1", fl, by,
                 run_conv(P, P.c1, packed, f.c1, f.p2, f.H2, f.W2, f.c2, f.p4, 0, f.p4, EPI_RELU, B, s));
     conv_work(P, P.c2, B, f.H4, f.W4, e, fl, by);
-    EMAVFI_STEP(rec, conv_name(P, P.c2) + " context_encoding.2", fl, by,
-                run_conv(P, P.c2, packed, f.c2, f.p4, f.H4, f.W4, f.c3, f.p4, 0, f.p4, EPI_RELU, B, s));
-    EMAVFI_STEP(rec, "avg_pool_partial", 0, (double)B * f.H4 * f.W4 * 4 * mid * e,
-                launch_pool_partial(f.c3, f.part, B, f.H4 * f.W4, f.p4, f.p4, f.nparts, dtype, s));
-    EMAVFI_STEP(rec, "context_linear_fold", 0, (double)B * f.nparts * 4 * mid * 4,
+    // conv_wreg.inl at the reference width: the layer's only reader is the pool, so the kernel writes per-tile channel sums instead of the
+    // tensor (no 236 MB store + read at B = 8 x 720p); avg_pool_partial then adds tiles instead of pixels.  EMAVFI_CONV_POOLFUSE=0: A/B
+    const bool poolfuse = P.c2.ring == 4 && f.p4 == 256 && !(emavfi_switches() & SW_NO_POOLFUSE);
+    if (poolfuse) {
+        EMAVFI_STEP(rec, conv_name(P, P.c2) + " context_encoding.2 + pool (tile sums)", fl, by - (double)B * f.H4 * f.W4 * 4 * mid * e,
+                    run_conv(P, P.c2, packed, f.c2, f.p4, f.H4, f.W4, nullptr, f.p4, 0, f.p4, EPI_RELU, B, s, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, nullptr,
+                             f.tpart));
+        EMAVFI_STEP(rec, "avg_pool_partial", 0, (double)B * f.ntiles * 4 * mid * 4,
+                    launch_pool_partial(f.tpart, f.part, B, f.ntiles, f.p4, f.p4, f.nparts2, EMAVFI_F32, s));
+    } else {
+        EMAVFI_STEP(rec, conv_name(P, P.c2) + " context_encoding.2", fl, by,
+                    run_conv(P, P.c2, packed, f.c2, f.p4, f.H4, f.W4, f.c3, f.p4, 0, f.p4, EPI_RELU, B, s));
+        EMAVFI_STEP(rec, "avg_pool_partial", 0, (double)B * f.H4 * f.W4 * 4 * mid * e,
+                    launch_pool_partial(f.c3, f.part, B, f.H4 * f.W4, f.p4, f.p4, f.nparts, dtype, s));
+    }
+    const int np = poolfuse ? f.nparts2 : f.nparts;
+    EMAVFI_STEP(rec, "context_linear_fold", 0, (double)B * np * 4 * mid * 4,
                 launch_ctx_finish(f.part, packed ? (const float *)((const char *)packed + P.ctx_off) : nullptr, f.ctx, f.table, B, mid, f.p4,
-                                  f.nparts, f.H4 * f.W4, P.m0.coutpad, P.amp ? 1 : 0, s));
+                                  np, f.H4 * f.W4, P.m0.coutpad, P.amp ? 1 : 0, s));
     return EMAVFI_OK;
 }
 
