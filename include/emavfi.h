@@ -120,8 +120,8 @@ int emavfi_pack_weights(int in_channels, int mid_channels, int num_blocks,
  * caches on disk and broadcasts between ranks, so it has to say what it is.
  *
  * emavfi_layout_tag: bit mask of the process-wide environment switches the packed LAYOUT depends on (read once per process):
- *   1 EMAVFI_CONV_MFMA16=0, 2 EMAVFI_CONV_RING=0, 4 EMAVFI_CONV_S2RING=0, 8 EMAVFI_CONV_S2_CK64, 16 EMAVFI_PACK_F16_CHAIN=0,
- *   32 EMAVFI_NO_FUSED_OFFSET.  Cache keys must use it (not the environment, which may have changed since the library latched it).
+ *   1 EMAVFI_CONV_MFMA16=0, 2 EMAVFI_CONV_RING=0, 4 EMAVFI_CONV_S2RING=0, (8: unused since 0.4.1), 16 EMAVFI_PACK_F16_CHAIN=0,
+ *   32 EMAVFI_NO_FUSED_OFFSET, 64 EMAVFI_CONV_WREG=0.  Cache keys must use it (not the environment, which may have changed since the library latched it).
  * emavfi_packed_check: verifies header (magic, version, model, dtype, layout tag, size) and checksum of a blob in device OR host
  *   memory; EMAVFI_E_ARG with a message naming the mismatch.  THE ONE ENTRY THAT SYNCHRONISES (it copies a device blob to the
  *   host): call it when a blob arrives - from a file, another rank, another process - not per frame.

@@ -280,6 +280,42 @@ def test_ring_kernels_prime_their_rings_with_the_steady_state_pattern(tmp_path):
     assert len(seen) == 14, sorted(seen)
 
 
+def test_wreg_kernels_count_their_waits_exactly(tmp_path):
+    """csrc/conv_wreg.inl (context_encoding.1 / .2) streams its weights with inline-assembly global_load_dwordx4 and its input tile with
+    inline-assembly LDS-DMA, both behind COUNTED `s_waitcnt vmcnt(N)` that hipcc knows nothing about: "step s's two fragments have
+    landed" is N = 2 P, or 2 P + NI in the first P steps of a chunk (the next chunk's NI DMA instructions are younger than those
+    steps' loads).  The counts only hold while the k loop contains exactly those instructions - a spill (scratch), a flat access, an
+    ordinary load or a store inside it would shift every count, silently.  Checked on the shipped code objects (S = 1: P = 3, NI = 8,
+    36 steps per chunk; S = 2: P = 4, NI = 10, 18 steps), together with the register budget that lets two workgroups share a CU."""
+    import re
+    seen = {}
+    for dis in _device_disassembly(tmp_path):
+        for name, body in re.findall(r"<(_Z19conv3x3_wreg_kernel\w+)>:\n(.*?)(?=\n\n|\Z)", dis, re.S):
+            S = int(re.search(r"Li(\d)EEv", name).group(1))
+            P, NI, SPC = (3, 8, 36) if S == 1 else (4, 10, 18)
+            ins, _ = _loops_of(body)
+            txt = [t for _, t in ins]
+            first_bar = txt.index("s_barrier")
+            last_mfma = max(i for i, t in enumerate(txt) if t.startswith("v_mfma"))
+            loop = txt[first_bar:last_mfma + 1]
+            assert sum(t.startswith("v_mfma_f32_32x32x16") for t in loop) == 2 * SPC * 8, name            # two copies of the chunk body (not-last, last)
+            assert sum(t.startswith("global_load_lds_dwordx4") for t in loop) == NI, name                # the next chunk's DMA, in the not-last copy only
+            wl = [t for t in loop if t.startswith("global_load_dwordx4")]
+            assert len(wl) == 2 * (2 * SPC - P) and all(re.search(r", s\[\d+:\d+\]", t) for t in wl), (name, len(wl))   # weights: saddr form, two per step
+            other = [t for t in loop if re.match(r"(global_load_dword\b|global_load_ubyte|global_load_ushort|global_store|buffer_|flat_|scratch_)", t)]
+            assert not other, (name, other[:4])
+            waits = [int(m.group(1)) for t in loop for m in [re.match(r"s_waitcnt vmcnt\((\d+)\)", t)] if m]
+            want = [2 * P + NI] * P + [2 * P] * (SPC - P) + [2 * P]                                     # not-last chunk: its steps, then the boundary wait
+            want += [2 * min(P, SPC - 1 - sc) for sc in range(SPC)]                                     # last chunk: the prefetch runs dry
+            # hipcc adds its own waits for the bias loads (behind the first barrier, and a vmcnt(0) on the one-chunk entry path between the
+            # two copies; they only strengthen): compare the non-zero counts' tail, and the very last wait (the last step: nothing younger)
+            nz, want_nz = [w for w in waits if w], [w for w in want if w]
+            assert nz[-len(want_nz):] == want_nz and waits[-1] == 0, (name, nz[-len(want_nz):][:8], want_nz[:8], waits[-3:])
+            assert loop.count("s_barrier") == 2, name                                                     # the prologue's and the chunk boundary's
+            seen[name] = S
+    assert sorted(seen.values()) == [1, 1, 2, 2], sorted(seen)     # bf16 and f16, stride 1 and 2
+
+
 def test_packed_cache_file_carries_a_checksum(tmp_path):
     """ADVICE r2: the on-disk packed-weight cache trusted any file of the right size.  The file is now blob + sha256(blob);
     a flipped byte, a truncated file or a file of the old format is ignored (the caller re-packs and overwrites it)."""

@@ -64,6 +64,11 @@ def label(k):
     m = re.match(r"_Z21conv3x3_s2ring_kernelI(DF16b|DF16_)", k)
     if m:  # context_encoding.0: weights in registers, input rows through an LDS ring (csrc/conv3x3.inl)
         return f"conv3x3<{'bf16' if m.group(1) == 'DF16b' else 'f16'},ck=64,nf=4,s=2>"
+    m = re.match(r"_Z19conv3x3_wreg_kernelI(DF16b|DF16_)Li(1|2)E", k)
+    if m:  # context_encoding.1 / .2: all 256 output channels in one pass, weights streamed into registers (csrc/conv_wreg.inl)
+        return f"conv3x3<{'bf16' if m.group(1) == 'DF16b' else 'f16'},ck={'64' if m.group(2) == '1' else '32'},nf=8,s={m.group(2)}>"
+    if "conv3x3_wreg_kernel<" in k:   # (garbled demangling of the bf16 stride-1 instance)
+        return "conv3x3<bf16,ck=64,nf=8,s=1>"
     m = re.match(r"_Z14conv3x3_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)EEv", k)
     if m:
         return f"conv3x3<{'bf16' if m.group(1) == 'DF16b' else 'f32'},ck={m.group(2)},nf={m.group(3)},s={m.group(4)}>"

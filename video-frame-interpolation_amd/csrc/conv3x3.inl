@@ -967,8 +967,8 @@ template <typename T> static int launch_conv_any(const ConvParams &p, hipStream_
 #define X(CK_, NF_, ST_) \
     if (p.ck == CK_ && p.nf == NF_ && p.stride == ST_) return launch_conv_inst<T, CK_, NF_, ST_>(p, s);
     EMAVFI_CONV_INSTANCES(X)
-    if constexpr (sizeof(T) == 2) {  // 16-bit types only: stride-2 layers with 64-channel chunks (the fp32 tiles exceed the LDS)
-        X(32, 8, 2) X(64, 4, 2) X(64, 8, 2)
+    if constexpr (sizeof(T) == 2) {  // 16-bit types only: eight output fragments in one pass (EMAVFI_CONV_WREG=0: context_encoding.1)
+        X(32, 8, 2)
     }
 #undef X
     return -2;  // no instantiation

@@ -55,8 +55,8 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 // ---- which (CK, NF, stride) / (CK, NF) instantiations exist (keep in sync with the .inl lists) ----
 const int kConvInst[][3] = {{16, 1, 1}, {16, 2, 1}, {32, 1, 1}, {48, 1, 1}, {64, 1, 1}, {64, 2, 1},
                             {64, 4, 1}, {80, 1, 1}, {80, 2, 1}, {16, 1, 2}, {32, 2, 2}, {32, 4, 2}};
-// 16-bit types only (the fp32 tiles would not fit the LDS): stride-2 layers with 64-channel chunks
-const int kConvInst16[][3] = {{32, 8, 2}, {64, 4, 2}, {64, 8, 2}};
+// 16-bit types only: all eight output fragments of a stride-2 layer in one pass (128 accumulator registers)
+const int kConvInst16[][3] = {{32, 8, 2}};
 const int kDeformInst[][2] = {{16, 1}, {32, 1}, {48, 2}, {80, 3}};
 
 bool conv_inst_exists(int ck, int nf, int st, int esize)
@@ -89,11 +89,11 @@ struct Layer {
 // the two); only the stage-level entry emavfi_conv3x3, which packs and runs inside one call, reads them per call (the
 // parity tests compare kernels inside one process that way).  A blob packed by ANOTHER process under other switches is the
 // caller's responsibility: the Python binding keys its caches by them (emavfi/lib.py, layout_switches).
-struct LayoutEnv { bool m16_off, ring_off, s2ring_off, s2_ck64, wreg_off; };
+struct LayoutEnv { bool m16_off, ring_off, s2ring_off, wreg_off; };
 LayoutEnv read_layout_env()
 {
     const auto off = [](const char *name) { const char *e = getenv(name); return e && e[0] == '0'; };
-    return LayoutEnv{off("EMAVFI_CONV_MFMA16"), off("EMAVFI_CONV_RING"), off("EMAVFI_CONV_S2RING"), getenv("EMAVFI_CONV_S2_CK64") != nullptr, off("EMAVFI_CONV_WREG")};
+    return LayoutEnv{off("EMAVFI_CONV_MFMA16"), off("EMAVFI_CONV_RING"), off("EMAVFI_CONV_S2RING"), off("EMAVFI_CONV_WREG")};
 }
 const LayoutEnv &process_layout_env()
 {
@@ -106,21 +106,17 @@ const LayoutEnv &process_layout_env()
 bool pack_f16_chain();
 unsigned layout_tag_of(const LayoutEnv &e)
 {
-    return (e.m16_off ? 1u : 0u) | (e.ring_off ? 2u : 0u) | (e.s2ring_off ? 4u : 0u) | (e.s2_ck64 ? 8u : 0u) | (pack_f16_chain() ? 0u : 16u) |
+    return (e.m16_off ? 1u : 0u) | (e.ring_off ? 2u : 0u) | (e.s2ring_off ? 4u : 0u) | (pack_f16_chain() ? 0u : 16u) |   // (bit 3 was round 2's EMAVFI_CONV_S2_CK64 experiment, removed in round 4)
+          
            (deform16_can_fuse_offset_conv(80, 3, 67, 80, 1) ? 0u : 32u) | (e.wreg_off ? 64u : 0u);   // (EMAVFI_NO_FUSED_OFFSET, latched in deform_bf16.hip)
 }
 
 bool conv_geometry(Layer &L, int esize, const LayoutEnv &env)
 {
     L.cin_pad = rup(L.cin_take, 16);
-    // Stride-2 layers: 32-channel chunks, two workgroups per CU.  PMC shows 2.6 GB of HBM reads per launch for 0.7 GB of
-    // input: a pixel's record is fetched in 64-byte quarters several microseconds apart (chunk loop) and once per output
-    // pass, each time a whole 128-byte line.  The plan that reads every record once - 64-channel chunks, all output
-    // channels in one pass (EMAVFI_CONV_S2_CK64=1, 16-bit types) - needs a 85 KiB tile + 32-64 KiB of weights, i.e. one
-    // 4-wave workgroup per CU, and measured SLOWER (64->128: 757 vs 513 us, 128->256: 534 vs 513 us at B=8 x 720p):
-    // these layers are not bound by the over-fetch but by how little of a tile's DMA / MFMA / store phases one
-    // workgroup per CU can overlap.  Kept as an experiment switch, not the default.
-    const bool s2_ck64 = env.s2_ck64;
+    // Stride-2 layers on the tile kernel: 32-channel chunks, two workgroups per CU (round 2 measured 64-channel chunks - every record read
+    // once, but one workgroup per CU - SLOWER: 757 vs 513 us, 534 vs 513 us; that experiment and its instances were removed in round 4,
+    // when conv_wreg.inl took the 256-channel layers)
     // 64 -> 128 at stride 2 (context_encoding.0): one 64-channel chunk, each wave keeps one output fragment's weights in registers
     // (conv3x3.inl, conv3x3_s2ring_kernel); EMAVFI_CONV_S2RING=0 keeps the 32-channel-chunk plan (changes the packing: set before packing)
     const bool s2r_off = env.s2ring_off;
@@ -143,7 +139,7 @@ bool conv_geometry(Layer &L, int esize, const LayoutEnv &env)
     }
     // 256 output channels from >= 128 inputs (context_encoding.1 / .2 at mid_channels 64): conv_wreg.inl - all eight output fragments in one
     // pass, weights streamed into registers.  EMAVFI_CONV_WREG=0 keeps round 3's plans (changes the packing: set before packing)
-    if (esize == 2 && L.cout > 224 && L.cout <= 256 && L.cin_pad >= 128 && !env.wreg_off && !s2_ck64 &&
+    if (esize == 2 && L.cout > 224 && L.cout <= 256 && L.cin_pad >= 128 && !env.wreg_off &&
         ((L.stride == 1 && L.cin_pad % 64 == 0) || (L.stride == 2 && L.cin_pad % 32 == 0))) {
         L.ring = 4;
         L.ck = L.stride == 1 ? 64 : 32; L.nchunk = L.cin_pad / L.ck; L.nf = 8; L.npass = 1; L.coutpad = 256;
@@ -151,9 +147,7 @@ bool conv_geometry(Layer &L, int esize, const LayoutEnv &env)
         L.mfma16 = false;
         return true;
     }
-    const bool s2_wide = L.stride == 2 && esize == 2 && L.cin_pad % 64 == 0 && s2_ck64;
-    if (s2_wide) L.ck = 64;
-    else if (L.stride == 2) L.ck = (L.cin_pad % 32 == 0) ? 32 : 16;
+    if (L.stride == 2) L.ck = (L.cin_pad % 32 == 0) ? 32 : 16;
     else if (L.cin_pad <= 80) L.ck = L.cin_pad;
     else if (L.cin_pad % 64 == 0) L.ck = 64;
     else return false;
@@ -163,20 +157,13 @@ bool conv_geometry(Layer &L, int esize, const LayoutEnv &env)
     // 16-bit stride-2 layers with >= 256 output channels take all of them in ONE pass (8 fragments, 128 accumulator
     // registers per lane): every extra pass re-reads the whole input from HBM (FETCH_SIZE calibration,
     // tools/microbench/fetch_calib.hip: reading 64 bytes of every record fetches every 128-byte line)
-    if (L.stride == 2 && esize == 2 && frags % 8 == 0 && (L.ck == 32 || s2_wide)) L.nf = 8;
+    if (L.stride == 2 && esize == 2 && frags % 8 == 0 && L.ck == 32) L.nf = 8;
     if (L.stride == 2 && L.ck == 16) L.nf = 1;
     if (L.stride == 2 && L.ck == 32 && L.nf == 1) { L.ck = 16; L.nchunk = L.cin_pad / 16; }
     L.npass = frags / L.nf;
     L.coutpad = frags * 32;
     // fall back to narrower fragments if the preferred width has no instantiation
     while (!conv_inst_exists(L.ck, L.nf, L.stride, esize) && L.nf > 1) { L.nf /= 2; L.npass = frags / L.nf; }
-    if (!conv_inst_exists(L.ck, L.nf, L.stride, esize) && s2_wide) {  // e.g. 64 -> 32 stride 2: back to the 32-channel plan
-        L.ck = 32; L.nchunk = L.cin_pad / 32;
-        L.nf = (frags % 4 == 0) ? 4 : (frags % 2 == 0) ? 2 : 1;
-        if (L.nf == 1) { L.ck = 16; L.nchunk = L.cin_pad / 16; }
-        L.npass = frags / L.nf;
-        while (!conv_inst_exists(L.ck, L.nf, L.stride, esize) && L.nf > 1) { L.nf /= 2; L.npass = frags / L.nf; }
-    }
     if (!conv_inst_exists(L.ck, L.nf, L.stride, esize)) return false;
     L.w_bytes = (size_t)L.npass * L.nchunk * 9 * (L.ck * esize / 32) * L.nf * 1024;
     // full-resolution 64-channel layers with two output fragments: the 16x16x32 MFMA shape (conv3x3.inl, conv3x3_persist16_kernel).
@@ -979,7 +966,7 @@ int emavfi_packed_check(int in_channels, int mid_channels, int num_blocks, int d
         return fail(EMAVFI_E_ARG, "packed_check: blob is for EMA_VFI(%u, %u, %u), not (%d, %d, %d)", got.in_ch, got.mid, got.nb, in_channels, mid_channels, num_blocks);
     if (got.dtype != want.dtype) return fail(EMAVFI_E_ARG, "packed_check: blob was packed for dtype %u, asked for %d", got.dtype, dtype);
     if (got.layout_tag != want.layout_tag)
-        return fail(EMAVFI_E_ARG, "packed_check: blob was packed under layout switches 0x%x, this process runs 0x%x (EMAVFI_CONV_MFMA16 / _RING / _S2RING / _S2_CK64 / EMAVFI_PACK_F16_CHAIN / EMAVFI_NO_FUSED_OFFSET)",
+        return fail(EMAVFI_E_ARG, "packed_check: blob was packed under layout switches 0x%x, this process runs 0x%x (EMAVFI_CONV_MFMA16 / _RING / _WREG / _S2RING / _S2_CK64 / EMAVFI_PACK_F16_CHAIN / EMAVFI_NO_FUSED_OFFSET)",
                     got.layout_tag, want.layout_tag);
     if (got.header_bytes != want.header_bytes || got.total_bytes != want.total_bytes)
         return fail(EMAVFI_E_ARG, "packed_check: blob size fields (%u, %llu) do not match this build's layout (%u, %llu)", got.header_bytes,
