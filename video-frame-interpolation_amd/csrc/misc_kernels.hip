@@ -704,6 +704,56 @@ __global__ __launch_bounds__(256) void warp_tiled_kernel(const float *__restrict
         }
     }
     const float wden = (float)max(W - 1, 1), hden = (float)max(H - 1, 1);
+    if constexpr (std::is_same<T, bf16_t>::value || std::is_same<T, half_t>::value) {
+        if (ps == 8 && coff == 0) {
+            // The forward's 16-bit variant (compact 8-channel tail of the fusion input, 16 bytes per pixel): a wave takes whole ROWS of the
+            // tile, lane = column.  A store instruction then writes 1 KiB of consecutive addresses (the 4-pixels-per-thread mapping
+            // below wrote 16 bytes of every 64: four partial passes over each line), the corner reads of a wave are consecutive dwords
+            // of the window (conflict-free for a smooth flow; lanes four pixels apart were a four-way bank conflict) and the flow loads
+            // are 256 contiguous bytes per instruction.  Same warp_tap / warp_sample arithmetic per pixel: identical results.
+            constexpr int NR = TH / 4;
+            float gx[NR], gy[NR];
+            const int x = tx + lane;
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {   // while the DMA is in flight
+                const int y = ty + wave + 4 * k;
+                const bool ok = y < H && x < W;
+                const size_t pix = (size_t)(ok ? y : 0) * W + (ok ? x : 0);
+                gx[k] = flow[((size_t)b * 2) * plane + pix];
+                gy[k] = flow[((size_t)b * 2 + 1) * plane + pix];
+            }
+            __syncthreads();
+            typedef __attribute__((ext_vector_type(8))) T vec8;
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {
+                const int y = ty + wave + 4 * k;
+                if (y >= H || x >= W) continue;
+                const WarpTap t = warp_tap(x, y, gx[k], gy[k], H, W, wden, hden);
+                const bool inside = t.ya >= wy0 && t.yb <= wy0 + WR - 1 && t.xa >= wx0 && t.xb <= wx0 + WC - 1;
+                float v[C];
+                if (inside) {
+                    const int l00 = (t.ya - wy0) * WC + (t.xa - wx0), l01 = (t.ya - wy0) * WC + (t.xb - wx0);
+                    const int l10 = (t.yb - wy0) * WC + (t.xa - wx0), l11 = (t.yb - wy0) * WC + (t.xb - wx0);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const float *p = win + c * (WR * WC);
+                        float a = p[l00] * t.nw;
+                        a += p[l01] * t.ne;
+                        a += p[l10] * t.sw;
+                        a += p[l11] * t.se;
+                        v[c] = a;
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) v[c] = warp_sample(src_b + (size_t)c * plane, t);
+                }
+                const T z = (T)0.0f;
+                T *o = reinterpret_cast<T *>(cl_dst) + ((size_t)b * plane + (size_t)y * W + x) * 8;
+                *reinterpret_cast<vec8 *>(o) = vec8{(T)v[0], C > 1 ? (T)v[C > 1 ? 1 : 0] : z, C > 2 ? (T)v[C > 2 ? 2 : 0] : z, z, z, z, z, z};
+            }
+            return;
+        }
+    }
     // flow for this thread's two items (4 pixels each) while the DMA is in flight
     f32x4 fx[2], fy[2];
     int iy[2], ix[2];
