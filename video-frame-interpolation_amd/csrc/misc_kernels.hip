@@ -424,74 +424,89 @@ int launch_pool_partial(const void *src, float *part, int B, int npix, int cp, i
     return (int)hipGetLastError();
 }
 
-// One block per sample (m <= 64: 4m divides 256).  ctxw = [lin_w TRANSPOSED 4m x m][lin_b m][w9c as [c][o * 9 + tap]][b9 m]
+// One block of 1024 threads per sample (m <= 64: 4m divides 256).  ctxw = [lin_w TRANSPOSED 4m x m][lin_b m][w9c as [c][o * 9 + tap]][b9 m]
 // (pack_ctx_kernel): every loop below reads consecutive addresses from consecutive threads.
 // Writes ctx[b][m] and the border-class bias table R[b][16][coutpad]:
 //   R[cls][o] = b9[o] + sum over taps (ky,kx) inside the image for that class of
 //               sum_c W9[o, m + c, ky, kx] * ctx[c]
 // cls = ym*4 + xm; bit0 of ym: row y-1 exists, bit1: row y+1 exists (same for xm / columns).
-__global__ __launch_bounds__(256) void ctx_finish_kernel(const float *__restrict__ part, const float *__restrict__ ctxw,
-                                                         float *__restrict__ ctx_out, float *__restrict__ table,
-                                                         int m, int cp, int nparts, int npix, int coutpad, int round16)
+// The kernel is a chain of four dependent phases of a few hundred KB each - latency, not bandwidth: round 4 spreads every phase's
+// sum over all 1024 threads (partial sums meet in LDS, added in a fixed order: deterministic), which cut the loads a thread issues
+// one after another from 192 to 44 in the longest phase (37 -> ~15 us at B = 8).
+constexpr int kCtxThreads = 1024;
+__global__ __launch_bounds__(kCtxThreads) void ctx_finish_kernel(const float *__restrict__ part, const float *__restrict__ ctxw,
+                                                                 float *__restrict__ ctx_out, float *__restrict__ table,
+                                                                 int m, int cp, int nparts, int npix, int coutpad, int round16)
 {
     // round16 (EMAVFI_AMP16): the pooled mean and the Linear output are fp16 tensors under autocast
     const auto rq = [round16](float v) { return round16 ? (float)(half_t)v : v; };
+    constexpr int NT = kCtxThreads;
     extern __shared__ float sm[];
-    float *mean = sm, *ctx = sm + 4 * m, *tsum = ctx + m;  // tsum [m][9]
+    float *mean = sm, *ctx = sm + 4 * m, *tsum = ctx + m, *red = tsum + 9 * m;  // tsum [m][9]; red: max(NT, 3 * 9 m) floats
     const int b = blockIdx.x, tid = threadIdx.x;
     const float *lw = ctxw, *lb = lw + (size_t)m * 4 * m, *w9 = lb + m, *b9 = w9 + (size_t)m * m * 9;
-    for (int c = tid; c < 4 * m; c += 256) {
-        // up to 256 partial sums per channel: eight independent chains keep eight loads in flight (one chain = one L2 round
-        // trip per partial sum, which was most of this kernel's 90 us); fixed combination order, so still deterministic
-        float a[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        const float *pp = part + (size_t)b * nparts * cp + c;
-        int q = 0;
-        for (; q + 8 <= nparts; q += 8)
-#pragma unroll
-            for (int u = 0; u < 8; ++u) a[u] += pp[(size_t)(q + u) * cp];
-        for (; q < nparts; ++q) a[0] += pp[(size_t)q * cp];
-        const float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-        mean[c] = rq(s / (float)npix);
+    {   // ---- mean over the partial sums: thread (c, g) adds parts g, g + G, ...
+        const int C4 = 4 * m, G = NT / C4, c = tid % C4, g = tid / C4;
+        float a = 0.0f;
+        if (g < G)
+            for (int q = g; q < nparts; q += G) a += part[((size_t)b * nparts + q) * cp + c];
+        if (g < G) red[g * C4 + c] = a;
+        __syncthreads();
+        if (tid < C4) {
+            float s = 0.0f;
+            for (int q = 0; q < G; ++q) s += red[q * C4 + tid];
+            mean[tid] = rq(s / (float)npix);
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    // Linear (ema_vfi.py:91, 121): all 256 threads, thread (o, quarter) sums a quarter of the 4m inputs from the [c][o] copy
-    // (coalesced), the four partial sums of an output are added in a fixed order
-    {
-        const int nq = 256 / m > 0 ? (256 / m < 4 ? 256 / m : 4) : 1;   // m = 64: 4 quarters
-        const int o = tid % m, qd = tid / m, per = (4 * m + nq - 1) / nq;
-        float s = 0.0f;
-        if (qd < nq) {   // four independent chains: four weight loads in flight
+    {   // ---- Linear (ema_vfi.py:91, 121): thread (o, g) sums a slice of the 4m inputs from the [c][o] copy (coalesced), four chains
+        const int G = NT / m, o = tid % m, g = tid / m, per = (4 * m + G - 1) / G;
+        if (g < G) {
             float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            const int c1 = (qd + 1) * per < 4 * m ? (qd + 1) * per : 4 * m;
-            int c = qd * per;
+            const int c1 = (g + 1) * per < 4 * m ? (g + 1) * per : 4 * m;
+            int c = g * per;
             for (; c + 4 <= c1; c += 4)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) a[u] = fmaf(lw[(size_t)(c + u) * m + o], mean[c + u], a[u]);
             for (; c < c1; ++c) a[0] = fmaf(lw[(size_t)c * m + o], mean[c], a[0]);
-            s = (a[0] + a[1]) + (a[2] + a[3]);
-            tsum[qd * m + o] = s;   // tsum is free until the next phase (m * 9 >= 4 * m floats)
+            red[g * m + o] = (a[0] + a[1]) + (a[2] + a[3]);
         }
         __syncthreads();
         if (tid < m) {
             float t = lb[tid];
-            for (int q = 0; q < nq; ++q) t += tsum[q * m + tid];
+            for (int q = 0; q < G; ++q) t += red[q * m + tid];
             t = rq(t);
             ctx[tid] = t;
             ctx_out[(size_t)b * m + tid] = t;
         }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int k = tid; k < m * 9; k += 256) {   // [c][o * 9 + tap]: consecutive threads, consecutive addresses
-        float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        int c = 0;
-        for (; c + 4 <= m; c += 4)
+    {   // ---- tsum[k = o * 9 + tap] = sum_c w9[c][k] ctx[c]: blocks of KB outputs, thread (k, cg) sums a third (or less) of the channels
+        const int K9 = 9 * m, KB = K9 < 288 ? K9 : 288;
+        int CG = NT / KB; CG = CG > m ? m : CG; CG = CG > 3 ? 3 : CG;
+        const int per = (m + CG - 1) / CG, kk = tid % KB, cg = tid / KB;
+        for (int k0 = 0; k0 < K9; k0 += KB) {
+            const int k = k0 + kk;
+            if (cg < CG && k < K9) {
+                float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                const int c1 = (cg + 1) * per < m ? (cg + 1) * per : m;
+                int c = cg * per;
+                for (; c + 4 <= c1; c += 4)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) a[u] = fmaf(w9[(size_t)(c + u) * m * 9 + k], ctx[c + u], a[u]);
-        for (; c < m; ++c) a[0] = fmaf(w9[(size_t)c * m * 9 + k], ctx[c], a[0]);
-        tsum[k] = (a[0] + a[1]) + (a[2] + a[3]);
+                    for (int u = 0; u < 4; ++u) a[u] = fmaf(w9[(size_t)(c + u) * K9 + k], ctx[c + u], a[u]);
+                for (; c < c1; ++c) a[0] = fmaf(w9[(size_t)c * K9 + k], ctx[c], a[0]);
+                red[cg * K9 + k] = (a[0] + a[1]) + (a[2] + a[3]);
+            }
+        }
+        __syncthreads();
+        for (int k = tid; k < K9; k += NT) {
+            float t = 0.0f;
+            for (int q = 0; q < CG; ++q) t += red[q * K9 + k];
+            tsum[k] = t;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int k = tid; k < 16 * coutpad; k += 256) {
+    for (int k = tid; k < 16 * coutpad; k += NT) {
         const int cls = k / coutpad, o = k - cls * coutpad;
         float s = 0.0f;
         if (o < m) {
@@ -511,8 +526,9 @@ __global__ __launch_bounds__(256) void ctx_finish_kernel(const float *__restrict
 int launch_ctx_finish(const float *part, const float *ctxw, float *ctx_out, float *table, int B, int m, int cp, int nparts,
                       int npix, int coutpad, int round16, hipStream_t s)
 {
-    const size_t sh = (size_t)(4 * m + m + 9 * m) * sizeof(float);
-    ctx_finish_kernel<<<B, 256, sh, s>>>(part, ctxw, ctx_out, table, m, cp, nparts, npix, coutpad, round16);
+    const int nred = kCtxThreads > 27 * m ? kCtxThreads : 27 * m;
+    const size_t sh = (size_t)(4 * m + m + 9 * m + nred) * sizeof(float);
+    ctx_finish_kernel<<<B, kCtxThreads, sh, s>>>(part, ctxw, ctx_out, table, m, cp, nparts, npix, coutpad, round16);
     return (int)hipGetLastError();
 }
 
