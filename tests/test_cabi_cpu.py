@@ -280,13 +280,55 @@ def test_ring_kernels_prime_their_rings_with_the_steady_state_pattern(tmp_path):
     assert len(seen) == 14, sorted(seen)
 
 
+def _vregs(text):
+    """VGPR numbers an instruction's operands name (v7, v[4:7])."""
+    import re
+    regs = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", text):
+        regs.update(range(int(a), int(b) + 1))
+    regs.update(int(a) for a in re.findall(r"\bv(\d+)\b", text))
+    return regs
+
+
+def _touches_of_loads_in_flight(txt):
+    """Instructions (other than the counted waits) that read or write a VGPR while an inline-assembly weight load into it is still in
+    flight, in a straight-line reading of the function: VMEM retires in issue order, `s_waitcnt vmcnt(k)` leaves the youngest k."""
+    import re
+    fifo, bad = [], []
+    for t in txt:
+        m = re.match(r"s_waitcnt\s+(?:.*?)vmcnt\((\d+)\)", t)
+        if m:
+            k = int(m.group(1))
+            fifo = fifo[len(fifo) - k:] if 0 < k < len(fifo) else ([] if k == 0 else fifo)
+            continue
+        if re.match(r"(s_cbranch|s_branch|s_barrier|s_endpgm)", t):
+            continue
+        pend = set().union(*fifo) if fifo else set()
+        m = re.match(r"global_load_dwordx4 (v\[\d+:\d+\]), (v\d+), s\[", t)       # the asm weight loads: saddr form
+        if m:
+            if _vregs(m.group(2)) & pend:
+                bad.append(t)
+            fifo.append(_vregs(m.group(1)))
+            continue
+        if re.match(r"(global_|buffer_|flat_|scratch_)", t):
+            fifo.append(set())
+        if _vregs(t) & pend:
+            bad.append(t)
+    return bad
+
+
 def test_wreg_kernels_count_their_waits_exactly(tmp_path):
     """csrc/conv_wreg.inl (context_encoding.1 / .2) streams its weights with inline-assembly global_load_dwordx4 and its input tile with
     inline-assembly LDS-DMA, both behind COUNTED `s_waitcnt vmcnt(N)` that hipcc knows nothing about: "step s's two fragments have
     landed" is N = 2 P, or 2 P + NI in the first P steps of a chunk (the next chunk's NI DMA instructions are younger than those
     steps' loads).  The counts only hold while the k loop contains exactly those instructions - a spill (scratch), a flat access, an
-    ordinary load or a store inside it would shift every count, silently.  Checked on the shipped code objects (S = 1: P = 3, NI = 8,
-    36 steps per chunk; S = 2: P = 4, NI = 10, 18 steps), together with the register budget that lets two workgroups share a CU."""
+    ordinary load or a store inside it would shift every count, silently.  And hipcc believes an asm load's result is in its registers
+    when the statement ends: a copy, a spill or a reuse between the load and its wait reads (or clobbers) data still in flight (an
+    experiment with the wait in two arms of a branch got its "+v" registers merged by copies IN FRONT of the wait: sporadic wrong
+    weights on the GPU), and an "s" operand that arrives through v_readfirstlane gets none of the wait states a VMEM instruction needs
+    behind a VALU write of an SGPR (stale base address: a memory fault in another experiment).  Checked on the shipped code objects
+    (S = 1: P = 3, NI = 8, 36 steps per chunk; S = 2: P = 4, NI = 10, 18 steps), together with the register budget that lets two
+    workgroups share a CU."""
     import re
     seen = {}
     for dis in _device_disassembly(tmp_path):
@@ -295,6 +337,7 @@ def test_wreg_kernels_count_their_waits_exactly(tmp_path):
             P, NI, SPC = (3, 8, 36) if S == 1 else (4, 10, 18)
             ins, _ = _loops_of(body)
             txt = [t for _, t in ins]
+            assert not _touches_of_loads_in_flight(txt), (name, _touches_of_loads_in_flight(txt)[:4])
             first_bar = txt.index("s_barrier")
             last_mfma = max(i for i, t in enumerate(txt) if t.startswith("v_mfma"))
             loop = txt[first_bar:last_mfma + 1]
@@ -312,6 +355,11 @@ def test_wreg_kernels_count_their_waits_exactly(tmp_path):
             nz, want_nz = [w for w in waits if w], [w for w in want if w]
             assert nz[-len(want_nz):] == want_nz and waits[-1] == 0, (name, nz[-len(want_nz):][:8], want_nz[:8], waits[-3:])
             assert loop.count("s_barrier") == 2, name                                                     # the prologue's and the chunk boundary's
+            # the weight loads' base is an SGPR pair SALU / SMEM wrote: no v_readfirstlane into it anywhere near (VALU write of an SGPR ->
+            # VMEM read needs wait states nobody inserts in front of an asm string)
+            bases = {m.group(1) for t in wl for m in [re.search(r", s\[(\d+):\d+\]", t)]}
+            vrf = {m.group(1) for t in loop for m in [re.match(r"v_readfirstlane_b32 s(\d+),", t)] if m}
+            assert not ({int(b) for b in bases} | {int(b) + 1 for b in bases}) & {int(v) for v in vrf}, (name, bases, vrf)
             seen[name] = S
     assert sorted(seen.values()) == [1, 1, 2, 2], sorted(seen)     # bf16 and f16, stride 1 and 2
 
