@@ -78,6 +78,27 @@ def test_model_warp_method_signature():
     assert torch.allclose(got, oracle.warp(f2, flow), atol=1e-5)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(2, 40, 64), (1, 33, 132), (1, 75, 260), (3, 31, 68), (1, 360, 640)])
+def test_warp_inside_the_forward_equals_the_standalone_warp(dtype, shape):
+    """The warp the 16-bit forward runs at mid_channels 64 (warp_tiled_kernel, compact 16-byte pixels: a wave takes whole rows of the
+    tile since round 4) repeats emavfi_warp's arithmetic pixel for pixel: its `warped` tap must be EXACTLY the stand-alone warp of
+    frame2 by the forward's own `flow` tap, rounded to what the tail buffer stores (IEEE f16 in both 16-bit models at this width:
+    Plan::feat16).  Tile-edge widths (W % 64 = 0, 4, 68 - 64), heights around the 32-row tile, flows that leave the 8-pixel window
+    (synthetic "stress" frames), several samples."""
+    B, H, W = shape
+    sd = synth.synthetic_state_dict(seed=6)
+    f1, f2 = (t.to(DEV) for t in synth.synthetic_frames(36, B, H, W, "stress"))
+    m = make_model(sd, dtype=dtype)
+    with torch.no_grad():
+        _, taps = m(f1, f2, return_taps=True)
+    flow = taps["flow"].float().contiguous()
+    assert torch.isfinite(flow).all() and flow.abs().max().item() > 8.0      # some taps leave the LDS window: the global-gather path runs too
+    want = lib.warp(f2, flow).half().float()
+    got = taps["warped"].float()
+    assert torch.equal(got, want), f"{int((got != want).sum())} of {got.numel()} differ, max {(got - want).abs().max().item():.3e}"
+
+
 # ------------------------------------------------------------------ conv3x3 (row C)
 CONV_CASES = [  # (Cin, Cout, H, W, stride, act): one per reference layer shape + ragged sizes
     (6, 64, 40, 72, 1, 1), (64, 64, 24, 40, 1, 1), (64, 128, 33, 47, 2, 1), (128, 256, 18, 34, 2, 1),
