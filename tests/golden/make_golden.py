@@ -20,6 +20,7 @@ Outputs (data only - inputs and expected outputs):
                           and 1280x720 (B=1); weights/inputs are regenerated from
                           emavfi.synth by whoever replays it
   large_1080.npz          the same at 1920x1080 (B=1; BASELINE configs[4]'s size) - `large1080`
+  large_odd.npz           the same at 203x331 (B=2, stress input: odd in both dimensions, partial tiles at every level) - `odd`
   amp_mid8_23x37.npz, amp_mid64_40x56.npz
                           the reference's forward under torch.autocast("cpu", dtype=torch.float16) - `amp`: the only way
                           the reference's autocast path (inference.py:159, a CUDA autocast) can EXECUTE in this container.
@@ -203,6 +204,28 @@ def large1080():
     np.savez_compressed(os.path.join(OUT, "large_1080.npz"), **arrays)
 
 
+def large_odd():
+    """mid_channels 64 at an ODD size in both dimensions (B = 2, 203 x 331, stress input: flows far beyond one tile): every level of
+    the context pyramid ends in a partial tile (102 x 166, 51 x 83), the warp takes its W % 4 != 0 path, every ring strip its ragged
+    last columns.  Samples of every stage of the reference's forward."""
+    arrays = {}
+    sd = synth.synthetic_state_dict(seed=0)
+    tag, B, H, W, kind, seed = "odd", 2, 203, 331, "stress", 5
+    f1, f2 = synth.synthetic_frames(seed, B, H, W, kind)
+    t0 = time.time()
+    taps = run_reference(sd, f1, f2, 64)
+    print(f"  large {tag}: reference forward {time.time() - t0:.1f}s, flow range "
+          f"[{taps['flow'].min():.2f}, {taps['flow'].max():.2f}] out [{taps['out'].min():.3f},{taps['out'].max():.3f}]")
+    arrays[f"{tag}.meta"] = np.array([B, H, W, seed, 1], dtype=np.int64)
+    for k in ("feat", "ctx", "flow", "warped", "fused_0", "fused_1", "fused_2", "out"):
+        v = taps[k].contiguous().view(-1)
+        pos = sample_positions(seed, f"sample.{tag}.{k}", v.numel(), min(4096, v.numel()))
+        arrays[f"{tag}.pos.{k}"] = pos
+        arrays[f"{tag}.val.{k}"] = v[torch.from_numpy(pos)].numpy()
+        arrays[f"{tag}.stats.{k}"] = stage_stats(taps[k])
+    np.savez_compressed(os.path.join(OUT, "large_odd.npz"), **arrays)
+
+
 class DeformConv2dAutocastStandIn(DeformConv2dStandIn):
     """torchvision registers an Autocast kernel for deform_conv2d (torchvision/csrc/ops/autocast/deform_conv2d_kernel.cpp, restated):
     autocast is switched off inside, input / weight / offset / mask / bias are cast to float, the op runs in fp32 and the result is
@@ -291,6 +314,8 @@ if __name__ == "__main__":
         large()
     if "large1080" in which:
         large1080()
+    if "odd" in which:
+        large_odd()
     if "amp" in which:
         amp("amp_mid8_23x37", 8, 2, 23, 37, "stress", 12)
         amp("amp_mid64_40x56", 64, 1, 40, 56, "natural", 13)

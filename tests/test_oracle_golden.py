@@ -59,6 +59,21 @@ def test_large_256_stress_samples():
 
 @pytest.mark.skipif(not __import__("os").path.exists("/root/reference/src/models/ema_vfi.py"),
                     reason="the reference only exists in the authoring container")
+def test_large_odd_samples():
+    """mid=64 at 203x331 (B = 2, stress input, flows up to 16 px): odd in both dimensions, so every pyramid level (102x166, 51x83) and
+    every tile grid ends in a partial tile.  The oracle against the sampled pixels of the reference's own run
+    (tests/golden/large_odd.npz, `make_golden.py odd`)."""
+    g = load_golden("large_odd.npz")
+    B, H, W, seed, kind = (int(v) for v in g["odd.meta"])
+    assert (B, H, W, kind) == (2, 203, 331, 1)
+    f1, f2 = synth.synthetic_frames(seed, B, H, W, "stress")
+    taps = {}
+    oracle.forward(synth.synthetic_state_dict(seed=0), f1, f2, taps=taps)
+    for k in STAGES:
+        got = taps[k].contiguous().view(-1)[torch.from_numpy(g[f"odd.pos.{k}"])].numpy()
+        assert np.abs(got - g[f"odd.val.{k}"]).max() <= 2e-5 * max(1.0, np.abs(got).max()), k
+
+
 def test_generator_runs_the_reference_and_reproduces_the_committed_fixture(tmp_path):
     """tests/golden/make_golden.py at HEAD: loads the REFERENCE's ema_vfi.py by file path (not this repository's own
     src/ package), runs its forward, and the regenerated tiny fixture equals the committed one bit for bit."""
