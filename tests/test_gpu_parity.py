@@ -125,6 +125,22 @@ def test_conv3x3_matches_aten(case, dtype, tol):
     assert rel_err(got, ref) <= tol
 
 
+@pytest.mark.parametrize("dtype,tol", [("bf16", 2e-2), ("fp16", 3e-3)])
+@pytest.mark.parametrize("case", [(128, 256, 37, 131, 2, 1), (256, 256, 19, 67, 1, 1)])
+def test_conv3x3_round3_plans_of_the_256_channel_layers_still_match_aten(case, dtype, tol, monkeypatch):
+    """EMAVFI_CONV_WREG=0 (a layout switch: the stage entry reads it per call) puts context_encoding.1 / .2 back on the round-3 tile kernel
+    plans - conv3x3<32,8,2> and conv3x3<64,4,1> in two passes - which the A/B measurements of csrc/conv_wreg.inl compare against."""
+    monkeypatch.setenv("EMAVFI_CONV_WREG", "0")
+    Cin, Cout, H, W, stride, act = case
+    g = torch.Generator().manual_seed(Cin * 131 + Cout)
+    x = torch.randn(2, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g) * 0.1
+    got = lib.conv3x3(x.to(DEV), w.to(DEV), b.to(DEV), stride=stride, act=act, dtype=dtype).cpu()
+    ref = F.relu(F.conv2d(x, w, b, stride=stride, padding=1))
+    assert rel_err(got, ref) <= tol
+
+
 # ------------------------------------------------------------------ deformable conv (rows O, D)
 @pytest.mark.parametrize("dtype,tol", [("fp32", 3e-5), ("bf16", 3e-2), ("fp16", 4e-3)])
 @pytest.mark.parametrize("C,O,H,W,spread", [(67, 67, 19, 41, 2.0), (67, 67, 8, 32, 12.0), (11, 11, 23, 37, 1.5),
