@@ -141,6 +141,28 @@ def test_conv3x3_round3_plans_of_the_256_channel_layers_still_match_aten(case, d
     assert rel_err(got, ref) <= tol
 
 
+def test_conv_wreg_random_shapes_match_aten():
+    """csrc/conv_wreg.inl through emavfi_conv3x3: 60 random (stride, Cin in 128..256, Cout in 232..256, B <= 3, H <= 41, W <= 150, dtype,
+    activation) against ATen - partial tiles in both directions, 2 to 8 chunks, outputs narrower than the eight fragments."""
+    import random
+    rnd = random.Random(7)
+    for it in range(60):
+        stride = rnd.choice((1, 2))
+        Cin = rnd.choice((128, 192, 256)) if stride == 1 else rnd.choice((128, 160, 192, 256))
+        Cout = rnd.choice((256, 250, 232, 248))
+        H, W, B = rnd.randint(1, 41), rnd.randint(1, 150), rnd.randint(1, 3)
+        dtype, act = rnd.choice(("bf16", "fp16")), rnd.choice((0, 1))
+        g = torch.Generator().manual_seed(it)
+        x = torch.randn(B, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+        b = torch.randn(Cout, generator=g) * 0.1
+        got = lib.conv3x3(x.to(DEV), w.to(DEV), b.to(DEV), stride=stride, act=act, dtype=dtype).cpu()
+        ref = F.conv2d(x, w, b, stride=stride, padding=1)
+        ref = F.relu(ref) if act else ref
+        assert got.shape == ref.shape and torch.isfinite(got).all(), (it, stride, Cin, Cout, H, W, B, dtype)
+        assert rel_err(got, ref) <= (2e-2 if dtype == "bf16" else 3e-3), (it, stride, Cin, Cout, H, W, B, dtype, rel_err(got, ref))
+
+
 # ------------------------------------------------------------------ deformable conv (rows O, D)
 @pytest.mark.parametrize("dtype,tol", [("fp32", 3e-5), ("bf16", 3e-2), ("fp16", 4e-3)])
 @pytest.mark.parametrize("C,O,H,W,spread", [(67, 67, 19, 41, 2.0), (67, 67, 8, 32, 12.0), (11, 11, 23, 37, 1.5),
