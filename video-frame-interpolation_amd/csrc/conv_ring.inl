@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
                 for (int s = 0; s < AH; ++s) xq[s] = *reinterpret_cast<const vec *>(xb[s / 12] + ((s / 4) % 3) * C::PSTR + (s & 3) * 32);
 #pragma unroll
                 for (int s = 0; s < 36; ++s) {
-                    if (s + AH < 36 && !((EMAVFI_RING_ABL & 8) && (s + AH) / 12 == 2)) {   // (ablation 8: no operand reads for tap row 2 - 0.67 reads per MFMA, timing only)
+                    if (s + AH < 36) {
                         const int n = s + AH;
                         xq[n % (AH + 1)] = *reinterpret_cast<const vec *>(xb[n / 12] + ((n / 4) % 3) * C::PSTR + (n & 3) * 32);
                     }
