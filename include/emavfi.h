@@ -62,7 +62,7 @@
 extern "C" {
 #endif
 
-#define EMAVFI_VERSION 401 /* 0.4.1: context_encoding.1 / .2 re-packed for conv_wreg.inl; 0.4.0: the packed blob starts with a 256-byte self-describing header, emavfi_forward takes packed_bytes (round 4): re-pack */
+#define EMAVFI_VERSION 402 /* 0.4.2: emavfi_forward_staged, emavfi_mdcn_profiled (round 5; the packed layout is 0.4.1's, but a blob says which library packed it: re-pack); 0.4.1: context_encoding.1 / .2 re-packed for conv_wreg.inl; 0.4.0: the packed blob starts with a 256-byte self-describing header, emavfi_forward takes packed_bytes (round 4): re-pack */
 
 #define EMAVFI_F32 0
 #define EMAVFI_BF16 1
@@ -123,12 +123,16 @@ int emavfi_pack_weights(int in_channels, int mid_channels, int num_blocks,
  *   1 EMAVFI_CONV_MFMA16=0, 2 EMAVFI_CONV_RING=0, 4 EMAVFI_CONV_S2RING=0, (8: unused since 0.4.1), 16 EMAVFI_PACK_F16_CHAIN=0,
  *   32 EMAVFI_NO_FUSED_OFFSET, 64 EMAVFI_CONV_WREG=0.  Cache keys must use it (not the environment, which may have changed since the library latched it).
  * emavfi_packed_check: verifies header (magic, version, model, dtype, layout tag, size) and checksum of a blob in device OR host
- *   memory; EMAVFI_E_ARG with a message naming the mismatch.  THE ONE ENTRY THAT SYNCHRONISES (it copies a device blob to the
- *   host): call it when a blob arrives - from a file, another rank, another process - not per frame.
+ *   memory; EMAVFI_E_ARG with a message naming the mismatch.  THE ONE ENTRY THAT SYNCHRONISES: for a device blob it makes the
+ *   blob's device current, waits for EVERY stream of that device (hipDeviceSynchronize - the producer may have been the pack
+ *   kernels, an RCCL broadcast or a cache upload on any stream, also a non-blocking one), copies the blob to the host and restores
+ *   the caller's device.  Host memory is read in place: the caller orders its own writes.  Call it when a blob arrives - from a
+ *   file, another rank, another process - not per frame.
  * emavfi_forward itself (a) returns EMAVFI_E_ARG when packed_bytes is smaller than the model / dtype needs and (b) compares the
- *   header ON THE DEVICE with what the call expects: a blob of another version / model / dtype / layout tag yields an all-NaN
- *   frame (the context vector is poisoned), never plausible garbage; it cannot return a code for device-resident bytes without
- *   synchronising. */
+ *   header ON THE DEVICE with what the call expects, in its LAST launch (blob_guard, ~2 us): for a blob of another version /
+ *   model / dtype / layout tag every kernel still runs on the foreign bytes, and that last launch then overwrites `out` with NaN -
+ *   an all-NaN frame, never plausible garbage; it cannot return a code for device-resident bytes without synchronising.
+ *   The `taps` (a test hook) are NOT guarded: they hold whatever the kernels computed from the foreign bytes. */
 int emavfi_layout_tag(void);
 int emavfi_packed_check(int in_channels, int mid_channels, int num_blocks, int dtype, const void *packed, size_t packed_bytes);
 
@@ -154,6 +158,16 @@ int emavfi_forward(int in_channels, int mid_channels, int num_blocks, const void
  * events[2i] / events[2i+1] (caller-created hipEvent_t, timing enabled) on `stream`. */
 int emavfi_forward_launches(int in_channels, int mid_channels, int num_blocks, int B, int H, int W, int dtype,
                             char *names, size_t names_bytes, double *flops, double *bytes, int capacity);
+/* emavfi_forward with STAGE events, for a caller that pipelines pieces of a batch over several streams (frame pairs are
+ * independent, ema_vfi.py:110-147 has no cross-sample op; emavfi/model.py, EMAVFI_PIPELINE): `stage_events` is NULL or three
+ * caller-created hipEvent_t (any may be NULL), recorded on `stream` behind
+ *   [0] the front of the forward - feature extraction, context encoding, motion estimation, warp (ema_vfi.py:112-130),
+ *   [1] the last attention block (:136-138),   [2] the reconstruction (:144-146; the forward's last launch).
+ * `events` / `n_events` as in emavfi_forward_profiled, or NULL / 0.  No `taps`. */
+int emavfi_forward_staged(int in_channels, int mid_channels, int num_blocks, const void *packed, size_t packed_bytes,
+                          const float *frame1, const float *frame2, float *out,
+                          void *workspace, size_t workspace_bytes,
+                          int B, int H, int W, int dtype, void *const *stage_events, void *const *events, int n_events, void *stream);
 int emavfi_forward_profiled(int in_channels, int mid_channels, int num_blocks, const void *packed, size_t packed_bytes,
                             const float *frame1, const float *frame2, float *out,
                             void *workspace, size_t workspace_bytes,
@@ -214,6 +228,12 @@ int emavfi_deform_conv2d(const float *x, const float *offset, const float *mask,
 size_t emavfi_mdcn_workspace_bytes(int B, int C, int H, int W, int dtype, int flags);
 int emavfi_mdcn(const float *x, const float *offset_weight, const float *offset_bias, const float *dcn_weight, const float *dcn_bias,
                 float *y, int B, int C, int H, int W, int dtype, int flags, void *workspace, size_t workspace_bytes, void *stream);
+/* Measurement hook: emavfi_mdcn with the stage's own launches (one in the 16-bit modes at C = 67, else two) bracketed by
+ * hipEventRecord on events[2i] / events[2i+1]; the layout conversions around them are not bracketed (bench.py's
+ * also_pack_vs_offset_spread: what the dominant kernel costs when the offsets leave its staged window). */
+int emavfi_mdcn_profiled(const float *x, const float *offset_weight, const float *offset_bias, const float *dcn_weight, const float *dcn_bias,
+                         float *y, int B, int C, int H, int W, int dtype, int flags, void *workspace, size_t workspace_bytes,
+                         void *const *events, int n_events, void *stream);
 
 /* context_encoding(feat) -> ctx, ema_vfi.py:79-86 (called at :120): conv stride 2 + ReLU, conv stride 2 + ReLU, conv + ReLU,
  * AdaptiveAvgPool2d(1), Flatten, Linear.  feat [B,mid,H,W]; params = 8 device pointers in the Sequential's registration order:
@@ -230,11 +250,13 @@ size_t emavfi_reconstruct_workspace_bytes(int B, int mid_channels, int H, int W,
 int emavfi_reconstruct(const float *fused, const float *const *params, float *out, int B, int mid_channels, int H, int W, int dtype,
                        void *workspace, size_t workspace_bytes, void *stream);
 
-/* Test hook: the A/B switches of the launch sequence (EMAVFI_CONV_FIRST / _FIRSTRING / _HEAD / _TAILFUSE / _LIGHT / _RING2 = 0,
- * EMAVFI_NO_PERSISTENT_CONV) are read from the environment ONCE per process into one word; this replaces it by
+/* Test hook: the A/B switches of the launch sequence (EMAVFI_CONV_FIRST / _FIRSTRING / _HEAD / _TAILFUSE / _LIGHT / _RING2 /
+ * _POOLFUSE = 0, EMAVFI_NO_PERSISTENT_CONV) are read from the environment ONCE per process into one word; this replaces it by
  * (word & and_mask) | or_mask and returns the previous value (bits: 1 no conv_first, 2 no fused first two layers, 4 no fused flow
- * head, 8 no fused reconstruction tail, 16 no planar-head kernel, 32 no persistent conv, 64 no two-layer ring fusions).  None of
- * them changes the packed layout.  Not for production callers. */
+ * head, 8 no fused reconstruction tail, 16 no planar-head kernel, 32 no persistent conv, 64 no two-layer ring fusions, 128
+ * context_encoding.2 stores its output instead of fusing the average pool, 256 (EMAVFI_RING_ONE_WG=1, a measurement switch) the
+ * persistent LDS-ring kernels launch one workgroup per CU instead of two).  None of them changes the packed layout.  Not for
+ * production callers. */
 int emavfi_debug_switches(int and_mask, int or_mask);
 
 #ifdef __cplusplus

@@ -248,6 +248,8 @@ enum {
     SW_NO_PERSISTENT_CONV = 32,  // EMAVFI_NO_PERSISTENT_CONV: tile-per-workgroup kernel where the persistent one is the default
     SW_NO_RING2 = 64,            // EMAVFI_CONV_RING2=0: conv_block_1 + conv_block_2 / motion_estimation.0 + .1 + .2 as separate launches
     SW_NO_POOLFUSE = 128,        // EMAVFI_CONV_POOLFUSE=0: context_encoding.2 stores its output and avg_pool_partial reads it back
+    SW_RING_ONE_WG = 256,        // EMAVFI_RING_ONE_WG=1 (measurement, round 5): the persistent LDS-ring kernels launch ONE workgroup per CU instead
+                                 // of two, leaving half of every CU's LDS to a kernel of another stream (the pipelined forward's pack kernel)
 };
 unsigned emavfi_switches();
 

@@ -238,7 +238,7 @@ template <typename T> static int launch_conv_ringfirst_t(const FirstParams &fp, 
     if (const hipError_t e_ = set_lds_limit(once, reinterpret_cast<const void *>(&conv3x3_ringfirst_kernel<T>), C::LDS_BYTES); e_ != hipSuccess) return (int)e_;
     const int ncu = device_cu_count();
     if (ncu <= 0) return (int)hipErrorInvalidDevice;
-    const int nstrip = ((p.Wout + C::TWO - 1) / C::TWO) * p.B, grid = 2 * ncu;
+    const int nstrip = ((p.Wout + C::TWO - 1) / C::TWO) * p.B, grid = ((emavfi_switches() & SW_RING_ONE_WG) ? 1 : 2) * ncu;   // (SW_RING_ONE_WG: measurement switch, common.h)
     int nseg, seg_rows;
     conv_ring_segments(nstrip, p.Hout, grid, &nseg, &seg_rows);
     const int nitems = nstrip * nseg;

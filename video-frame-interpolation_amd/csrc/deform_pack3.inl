@@ -508,7 +508,6 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
 #if EMAVFI_DEFORM_STAMPS
         cnt_out += __popc(fb_taps);
 #endif
-        const char *gx = gplane + h * 16;
 #pragma unroll 1
         for (unsigned left = fb_taps; left != 0; left &= left - 1) {
             const int tap = __builtin_ctz(left);
@@ -544,49 +543,87 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
                 pc[0] = pix; pc[1] = pix + ddx; pc[2] = pix + (ddy ? (unsigned)W : 0u); pc[3] = pc[2] + ddx;
             };
             const unsigned w3a = w3lane + (unsigned)(tap * C::W3_TAP);
-#pragma unroll 1
-            for (int kg = 0; kg < 4; ++kg) {
-                f16x8 wf[2];
+            // Round 5 (bench.py also_pack_vs_offset_spread: 25 k cycles per (wave, tap) in this loop, against 2.1 k for a tap of the
+            // main loop): the loop used to issue a (k-group, row)'s four corner loads inside a divergent `if`, right in front of their
+            // blend - eight exposed global round trips per tap.  Now EVERY lane loads (a parked lane its clamped corners, every other
+            // lane pixel 0 of the plane: a valid address, one line, its value replaced by zero below, so a NaN there cannot leak through a
+            // zero weight), branch-free, the byte offsets of both rows' corners are computed once per tap, and k-group kg + 1's eight
+            // loads are issued BEFORE k-group kg is blended and contracted: one exposed round trip per tap, the other three under the
+            // arithmetic (their lines were fetched by k-group 0: a pixel's four k-groups share its 144-byte record).
+            unsigned co[2][4];
+            bool fl[2];
 #pragma unroll
-                for (int n = 0; n < 2; ++n) wf[n] = *reinterpret_cast<const f16x8 *>(wtap + (kg * 2 + n) * 1024 + lane16);
+            for (int m = 0; m < 2; ++m) {
+                unsigned pc[4];
+                corners_of(gp[m], pc);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) co[m][c] = __umul24(pc[c], ps_bytes) + (unsigned)(h * 16);
+                fl[m] = ((gp[m] >> 26) & 1u) != 0;
+            }
+            u32x4_t gb[2][2][4];   // [buffer][row][corner]
+            f16x8 wfb[2][2];       // [buffer][fragment]: a stage = 8 corner loads + its 2 weight fragments, so that "stage kg has landed" is
+                                   // a partial vmcnt (loads return in issue order: a fragment load issued BEHIND the next stage's gathers
+                                   // would make its wait drain them too)
+            auto issue = [&](int kg, u32x4_t (&dst)[2][4], f16x8 (&wdst)[2]) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) dst[m][c] = *reinterpret_cast<const u32x4_t *>(gplane + (size_t)(co[m][c] + (unsigned)(kg * 32)));   // (uniform base + 32-bit offset: no address pairs)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) wdst[n] = *reinterpret_cast<const f16x8 *>(wtap + (kg * 2 + n) * 1024 + lane16);
+            };
+            // storage -> f16 without a branch (a uniform branch per piece cut the block into regions and pinned a full wait in each)
+            const unsigned keep_raw = (std::is_same<TS, bf16_t>::value && !p.in_f16) ? 0u : 0xffffffffu;
+            auto conv_piece = [&](u32x4_t v) {
+                if constexpr (std::is_same<TS, bf16_t>::value) {
+                    const u32x4_t cv = to_f16_piece<TS>(v);
+                    return u32x4_t{(v[0] & keep_raw) | (cv[0] & ~keep_raw), (v[1] & keep_raw) | (cv[1] & ~keep_raw),
+                                   (v[2] & keep_raw) | (cv[2] & ~keep_raw), (v[3] & keep_raw) | (cv[3] & ~keep_raw)};
+                } else {
+                    return v;
+                }
+            };
+            u32x2_t traw[4];
+            issue(0, gb[0], wfb[0]);
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) {
+                if (kg + 1 < 4) issue(kg + 1, gb[(kg + 1) & 1], wfb[(kg + 1) & 1]);
+                if (kg == 2) {   // the parked lanes' tail channels (one 8-byte piece per corner): in flight under the last two k-groups
+                    unsigned pc[4];
+                    corners_of(gpk, pc);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        traw[c] = tplane ? *reinterpret_cast<const u32x2_t *>(tplane + (size_t)__umul24(pc[c], tail_bytes))
+                                         : *reinterpret_cast<const u32x2_t *>(gplane + (size_t)(__umul24(pc[c], ps_bytes) + 128u));
+                }
                 const f16x8 w3f = __builtin_bit_cast(f16x8, lds_read16(lds_r + w3a + (unsigned)(kg * 128)));
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     unsigned d[4][4];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) d[c][0] = d[c][1] = d[c][2] = d[c][3] = 0u;
-                    if ((gp[m] >> 26) & 1u) {
-                        unsigned pc[4];
-                        corners_of(gp[m], pc);
+                    for (int c = 0; c < 4; ++c) {
+                        const u32x4_t v = conv_piece(gb[kg & 1][m][c]);
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const u32x4_t v = to_f16_piece_rt<TS>(*reinterpret_cast<const u32x4_t *>(gx + (size_t)__umul24(pc[c], ps_bytes) + (unsigned)(kg * 32)), p.in_f16);
-                            d[c][0] = v[0]; d[c][1] = v[1]; d[c][2] = v[2]; d[c][3] = v[3];
-                        }
+                        for (int q = 0; q < 4; ++q) d[c][q] = fl[m] ? v[q] : 0u;
                     }
                     unsigned xd[4];
                     blend_corners_cm<4>(d, w01[m], w23[m], xd);
                     const f16x8 xf = __builtin_bit_cast(f16x8, u32x4_t{xd[0], xd[1], xd[2], xd[3]});
-                    mma_kg(acc[m][0], wf[0], xf);
-                    mma_kg(acc[m][1], wf[1], xf);
+                    mma_kg(acc[m][0], wfb[kg & 1][0], xf);
+                    mma_kg(acc[m][1], wfb[kg & 1][1], xf);
                     mma_kg(acc[m][2], w3f, xf);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
             // tail channels of the parked lanes' own pixels: one im2col k-group with this tap's slot alone
             {
                 unsigned vt[4][4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) vt[c][0] = vt[c][1] = vt[c][2] = vt[c][3] = 0u;
-                if (need_fb) {
-                    unsigned pc[4];
-                    corners_of(gpk, pc);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const char *src = tplane ? tplane + (size_t)__umul24(pc[c], tail_bytes) : gplane + (size_t)__umul24(pc[c], ps_bytes) + 128;
-                        const u32x2_t raw = *reinterpret_cast<const u32x2_t *>(src);
-                        const u32x4_t cv = to_f16_piece_rt<TS>(u32x4_t{raw[0], raw[1], 0u, 0u}, p.in_f16);
-                        vt[c][0] = cv[0]; vt[c][1] = cv[1];
-                    }
+                for (int c = 0; c < 4; ++c) {
+                    const u32x4_t cv = conv_piece(u32x4_t{traw[c][0], traw[c][1], 0u, 0u});
+                    vt[c][0] = need_fb ? cv[0] : 0u; vt[c][1] = need_fb ? cv[1] : 0u;
+                    vt[c][2] = vt[c][3] = 0u;
                 }
                 unsigned td[4];
                 blend_corners_cm<2>(vt, w01h, w23h, td);

@@ -44,6 +44,7 @@ void init_switches()
         if (off("EMAVFI_CONV_RING2")) v |= SW_NO_RING2;
         if (off("EMAVFI_CONV_POOLFUSE")) v |= SW_NO_POOLFUSE;
         if (getenv("EMAVFI_NO_PERSISTENT_CONV") != nullptr) v |= SW_NO_PERSISTENT_CONV;
+        if (const char *e = getenv("EMAVFI_RING_ONE_WG"); e && e[0] == '1') v |= SW_RING_ONE_WG;
         g_switches.store(v, std::memory_order_relaxed);
     });
 }
@@ -482,7 +483,16 @@ struct Recorder {
     void *const *events = nullptr;           // 2 per launch: start, stop
     int n_events = 0, idx = 0;
     bool dry = false;                        // enumerate only, launch nothing
+    void *const *stage_events = nullptr;     // emavfi_forward_staged: up to 3 hipEvent_t recorded behind the front / the attention blocks / the reconstruction
 };
+
+// records stage event i of a staged forward on the launch stream (no-op for every other entry)
+#define EMAVFI_STAGE_EVENT(rec, i)                                                                              \
+    do {                                                                                                        \
+        if (!(rec).dry && (rec).stage_events && (rec).stage_events[i] &&                                        \
+            hipEventRecord((hipEvent_t)(rec).stage_events[i], s) != hipSuccess)                                 \
+            return fail(EMAVFI_E_LAUNCH, "forward_staged: hipEventRecord of stage event %d failed", (int)(i));  \
+    } while (0)
 
 const char *dtype_name(int dtype) { return dtype == EMAVFI_F32 ? "f32" : dtype == EMAVFI_F16 ? "f16" : "bf16"; }
 
@@ -805,6 +815,7 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
         EMAVFI_STEP(rec, "fusion_round_warped", 0, px * 16 * 6.0, launch_convert_cl(xF, f.fu0, npx, P.fpad, P.fps, mid, P.fpad - mid, 0, s));
         if (!rec.dry && taps && taps[3])
             EMAVFI_TRY(launch_cl_to_nchw(xF, taps[3], B, C, H, W, P.fpad, mid, EMAVFI_F32, s), "tap warped");
+        EMAVFI_STAGE_EVENT(rec, 0);
         for (int i = 0; i < P.nb; ++i) {
             if (const int rc = attention_block_amp(P, i, packed, x, xF, yF, f.om, B, H, W, s, rec); rc != EMAVFI_OK) return rc;
             EMAVFI_STEP(rec, "fusion_round", 0, px * cf * 6.0, launch_convert_cl(yF, y, npx, P.fpad, P.fps, 0, P.fpad, 0, s));
@@ -825,6 +836,7 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
         if (!rec.dry && taps && taps[3])
             EMAVFI_TRY(split_tail ? launch_cl_to_nchw(f.in16, taps[3], B, C, H, W, 8, 0, feat_dtype, s)
                                   : launch_cl_to_nchw(f.fu0, taps[3], B, C, H, W, P.fps, mid, feat_dtype, s), "tap warped");
+        EMAVFI_STAGE_EVENT(rec, 0);
 
         // --- multi-attention fusion: num_blocks x ModulatedDeformConvPack, no activation (ema_vfi.py:136-138)
         for (int i = 0; i < P.nb; ++i) {
@@ -838,9 +850,11 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
         }
     }
 
+    EMAVFI_STAGE_EVENT(rec, 1);
     // --- reconstruction (ema_vfi.py:144-146)
     if (const int rc = reconstruction_stage(P, packed, x, f, out, B, H, W, s, rec); rc != EMAVFI_OK) return rc;
     EMAVFI_STEP(rec, "blob_guard", 0, 64.0, launch_blob_guard(guard, out, npx * (size_t)C, s));
+    EMAVFI_STAGE_EVENT(rec, 2);
     return EMAVFI_OK;
 }
 
@@ -953,8 +967,17 @@ int emavfi_packed_check(int in_channels, int mid_channels, int num_blocks, int d
     const bool on_device = hipPointerGetAttributes(&attr, packed) == hipSuccess && (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged);
     (void)hipGetLastError();   // (a plain host pointer makes hipPointerGetAttributes fail: not an error of this call)
     if (on_device) {
+        // The blob's producer (the pack kernels on the caller's stream, an RCCL broadcast, a cache upload) may have run on ANY stream of
+        // the blob's device - also a non-blocking one, which the legacy null stream of a plain hipMemcpy does not wait for - and that
+        // device need not be the current one.  So: make the blob's device current, wait for ALL of its streams, then copy.
+        int cur_dev = 0;
+        if (hipGetDevice(&cur_dev) != hipSuccess) return fail(EMAVFI_E_LAUNCH, "packed_check: hipGetDevice failed");
+        const bool other = attr.device != cur_dev;
+        if (other && hipSetDevice(attr.device) != hipSuccess) return fail(EMAVFI_E_LAUNCH, "packed_check: cannot select the blob's device %d", attr.device);
         host.resize(P.total);
-        if (hipMemcpy(host.data(), packed, P.total, hipMemcpyDeviceToHost) != hipSuccess) return fail(EMAVFI_E_LAUNCH, "packed_check: device-to-host copy failed");
+        const bool ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(host.data(), packed, P.total, hipMemcpyDeviceToHost) == hipSuccess;
+        if (other) (void)hipSetDevice(cur_dev);
+        if (!ok) { (void)hipGetLastError(); return fail(EMAVFI_E_LAUNCH, "packed_check: device synchronise / device-to-host copy failed"); }
         bytes = host.data();
     }
     BlobHeader got;
@@ -966,7 +989,7 @@ int emavfi_packed_check(int in_channels, int mid_channels, int num_blocks, int d
         return fail(EMAVFI_E_ARG, "packed_check: blob is for EMA_VFI(%u, %u, %u), not (%d, %d, %d)", got.in_ch, got.mid, got.nb, in_channels, mid_channels, num_blocks);
     if (got.dtype != want.dtype) return fail(EMAVFI_E_ARG, "packed_check: blob was packed for dtype %u, asked for %d", got.dtype, dtype);
     if (got.layout_tag != want.layout_tag)
-        return fail(EMAVFI_E_ARG, "packed_check: blob was packed under layout switches 0x%x, this process runs 0x%x (EMAVFI_CONV_MFMA16 / _RING / _WREG / _S2RING / _S2_CK64 / EMAVFI_PACK_F16_CHAIN / EMAVFI_NO_FUSED_OFFSET)",
+        return fail(EMAVFI_E_ARG, "packed_check: blob was packed under layout switches 0x%x, this process runs 0x%x (EMAVFI_CONV_MFMA16 / _RING / _WREG / _S2RING / EMAVFI_PACK_F16_CHAIN / EMAVFI_NO_FUSED_OFFSET)",
                     got.layout_tag, want.layout_tag);
     if (got.header_bytes != want.header_bytes || got.total_bytes != want.total_bytes)
         return fail(EMAVFI_E_ARG, "packed_check: blob size fields (%u, %llu) do not match this build's layout (%u, %llu)", got.header_bytes,
@@ -1003,6 +1026,17 @@ int emavfi_forward_profiled(int in_channels, int mid_channels, int num_blocks, c
     if (!events || n_events < 2) return fail(EMAVFI_E_ARG, "forward_profiled: events array required");
     Recorder rec;
     rec.events = events; rec.n_events = n_events;
+    return forward_impl(in_channels, mid_channels, num_blocks, packed, packed_bytes, frame1, frame2, out, workspace, workspace_bytes, B, H, W,
+                        dtype, nullptr, stream, rec);
+}
+
+int emavfi_forward_staged(int in_channels, int mid_channels, int num_blocks, const void *packed, size_t packed_bytes, const float *frame1,
+                          const float *frame2, float *out, void *workspace, size_t workspace_bytes, int B, int H, int W, int dtype,
+                          void *const *stage_events, void *const *events, int n_events, void *stream)
+{
+    Recorder rec;
+    rec.stage_events = stage_events;
+    if (events) { rec.events = events; rec.n_events = n_events; }
     return forward_impl(in_channels, mid_channels, num_blocks, packed, packed_bytes, frame1, frame2, out, workspace, workspace_bytes, B, H, W,
                         dtype, nullptr, stream, rec);
 }
@@ -1240,8 +1274,8 @@ size_t emavfi_mdcn_workspace_bytes(int B, int C, int H, int W, int dtype, int fl
     return ws.used;
 }
 
-int emavfi_mdcn(const float *x, const float *offset_weight, const float *offset_bias, const float *dcn_weight, const float *dcn_bias, float *y,
-                int B, int C, int H, int W, int dtype, int flags, void *workspace, size_t workspace_bytes, void *stream)
+static int mdcn_impl(const float *x, const float *offset_weight, const float *offset_bias, const float *dcn_weight, const float *dcn_bias, float *y,
+                     int B, int C, int H, int W, int dtype, int flags, void *workspace, size_t workspace_bytes, void *stream, Recorder &rec)
 {
     Plan P;
     bool split; int in_f16, out_f16;
@@ -1266,7 +1300,6 @@ int emavfi_mdcn(const float *x, const float *offset_weight, const float *offset_
     if (P.has_offh) EMAVFI_TRY(pack_layer(P.offh[0], params.data(), m.blob, kd, s), "mdcn pack offset_conv (f16 fragments)");
     EMAVFI_TRY(pack_layer(P.dcn[0], params.data(), m.blob, kd, s), "mdcn pack dcn_v2");
     if (P.amp) EMAVFI_TRY(pack_layer(P.dcn32[0], params.data(), m.blob, EMAVFI_F32, s), "mdcn pack dcn_v2 (fp32 master weights)");
-    Recorder rec;
     if (P.amp) {
         EMAVFI_TRY(launch_nchw_to_cl(x, m.xF, B, C, H, W, P.fpad, EMAVFI_F32, s), "mdcn layout in (fp32)");
         EMAVFI_TRY(launch_nchw_to_cl(x, m.xcl, B, C, H, W, P.fps, EMAVFI_F16, s), "mdcn layout in (fp16 rounding)");
@@ -1284,6 +1317,23 @@ int emavfi_mdcn(const float *x, const float *offset_weight, const float *offset_
     if (const int rc = attention_block(P, 0, m.blob, m.xcl, m.ycl, m.om, m.tail, in_f16, out_f16, B, H, W, s, rec); rc != EMAVFI_OK) return rc;
     EMAVFI_TRY(launch_cl_to_nchw(m.ycl, y, B, C, H, W, P.fps, 0, ydt, s), "mdcn layout out");
     return EMAVFI_OK;
+}
+
+int emavfi_mdcn(const float *x, const float *offset_weight, const float *offset_bias, const float *dcn_weight, const float *dcn_bias, float *y,
+                int B, int C, int H, int W, int dtype, int flags, void *workspace, size_t workspace_bytes, void *stream)
+{
+    Recorder rec;
+    return mdcn_impl(x, offset_weight, offset_bias, dcn_weight, dcn_bias, y, B, C, H, W, dtype, flags, workspace, workspace_bytes, stream, rec);
+}
+
+int emavfi_mdcn_profiled(const float *x, const float *offset_weight, const float *offset_bias, const float *dcn_weight, const float *dcn_bias, float *y,
+                         int B, int C, int H, int W, int dtype, int flags, void *workspace, size_t workspace_bytes, void *const *events, int n_events,
+                         void *stream)
+{
+    if (!events || n_events < 2) return fail(EMAVFI_E_ARG, "mdcn_profiled: events array required");
+    Recorder rec;
+    rec.events = events; rec.n_events = n_events;
+    return mdcn_impl(x, offset_weight, offset_bias, dcn_weight, dcn_bias, y, B, C, H, W, dtype, flags, workspace, workspace_bytes, stream, rec);
 }
 
 // ---- context_encoding and reconstruction as stage-level entries (SURVEY 8b's proposed emavfi_context / emavfi_reconstruct): the model is

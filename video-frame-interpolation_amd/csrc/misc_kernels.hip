@@ -738,6 +738,10 @@ __global__ __launch_bounds__(256) void warp_tiled_kernel(const float *__restrict
                 gx[k] = flow[((size_t)b * 2) * plane + pix];
                 gy[k] = flow[((size_t)b * 2 + 1) * plane + pix];
             }
+            // the window is filled by LDS-DMA, which hipcc drains (vmcnt(0)) ahead of the barrier today; pinned here so that a compiler
+            // that moves its wait behind the barrier cannot let a wave read another wave's unlanded window.  Free: the
+            // flow loads were issued after the DMA and return in order.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             typedef __attribute__((ext_vector_type(8))) T vec8;
 #pragma unroll
@@ -784,7 +788,8 @@ __global__ __launch_bounds__(256) void warp_tiled_kernel(const float *__restrict
         fx[k] = *reinterpret_cast<const f32x4 *>(flow + ((size_t)b * 2) * plane + pix);
         fy[k] = *reinterpret_cast<const f32x4 *>(flow + ((size_t)b * 2 + 1) * plane + pix);
     }
-    __syncthreads();  // hipcc drains the DMA (vmcnt(0)) ahead of the barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA has landed before the barrier, whatever hipcc does with its own wait
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         if (!live[k]) continue;

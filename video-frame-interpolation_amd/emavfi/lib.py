@@ -15,7 +15,7 @@ F32, BF16, F16, AMP16 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_TANH01 = 0, 1, 2
 MDCN_IN_F16, MDCN_OUT_F16, MDCN_SPLIT_TAIL = 1, 2, 4
 # emavfi_debug_switches bits (include/emavfi.h)
-SW_NO_CONV_FIRST, SW_NO_FIRSTRING, SW_NO_HEAD, SW_NO_TAILFUSE, SW_NO_CONV_LIGHT, SW_NO_PERSISTENT_CONV, SW_NO_RING2, SW_NO_POOLFUSE = 1, 2, 4, 8, 16, 32, 64, 128
+SW_NO_CONV_FIRST, SW_NO_FIRSTRING, SW_NO_HEAD, SW_NO_TAILFUSE, SW_NO_CONV_LIGHT, SW_NO_PERSISTENT_CONV, SW_NO_RING2, SW_NO_POOLFUSE, SW_RING_ONE_WG = 1, 2, 4, 8, 16, 32, 64, 128, 256
 DTYPES = {"fp32": F32, "f32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16,
           "fp16": F16, "f16": F16, "float16": F16, "half": F16,
           # the reference's forward under torch.cuda.amp.autocast(), op policy restated (include/emavfi.h, EMAVFI_AMP16)
@@ -38,6 +38,7 @@ _PROTOTYPES = {
     "emavfi_forward": (c_int, [c_int] * 3 + [c_void_p, c_size_t] + [c_void_p] * 4 + [c_size_t] + [c_int] * 4 + [POINTER(c_void_p), c_void_p]),
     "emavfi_forward_launches": (c_int, [c_int] * 7 + [c_char_p, c_size_t, POINTER(ctypes.c_double), POINTER(ctypes.c_double), c_int]),
     "emavfi_forward_profiled": (c_int, [c_int] * 3 + [c_void_p, c_size_t] + [c_void_p] * 4 + [c_size_t] + [c_int] * 4 + [POINTER(c_void_p), c_int, c_void_p]),
+    "emavfi_forward_staged": (c_int, [c_int] * 3 + [c_void_p, c_size_t] + [c_void_p] * 4 + [c_size_t] + [c_int] * 4 + [POINTER(c_void_p), POINTER(c_void_p), c_int, c_void_p]),
     "emavfi_warp": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
     "emavfi_preprocess_u8": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [POINTER(ctypes.c_float), POINTER(ctypes.c_float), c_void_p]),
     "emavfi_postprocess_u8": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [POINTER(ctypes.c_double), POINTER(ctypes.c_double), c_int, c_void_p]),
@@ -47,6 +48,7 @@ _PROTOTYPES = {
     "emavfi_deform_conv2d": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
     "emavfi_mdcn_workspace_bytes": (c_size_t, [c_int] * 6),
     "emavfi_mdcn": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
+    "emavfi_mdcn_profiled": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p, c_size_t, POINTER(c_void_p), c_int, c_void_p]),
     "emavfi_context_workspace_bytes": (c_size_t, [c_int] * 5),
     "emavfi_context": (c_int, [c_void_p, POINTER(c_void_p), c_void_p] + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "emavfi_reconstruct_workspace_bytes": (c_size_t, [c_int] * 5),
@@ -198,6 +200,73 @@ def release_workspaces():
         del _ws_graph_held[:]
 
 
+# ---------------------------------------------------------------- HIP events / side streams for the pipelined forward (model.py)
+class _Hip:
+    """hipEvent* / hipStreamWaitEvent of the HIP runtime torch has already loaded into this process (plain handles: what the C-ABI's
+    stage events are).  Events are created once per (device, purpose) and re-recorded: a hipStreamWaitEvent captures the record
+    that precedes it in host call order."""
+
+    def __init__(self):
+        path = None
+        for line in open("/proc/self/maps"):
+            if "libamdhip64" in line:
+                path = line.split()[-1]
+                break
+        self.rt = ctypes.CDLL(path or "libamdhip64.so")
+        self.rt.hipEventCreateWithFlags.argtypes = [POINTER(c_void_p), ctypes.c_uint]
+        self.rt.hipEventRecord.argtypes = [c_void_p, c_void_p]
+        self.rt.hipStreamWaitEvent.argtypes = [c_void_p, c_void_p, ctypes.c_uint]
+        self._events = {}
+
+    def event(self, key):
+        e = self._events.get(key)
+        if e is None:
+            h = c_void_p()
+            rc = self.rt.hipEventCreateWithFlags(ctypes.byref(h), 2)   # hipEventDisableTiming
+            if rc != 0:
+                raise RuntimeError(f"hipEventCreateWithFlags failed ({rc})")
+            e = self._events[key] = h
+        return e
+
+    def record(self, event, stream):
+        rc = self.rt.hipEventRecord(event, c_void_p(stream.cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"hipEventRecord failed ({rc})")
+
+    def wait(self, stream, event):
+        rc = self.rt.hipStreamWaitEvent(c_void_p(stream.cuda_stream), event, 0)
+        if rc != 0:
+            raise RuntimeError(f"hipStreamWaitEvent failed ({rc})")
+
+
+_hip = None
+_side_streams = {}
+
+
+def hip() -> _Hip:
+    global _hip
+    if _hip is None:
+        with _lock:
+            if _hip is None:
+                _hip = _Hip()
+    return _hip
+
+
+def side_stream(device, which=0, priority=0):
+    """One cached side stream per (device, which): the pipelined forward's second lane, the harness's pre / post lanes."""
+    import torch
+    device = torch.device(device)
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (index, which, priority)
+    s = _side_streams.get(key)
+    if s is None:
+        with _lock:
+            s = _side_streams.get(key)
+            if s is None:
+                s = _side_streams[key] = torch.cuda.Stream(device=torch.device("cuda", index), priority=priority)
+    return s
+
+
 # ---------------------------------------------------------------- operator-level wrappers
 def warp(frame2, flow):
     """EMA_VFI.warp (reference ema_vfi.py:149-171) on the GPU."""
@@ -259,9 +328,10 @@ def deform_conv2d(x, offset, mask, weight, bias, dtype="fp32"):
     return y
 
 
-def mdcn(x, offset_weight, offset_bias, dcn_weight, dcn_bias, dtype="fp32", flags=0):
+def mdcn(x, offset_weight, offset_bias, dcn_weight, dcn_bias, dtype="fp32", flags=0, _events=None):
     """ModulatedDeformConvPack.forward (reference ema_vfi.py:53-60) as ONE stage, routed as a block of the forward is
-    (include/emavfi.h, emavfi_mdcn): the one-launch kernel in the 16-bit modes at the reference width."""
+    (include/emavfi.h, emavfi_mdcn): the one-launch kernel in the 16-bit modes at the reference width.
+    `_events` (bench.py): (ctypes array of hipEvent_t, count) bracketing the stage's own launches (emavfi_mdcn_profiled)."""
     import torch
     _require_cuda(x, offset_weight, offset_bias, dcn_weight, dcn_bias)
     dt = dtype_code(dtype)
@@ -277,8 +347,13 @@ def mdcn(x, offset_weight, offset_bias, dcn_weight, dcn_bias, dtype="fp32", flag
     ws = workspace(n, x.device)
     y = torch.empty_like(x)
     with torch.cuda.device(x.device):
-        check(L.emavfi_mdcn(x.data_ptr(), ow.data_ptr(), ob.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None, y.data_ptr(),
-                            B, C, H, W, dt, flags, ws.data_ptr(), ws.numel(), _stream()), "emavfi_mdcn")
+        if _events is not None:
+            check(L.emavfi_mdcn_profiled(x.data_ptr(), ow.data_ptr(), ob.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None,
+                                         y.data_ptr(), B, C, H, W, dt, flags, ws.data_ptr(), ws.numel(), ctypes.cast(_events[0], POINTER(c_void_p)),
+                                         _events[1], _stream()), "emavfi_mdcn_profiled")
+        else:
+            check(L.emavfi_mdcn(x.data_ptr(), ow.data_ptr(), ob.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None, y.data_ptr(),
+                                B, C, H, W, dt, flags, ws.data_ptr(), ws.numel(), _stream()), "emavfi_mdcn")
     return y
 
 

@@ -113,6 +113,10 @@ class EMA_VFI(nn.Module):
         self.num_blocks = num_blocks
         self.deformable_groups = 8  # present but unused in the reference too (ema_vfi.py:70)
         self.compute_dtype = compute_dtype if compute_dtype is not None else os.environ.get("EMAVFI_DTYPE")
+        # pieces of a batch pipelined over two streams (forward(): _forward_pipelined); 1 = the whole batch as one sequence of launches
+        self.pipeline = int(os.environ.get("EMAVFI_PIPELINE", "1"))
+        # which stage event of piece k releases piece k + 1: 0 = its front (default), 1 = its attention blocks, -1 = none (pieces start together)
+        self.pipeline_stagger = int(os.environ.get("EMAVFI_PIPELINE_STAGGER", "0"))
         m = mid_channels
         self.feat_ext_conv1 = conv_block(in_channels * 2, m)
         self.feat_ext_blocks = nn.Sequential(OrderedDict(
@@ -315,10 +319,6 @@ class EMA_VFI(nn.Module):
         B, C, H, W = f1.shape
         L = _lib.load()
         packed = self.packed_weights(dt, dev)
-        nws = L.emavfi_workspace_bytes(C, self.mid_channels, self.num_blocks, B, H, W, dt)
-        if nws == 0:
-            raise RuntimeError(f"EMA_VFI: {_lib.last_error()}")
-        ws = _lib.workspace(nws, dev)
         out = torch.empty_like(f1)
         taps_arg, taps = None, None
         if return_taps:
@@ -330,16 +330,26 @@ class EMA_VFI(nn.Module):
                 taps[f"fused_{i}"] = torch.empty(B, m + 3, H, W, device=dev)
                 ptrs.append(taps[f"fused_{i}"].data_ptr())
             taps_arg = cast((c_void_p * len(ptrs))(*ptrs), POINTER(c_void_p))
-        with torch.cuda.device(dev):
-            if _events is not None:  # bench.py: (ctypes array of hipEvent_t, count) bracketing every launch
-                _lib.check(L.emavfi_forward_profiled(C, self.mid_channels, self.num_blocks, packed.data_ptr(), packed.numel(), f1.data_ptr(),
-                                                     f2.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, dt,
-                                                     cast(_events[0], POINTER(c_void_p)), _events[1], _lib._stream()),
-                           "emavfi_forward_profiled")
-            else:
-                _lib.check(L.emavfi_forward(C, self.mid_channels, self.num_blocks, packed.data_ptr(), packed.numel(), f1.data_ptr(),
-                                            f2.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, dt, taps_arg,
-                                            _lib._stream()), "emavfi_forward")
+        pieces = min(int(self.pipeline), B)
+        if (C * H * W) % 4 != 0:
+            pieces = 1   # a slice of the batch must start 16-byte aligned (include/emavfi.h): odd sample sizes run as one sequence
+        if pieces >= 2 and not return_taps and not torch.cuda.is_current_stream_capturing():
+            self._forward_pipelined(L, packed, f1, f2, out, dt, pieces, _events)
+        else:
+            nws = L.emavfi_workspace_bytes(C, self.mid_channels, self.num_blocks, B, H, W, dt)
+            if nws == 0:
+                raise RuntimeError(f"EMA_VFI: {_lib.last_error()}")
+            ws = _lib.workspace(nws, dev)
+            with torch.cuda.device(dev):
+                if _events is not None:  # bench.py: (ctypes array of hipEvent_t, count) bracketing every launch
+                    _lib.check(L.emavfi_forward_profiled(C, self.mid_channels, self.num_blocks, packed.data_ptr(), packed.numel(), f1.data_ptr(),
+                                                         f2.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, dt,
+                                                         cast(_events[0], POINTER(c_void_p)), _events[1], _lib._stream()),
+                               "emavfi_forward_profiled")
+                else:
+                    _lib.check(L.emavfi_forward(C, self.mid_channels, self.num_blocks, packed.data_ptr(), packed.numel(), f1.data_ptr(),
+                                                f2.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, dt, taps_arg,
+                                                _lib._stream()), "emavfi_forward")
         # under autocast the reference's reconstruction tail is fp16, so its frame is an fp16 tensor (the values computed
         # here are fp16-representable: the conversion is exact)
         out = out.half() if dt == _lib.AMP16 else out.to(frame1.dtype)
@@ -347,6 +357,56 @@ class EMA_VFI(nn.Module):
             taps["out"] = out
             return out, taps
         return out
+
+    def _forward_pipelined(self, L, packed, f1, f2, out, dt, pieces, _events=None):
+        """The batch as `pieces` contiguous slices alternating between the caller's stream and one side stream, piece k + 1 starting
+        when piece k's FRONT (feature extraction, context, motion, warp: ema_vfi.py:112-130) has been enqueued-and-finished, so that one
+        piece's attention blocks (the LDS-window pack kernel: gather / blend / MFMA per sample) run beside another piece's plain
+        convolutions (LDS-ring kernels: MFMA-dense) on the same CUs - the two kernel families fit beside each other (80.8 KB + <= 80 KiB
+        of LDS, <= 256 VGPRs each).  Frame pairs are independent (no cross-sample op in ema_vfi.py:110-147) and every kernel is
+        batch-invariant per sample, so the result is bit-identical to the one-sequence forward
+        (tests/test_gpu_runtime.py::test_pipelined_forward_is_bit_identical).  Joins back onto the caller's stream before returning.
+        `_events`: per-launch event pairs, piece k's launches in [k * count / pieces, (k + 1) * count / pieces)."""
+        B, C, H, W = f1.shape
+        dev = f1.device
+        hip = _lib.hip()
+        cur = torch.cuda.current_stream(dev)
+        side = _lib.side_stream(dev)
+        if side.cuda_stream == cur.cuda_stream:
+            side = _lib.side_stream(dev, which=1)
+        cuts = [B * k // pieces for k in range(pieces + 1)]
+        key = (dev.index, cur.cuda_stream)
+        fork, join = hip.event(key + ("fork",)), hip.event(key + ("join",))
+        hip.record(fork, cur)          # the frames (and the packed blob) are ready on the caller's stream
+        hip.wait(side, fork)
+        per = (_events[1] // pieces) if _events is not None else 0
+        front_prev = None
+        with torch.cuda.device(dev):
+            for k in range(pieces):
+                b0, b1 = cuts[k], cuts[k + 1]
+                s = cur if k % 2 == 0 else side
+                if front_prev is not None:
+                    hip.wait(s, front_prev)
+                front = hip.event(key + ("stage", k))
+                with torch.cuda.stream(s):
+                    nws = L.emavfi_workspace_bytes(C, self.mid_channels, self.num_blocks, b1 - b0, H, W, dt)
+                    if nws == 0:
+                        raise RuntimeError(f"EMA_VFI: {_lib.last_error()}")
+                    ws = _lib.workspace(nws, dev)
+                    stage = (c_void_p * 3)(*[front if i == self.pipeline_stagger else None for i in range(3)])
+                    evp = None
+                    if _events is not None:
+                        import ctypes
+                        evp = cast(c_void_p(_events[0].value + k * per * ctypes.sizeof(c_void_p)), POINTER(c_void_p))
+                    _lib.check(L.emavfi_forward_staged(C, self.mid_channels, self.num_blocks, packed.data_ptr(), packed.numel(),
+                                                       f1[b0:b1].data_ptr(), f2[b0:b1].data_ptr(), out[b0:b1].data_ptr(), ws.data_ptr(), ws.numel(),
+                                                       b1 - b0, H, W, dt, cast(stage, POINTER(c_void_p)), evp, per, c_void_p(s.cuda_stream)),
+                               "emavfi_forward_staged")
+                front_prev = front if self.pipeline_stagger >= 0 else None
+        hip.record(join, side)
+        hip.wait(cur, join)
+        # the caching allocator knows `out` (and the frames) only on the caller's stream; the side stream's work on them is ordered
+        # before everything the caller enqueues from here on by the join above
 
     def warp(self, frame2, feature, flow):
         """Same signature as the reference (ema_vfi.py:149); ``feature`` is only a device hint there."""
