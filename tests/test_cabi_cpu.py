@@ -364,6 +364,69 @@ def test_wreg_kernels_count_their_waits_exactly(tmp_path):
     assert sorted(seen.values()) == [1, 1, 2, 2], sorted(seen)     # bf16 and f16, stride 1 and 2
 
 
+# Every kernel family of the library that moves data with LDS-DMA (global_load_lds: hand-written asm or the compiler's builtin - the
+# disassembly cannot tell them apart) or with loads hipcc does not know of.  "asm": the DMA / loads are inline assembly retired by COUNTED
+# waits the compiler cannot check - the named test pins their instruction counts on the shipped code objects.  "builtin": the compiler
+# sees the DMA and drains it itself; only the generic barrier rule below applies.  A NEW family with LDS-DMA fails the enumeration
+# test until it is listed here - and an "asm" entry must name a test that exists.
+_VMEM_FAMILIES = {
+    "conv3x3_ring_kernel": ("asm", "test_ring_kernels_issue_a_fixed_number_of_vmem_instructions_per_step"),
+    "conv3x3_ringtail_kernel": ("asm", "test_ring_kernels_issue_a_fixed_number_of_vmem_instructions_per_step"),
+    "conv3x3_ring2_kernel": ("asm", "test_ring_kernels_prime_their_rings_with_the_steady_state_pattern"),
+    "conv3x3_wreg_kernel": ("asm", "test_wreg_kernels_count_their_waits_exactly"),
+    "conv3x3_s2ring_kernel": ("builtin", None), "conv3x3_kernel": ("builtin", None), "conv3x3_persist_kernel": ("builtin", None),
+    "conv3x3_persist16_kernel": ("builtin", None), "conv_light_kernel": ("builtin", None), "deform_pack3_kernel": ("builtin", None),
+    "deform_f32w_kernel": ("builtin", None), "warp_tiled_kernel": ("builtin", None),
+}
+
+
+def test_every_kernel_with_lds_dma_is_listed_and_waits_before_its_barrier(tmp_path):
+    """One enumeration over EVERY kernel symbol of the shipped code objects: (1) a kernel that contains
+    global_load_lds belongs to a family listed in _VMEM_FAMILIES, and every listed family exists - so an inline-assembly VMEM kernel cannot
+    ship without somebody deciding which code-object test pins its counted waits; (2) the generic rule of an LDS-DMA producer: between a
+    global_load_lds and the NEXT s_barrier (the point where other waves start reading what it wrote) there is an `s_waitcnt` with a vmcnt
+    field - counted or zero - in the ten instructions in front of that barrier.  hipcc places vmcnt(0) there for its builtin today
+    (warp_tiled_kernel now also says so itself), the asm kernels place their counted wait; a compiler that moved the wait behind the
+    barrier would otherwise produce silently wrong windows; (3) no family of the "asm" kind carries flat_ instructions anywhere (they
+    count in vmcnt AND lgkmcnt: DESIGN 3.2b, the lost address space of an indexed LDS base array) or reads an SGPR written by
+    v_readfirstlane as the m0 / saddr operand of its DMA inside a loop."""
+    import re
+    seen = {}
+    for dis in _device_disassembly(tmp_path):
+        for name, body in re.findall(r"<(\w+)>:\n(.*?)(?=\n\n|\Z)", dis, re.S):
+            if "s_endpgm" not in body or "global_load_lds" not in body:
+                continue
+            m = re.match(r"_Z\d+(\w+?_kernel)", name)
+            fam = m.group(1) if m else name
+            assert fam in _VMEM_FAMILIES, f"{name}: a kernel with LDS-DMA that tests/test_cabi_cpu.py::_VMEM_FAMILIES does not list"
+            kind, test = _VMEM_FAMILIES[fam]
+            ins, loops = _loops_of(body)
+            txt = [t for _, t in ins]
+            pending = False
+            for i, t in enumerate(txt):
+                if t.startswith("global_load_lds"):
+                    pending = True
+                elif t == "s_barrier" and pending:
+                    near = txt[max(0, i - 10):i]   # (conv_ring2: the counted wait sits in the A-role arm of a branch that ends right in front of the barrier)
+                    assert any(re.match(r"s_waitcnt\b.*vmcnt\(\d+\)", w) for w in near), (name, "barrier behind LDS-DMA without a vmcnt wait", near)
+                    pending = False
+            if kind == "asm":
+                assert test in globals(), (fam, test)
+                assert not any(t.startswith("flat_") for t in txt), (name, "flat access in a counted-wait kernel")
+                vrf = {int(mm.group(1)) for t in txt for mm in [re.match(r"v_readfirstlane_b32 s(\d+),", t)] if mm}
+                for (a0, a1) in loops:
+                    inloop = [t for a, t in ins if a0 <= a <= a1]
+                    for j, t in enumerate(inloop):
+                        if t.startswith("global_load_lds"):
+                            mm = re.match(r"s_mov_b32 m0, s(\d+)", next((w for w in reversed(inloop[:j]) if w.startswith("s_mov_b32 m0")), ""))
+                            # (m0 fed from an SGPR: that SGPR must not be a v_readfirstlane result produced inside the same loop)
+                            if mm and int(mm.group(1)) in vrf:
+                                assert not any(re.match(rf"v_readfirstlane_b32 s{mm.group(1)},", w) for w in inloop), (name, "m0 from v_readfirstlane inside the loop")
+            seen.setdefault(fam, 0)
+            seen[fam] += 1
+    assert set(seen) == set(_VMEM_FAMILIES), (sorted(set(_VMEM_FAMILIES) - set(seen)), sorted(set(seen) - set(_VMEM_FAMILIES)))
+
+
 def test_packed_cache_file_carries_a_checksum(tmp_path):
     """ADVICE r2: the on-disk packed-weight cache trusted any file of the right size.  The file is now blob + sha256(blob);
     a flipped byte, a truncated file or a file of the old format is ignored (the caller re-packs and overwrites it)."""
