@@ -164,6 +164,20 @@ def test_preprocess_and_postprocess_bit_exact():
         else:
             ref = (np.clip(np.transpose(x.numpy(), (0, 2, 3, 1)).astype(np.float64), 0, 1) * 255).astype(np.uint8)
         assert np.array_equal(got, ref)
+    # the 16-byte-quad kernels (round 5: whole batch a multiple of 16 bytes): quads that straddle pixels AND frames (420-byte frames)
+    w8 = g.integers(0, 256, (4, 10, 14, 3), dtype=np.uint8)
+    for src in (torch.from_numpy(w8).cuda(), torch.from_numpy(w8).pin_memory()):
+        assert torch.equal(lib.preprocess_u8(src, device="cuda:0").cpu(), torch.stack([ref_preprocess(f) for f in w8]))
+    z = torch.from_numpy(g.normal(0.4, 0.6, (4, 3, 10, 14)).astype(np.float32))
+    z[1, 2, 9, 13], z[2, 0, 0, 0] = float("nan"), 7.0
+    for denorm in (True, False):
+        zp = torch.empty(4, 10, 14, 3, dtype=torch.uint8).pin_memory()
+        lib.postprocess_u8(z.cuda(), denormalize=denorm, out=zp)
+        torch.cuda.synchronize()
+        ref = np.stack([ref_denormalize(t) for t in z]) if denorm else (np.clip(np.nan_to_num(np.transpose(z.numpy(), (0, 2, 3, 1)).astype(np.float64), nan=0.0), 0, 1) * 255).astype(np.uint8)
+        keep = ~np.isnan(np.transpose(z.numpy(), (0, 2, 3, 1)))      # (a NaN has no defined uint8 image in numpy; the kernels write 0)
+        assert np.array_equal(zp.numpy()[keep], ref[keep]) and zp.numpy()[1, 9, 13, 2] == 0
+        assert np.array_equal(zp.numpy(), lib.postprocess_u8(z.cuda(), denormalize=denorm).cpu().numpy())
     # round trip of a source frame: what the reference writes for frame1 (inference.py:187-188)
     rt = lib.postprocess_u8(lib.preprocess_u8(torch.from_numpy(u8).cuda())).cpu().numpy()
     assert np.array_equal(rt, np.stack([ref_denormalize(ref_preprocess(f)) for f in u8]))

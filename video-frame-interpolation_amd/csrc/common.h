@@ -202,7 +202,44 @@ struct ConvParams {
                          // tile instead: [B][tiles][256] floats (context_encoding.2 feeds AdaptiveAvgPool2d and nothing else)
     int in_pieces;       // 16-byte pieces of an input pixel (single-chunk layers) that exist in memory; 0 = all CK of them.
                          // Pieces beyond read as zeros: the 72-channel fusion buffers feed CK = 80 layers this way.
+    unsigned long long *stamps;  // diagnostic build (-DEMAVFI_DEFORM_STAMPS=1) only, else null: per-wave phase sums of the LDS-ring kernels
+                                 // (tools/ring_stamps.py; EMAVFI_STAMP_RING selects the launch)
 };
+
+// In-kernel stamps of the LDS-ring convolution kernels (diagnostic build only; cdna_hip_programming.md section 7): s_memtime at the
+// seams of a row step, per-wave sums over all steps of all items, one row of eight u64 per (workgroup, wave) at the end of the
+// kernel: {seg0..seg4, kernel total, kind, steps}.  The stamp waits lgkmcnt(0) (s_memtime is an SMEM instruction), i.e. it also drains
+// the wave's outstanding LDS accesses at the seam - the stamped kernel runs a few per cent slower than the product; read SHARES.
+#if defined(EMAVFI_DEFORM_STAMPS) && EMAVFI_DEFORM_STAMPS
+__device__ __forceinline__ unsigned long long ring_stamp()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define RING_STAMP_DECL unsigned long long rsum_[5] = {0, 0, 0, 0, 0}, rsteps_ = 0; const unsigned long long rbegin_ = ring_stamp()
+#define RING_STAMP(v) const unsigned long long v = ring_stamp()
+#define RING_STAMP_ADD(i, a, b) rsum_[i] += (b) - (a)
+#define RING_STAMP_STEP() ++rsteps_
+#define RING_STAMP_WRITE(p, kind, nwaves)                                                                  \
+    do {                                                                                                   \
+        const unsigned long long rend_ = ring_stamp();                                                     \
+        const unsigned row_ = blockIdx.x * (nwaves) + (threadIdx.x >> 6);                                  \
+        if ((p).stamps && (threadIdx.x & 63) == 0 && row_ < DEFORM_STAMP_ROWS) {                           \
+            unsigned long long *o_ = (p).stamps + (size_t)row_ * 8;                                        \
+            o_[0] = rsum_[0]; o_[1] = rsum_[1]; o_[2] = rsum_[2]; o_[3] = rsum_[3]; o_[4] = rsum_[4];      \
+            o_[5] = rend_ - rbegin_; o_[6] = (kind); o_[7] = rsteps_;                                      \
+        }                                                                                                  \
+    } while (0)
+#else
+#define RING_STAMP_DECL
+#define RING_STAMP(v)
+#define RING_STAMP_ADD(i, a, b)
+#define RING_STAMP_STEP()
+#define RING_STAMP_WRITE(p, kind, nwaves)
+#endif
 
 struct DeformParams {
     const void *x;     // channels-last T, CK channels used

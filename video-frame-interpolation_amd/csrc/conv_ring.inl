@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
         tdx[k] = tap - 3 * tdy[k];
     }
 
+    RING_STAMP_DECL;
 #pragma unroll 1
     for (int item = (int)blockIdx.x; item < nitems; item += (int)gridDim.x) {
         const int strip = item % nstrip, seg = item / nstrip;
@@ -258,19 +259,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
         int s0 = 0;   // ring slot of input row y - 1
 #pragma unroll 1
         for (int y = a0; y <= a1; ++y) {
+            RING_STAMP(ts0);
             // this wave's part of input row y + 1 (all but the youngest VMWAIT instructions) and its LDS writes of row y - 1
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C::VMWAIT) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            RING_STAMP(ts1);
             {
                 int sl = s0 + C::D + 1; sl = sl >= C::RING ? sl - C::RING : sl;
                 dma_row(y + C::D, sl, y + C::D <= a1 + 1);
             }
             if constexpr (HEAD) {
                 head_finish(y - 3, y - 3 >= ys && !(EMAVFI_RING_ABL & 2));
+                RING_STAMP(ts1b);
                 head_partial(y - 2);
+                RING_STAMP_ADD(4, ts1b, ring_stamp());
             } else
                 store_row(y - 1, y > a0 && !(EMAVFI_RING_ABL & 2));
+            RING_STAMP(ts2);
             f32x16 acc[2];
             {
                 // motion_estimation.0 (bias_mode 1): the folded context half depends on the pixel's border class
@@ -329,6 +335,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
                     __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks every read to just above its MFMA)
                 }
             }
+            RING_STAMP(ts3);
             // ---- optional ReLU; this wave's 32 channels of its 32 pixels into the row's staging buffer (HEAD: the ring of 64 -> 64
             // rows, zero outside the image: they are the head convolution's padding)
             {
@@ -355,6 +362,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
                 }
             }
             s0 = s0 + 1 >= C::RING ? 0 : s0 + 1;
+            RING_STAMP(ts4);
+            RING_STAMP_ADD(0, ts0, ts1); RING_STAMP_ADD(1, ts1, ts2); RING_STAMP_ADD(2, ts2, ts3); RING_STAMP_ADD(3, ts3, ts4);
+            RING_STAMP_STEP();
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the next item primes the same slots)
         __syncthreads();
@@ -367,6 +377,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
         } else
             store_row(a1, true);
     }
+    RING_STAMP_WRITE(p, 10 + (TAIL ? 1 : 0) + (HEAD ? 2 : 0), 4);
 }
 
 // Segment height: the item count should fill whole rounds of the 2-per-CU grid (a strip's segment re-reads two halo rows).

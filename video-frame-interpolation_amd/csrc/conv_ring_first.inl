@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringfirst_kernel(const FirstPa
         adx[kg] = tap - 3 * ady[kg];
     }
 
+    RING_STAMP_DECL;
 #pragma unroll 1
     for (int item = (int)blockIdx.x; item < nitems; item += (int)gridDim.x) {
         const int strip = item % nstrip, seg = item / nstrip;
@@ -126,10 +127,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringfirst_kernel(const FirstPa
         };
 #pragma unroll 1
         for (int t = a0; t <= ye + 1; ++t) {
+            RING_STAMP(ts0);
             __syncthreads();   // stage A's row t - 1, stage B's staged row t - 3 and frame row t + 1 are visible
+            RING_STAMP(ts1);
             float fnew[6];
             frame_load(t + 3, fnew);
             store_row(t - 3, t - 3 >= ys);
+            RING_STAMP(ts2);
 #if defined(EMAVFI_RF_ABL) && (EMAVFI_RF_ABL & 2)   // timing-only: no stage A
             if (t <= ye && t == -12345) {
 #else
@@ -171,6 +175,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringfirst_kernel(const FirstPa
                     *reinterpret_cast<__attribute__((address_space(3))) u4_t *>(mid + 16 * (g + h)) = u4_t{a[0], a[1], c[0], c[1]};
                 }
             }
+            RING_STAMP(ts3);
             const int yb = t - 2;
             if (yb >= ys) {
                 // ---- stage B: row yb of conv_block_0 from stage-A rows yb - 1 .. yb + 1 (conv3x3_ring_kernel's main loop)
@@ -221,13 +226,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringfirst_kernel(const FirstPa
                     *reinterpret_cast<__attribute__((address_space(3))) u4_t *>(stg + 16 * (g + h)) = u4_t{a[0], a[1], c[0], c[1]};
                 }
             }
+            RING_STAMP(ts4);
             frame_put(t + 2, fold);
 #pragma unroll
             for (int c = 0; c < 6; ++c) fold[c] = fnew[c];
+            RING_STAMP(ts5);
+            RING_STAMP_ADD(0, ts0, ts1); RING_STAMP_ADD(1, ts1, ts2); RING_STAMP_ADD(2, ts2, ts3); RING_STAMP_ADD(3, ts3, ts4); RING_STAMP_ADD(4, ts4, ts5);
+            RING_STAMP_STEP();
         }
         __syncthreads();
         store_row(ye - 1, true);
     }
+    RING_STAMP_WRITE(p, 15, 4);
 }
 
 template <typename T> static int launch_conv_ringfirst_t(const FirstParams &fp, const ConvParams &p, hipStream_t s)

@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvPara
         xcol[i] = q < C::ROWSLOT ? (unsigned)px : 0x40000000u;
     }
 
+    RING_STAMP_DECL;
 #pragma unroll 1
     for (int item = (int)blockIdx.x; item < nitems; item += (int)gridDim.x) {
         const int strip = item % nstrip, seg = item / nstrip;
@@ -207,19 +208,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvPara
         int s0 = 0;   // ring slot of input row y - 1
 #pragma unroll 1
         for (int y = a0; y <= a1; ++y) {
+            RING_STAMP(ts0);
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C::VMWAIT) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            RING_STAMP(ts1);
             {
                 int sl = s0 + C::D + 1; sl = sl >= C::RING ? sl - C::RING : sl;
                 dma_row(y + C::D, sl, y + C::D <= a1 + 1);
             }
+            RING_STAMP(ts2);
             // one basic block: the head's and finish_a's LDS round trips overlap (finish_a(a0 - 1) at the first step turns garbage into
             // row-ring slot 3, which finish_a(a0 + 3) rewrites before any head row reads it)
             head_row(y - 3, y - 3 >= ys);
+            RING_STAMP(ts3);
             finish_a(y - 1);
+            RING_STAMP(ts4);
             partial_a(y, s0);
             s0 = s0 + 1 >= C::RING ? 0 : s0 + 1;
+            RING_STAMP(ts5);
+            RING_STAMP_ADD(0, ts0, ts1); RING_STAMP_ADD(1, ts1, ts2); RING_STAMP_ADD(2, ts2, ts3); RING_STAMP_ADD(3, ts3, ts4); RING_STAMP_ADD(4, ts4, ts5);
+            RING_STAMP_STEP();
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -229,6 +238,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvPara
         head_row(a1 - 1, true);
         __syncthreads();   // the next item's first rows overwrite the rings and the partial sums
     }
+    RING_STAMP_WRITE(p, 14, 4);
 }
 
 template <typename T> static int launch_conv_ringtail(const ConvParams &p, hipStream_t s)

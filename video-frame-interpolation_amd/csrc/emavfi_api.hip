@@ -373,6 +373,11 @@ int run_conv(const Plan &P, const Layer &L, const void *packed, const void *in, 
     c.ck = L.ck; c.nf = L.nf; c.stride = L.stride; c.mfma16 = L.mfma16 ? 1 : 0; c.ring = L.ring;
 #if defined(EMAVFI_DEFORM_STAMPS) && EMAVFI_DEFORM_STAMPS
     if (L.ring == 4 && !planar) c.out_planar = reinterpret_cast<float *>(debug_stamp_buffer());   // diagnostic build: conv_wreg.inl's stamps (tools/wreg_stamps.py)
+    {   // diagnostic build: the LDS-ring kernels' stamps (tools/ring_stamps.py); EMAVFI_STAMP_RING = ring | tail | head | ringtail | ringfirst
+        const char *sel = getenv("EMAVFI_STAMP_RING");
+        const char *kind = first ? "ringfirst" : (head && L.ring == 2) ? "head" : (head && L.mfma16) ? "ringtail" : L.ring == 3 ? "tail" : (L.ring == 2 && !second) ? "ring" : "";
+        if (sel && kind[0] && strcmp(sel, kind) == 0) c.stamps = debug_stamp_buffer();
+    }
 #endif
     if (first) return P.dtype == EMAVFI_F16 ? launch_conv_ringfirst_f16(*first, c, s) : launch_conv_ringfirst_bf16(*first, c, s);
     if (L.f16_of_bf16 && !L.deform) return launch_conv3x3_f16(c, s);   // feat16: f16 activations in, bf16-rounded weights stored as f16

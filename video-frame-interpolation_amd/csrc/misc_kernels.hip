@@ -5,6 +5,7 @@
 #include <atomic>
 #include <type_traits>
 #include <cstddef>
+#include <cstdlib>
 
 int device_cu_count()
 {
@@ -987,6 +988,61 @@ __global__ void postprocess_u8x4_kernel(const float *__restrict__ src, unsigned 
             dst[g * 3 + k] = (unsigned)by[4 * k] | ((unsigned)by[4 * k + 1] << 8) | ((unsigned)by[4 * k + 2] << 16) | ((unsigned)by[4 * k + 3] << 24);
     }
 }
+// C = 3, the whole batch a multiple of 16 bytes on the uint8 side: one thread = ONE 16-byte quad of the interleaved byte stream
+// (5 1/3 pixels), so that a wave's access to the uint8 side is 1 KiB of consecutive addresses per instruction.  That side is pinned
+// host memory in the streaming harness (emavfi/stream.py): fine-grained, not cached by the GPU, every instruction its own PCIe
+// transactions - the dword kernels above touch every 64-byte line three times (three 12-byte-strided instructions per thread).  The
+// fp32 planes (HBM) are read / written as scalars at a lane stride of 5 1/3 floats: cached, cheap.  Byte g of the batch is channel
+// g % 3 of global pixel g / 3; same per-element arithmetic as the scalar kernels (round 5).
+__global__ __launch_bounds__(256) void preprocess_u8q_kernel(const uint4 *__restrict__ src, float *__restrict__ dst, size_t nquads, size_t plane,
+                                                             Stats4 st)
+{
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquads; q += (size_t)gridDim.x * blockDim.x) {
+        const uint4 v = src[q];
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+        const size_t g0 = q * 16;
+        size_t px = g0 / 3;
+        int c = (int)(g0 - px * 3);
+        size_t b = px / plane, pix = px - b * plane;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float u = (float)((w[j >> 2] >> (8 * (j & 3))) & 0xffu) / 255.0f;
+            dst[(b * 3 + c) * plane + pix] = (u - st.mean[c]) / st.stdv[c];
+            if (++c == 3) { c = 0; if (++pix == plane) { pix = 0; ++b; } }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void postprocess_u8q_kernel(const float *__restrict__ src, uint4 *__restrict__ dst, size_t nquads, size_t plane,
+                                                              Stats4d st, int denorm)
+{
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquads; q += (size_t)gridDim.x * blockDim.x) {
+        const size_t g0 = q * 16;
+        size_t px = g0 / 3;
+        int c = (int)(g0 - px * 3);
+        size_t b = px / plane, pix = px - b * plane;
+        unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            double v = (double)src[(b * 3 + c) * plane + pix];
+            if (denorm) v = v * st.stdv[c] + st.mean[c];
+            v = fmin(fmax(v, 0.0), 1.0) * 255.0;
+            w[j >> 2] |= (unsigned)(unsigned char)v << (8 * (j & 3));
+            if (++c == 3) { c = 0; if (++pix == plane) { pix = 0; ++b; } }
+        }
+        dst[q] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+// measurement knob (round 5): cap the grid of the quad kernels (EMAVFI_PREPOST_WGS=n; 0 / unset: one thread per quad up to 262 140 blocks)
+static int prepost_grid(size_t nq)
+{
+    static const int cap = [] { const char *e = getenv("EMAVFI_PREPOST_WGS"); return e ? atoi(e) : 0; }();
+    const size_t want = (nq + 255) / 256;
+    return (int)std::min<size_t>(want, cap > 0 ? (size_t)cap : (size_t)65535 * 4);
+}
+static bool u8q_ok(const void *u8, int B, int H, int W, int C)
+{
+    return C == 3 && ((size_t)B * H * W * 3) % 16 == 0 && ((uintptr_t)u8 & 15) == 0;
+}
 static bool u8x4_ok(const void *u8, const void *f32, int H, int W, int C)
 {
     return C == 3 && ((size_t)H * W) % 4 == 0 && ((uintptr_t)u8 & 3) == 0 && ((uintptr_t)f32 & 15) == 0;
@@ -996,6 +1052,12 @@ int launch_preprocess_u8(const unsigned char *src, float *dst, int B, int H, int
 {
     Stats4 st{};
     for (int c = 0; c < C && c < 4; ++c) { st.mean[c] = mean[c]; st.stdv[c] = stdv[c]; }
+    if (u8q_ok(src, B, H, W, C)) {
+        const size_t nq = (size_t)B * H * W * 3 / 16;
+        const int grid = prepost_grid(nq);
+        preprocess_u8q_kernel<<<grid, 256, 0, s>>>((const uint4 *)src, dst, nq, (size_t)H * W, st);
+        return (int)hipGetLastError();
+    }
     if (u8x4_ok(src, dst, H, W, C)) {
         const int grid = (int)std::min<size_t>(((size_t)B * H * W / 4 + 255) / 256, 65535 * 4);
         preprocess_u8x4_kernel<<<grid, 256, 0, s>>>((const unsigned *)src, dst, B, (size_t)H * W, st);
@@ -1010,6 +1072,12 @@ int launch_postprocess_u8(const float *src, unsigned char *dst, int B, int H, in
 {
     Stats4d st{};
     for (int c = 0; c < C && c < 4; ++c) { st.mean[c] = mean[c]; st.stdv[c] = stdv[c]; }
+    if (u8q_ok(dst, B, H, W, C)) {
+        const size_t nq = (size_t)B * H * W * 3 / 16;
+        const int grid = prepost_grid(nq);
+        postprocess_u8q_kernel<<<grid, 256, 0, s>>>(src, (uint4 *)dst, nq, (size_t)H * W, st, denorm);
+        return (int)hipGetLastError();
+    }
     if (u8x4_ok(dst, src, H, W, C)) {
         const int grid4 = (int)std::min<size_t>(((size_t)B * H * W / 4 + 255) / 256, 65535 * 4);
         postprocess_u8x4_kernel<<<grid4, 256, 0, s>>>(src, (unsigned *)dst, B, (size_t)H * W, st, denorm);

@@ -427,10 +427,11 @@ def _pinned_or_cuda(t, what):
         raise RuntimeError(f"{what}: a ROCm tensor or a PINNED host tensor (read / written by the kernel over PCIe) is expected")
 
 
-def preprocess_u8(frames_hwc, mean=IMAGENET_MEAN, std=IMAGENET_STD, device=None):
+def preprocess_u8(frames_hwc, mean=IMAGENET_MEAN, std=IMAGENET_STD, device=None, out=None):
     """ToTensor + Normalize of reference inference.py:38-41 on the GPU: uint8 [B,H,W,C] -> fp32 [B,C,H,W].
     `frames_hwc` may be a pinned host tensor: the kernel then reads it in place over PCIe (no separate H2D copy;
-    `device` names the GPU) - the caller keeps it unchanged until the kernel has run."""
+    `device` names the GPU) - the caller keeps it unchanged until the kernel has run.  `out`: a contiguous fp32 [B,C,H,W] device
+    tensor to fill (the streaming harness keeps one per buffer slot, so nothing is allocated on its side streams)."""
     import torch
     _pinned_or_cuda(frames_hwc, "preprocess_u8")
     if frames_hwc.dtype != torch.uint8 or frames_hwc.dim() != 4:
@@ -439,7 +440,10 @@ def preprocess_u8(frames_hwc, mean=IMAGENET_MEAN, std=IMAGENET_STD, device=None)
     dev = x.device if x.is_cuda else torch.device(device if device is not None else "cuda")
     B, H, W, C = x.shape
     m, s = _stats(mean, std, C)
-    out = torch.empty(B, C, H, W, dtype=torch.float32, device=dev)
+    if out is None:
+        out = torch.empty(B, C, H, W, dtype=torch.float32, device=dev)
+    elif not (out.is_cuda and out.dtype == torch.float32 and tuple(out.shape) == (B, C, H, W) and out.is_contiguous()):
+        raise ValueError("preprocess_u8: out must be a contiguous fp32 [B,C,H,W] device tensor")
     with torch.cuda.device(dev):
         check(load().emavfi_preprocess_u8(x.data_ptr(), out.data_ptr(), B, H, W, C, m, s, _stream()), "emavfi_preprocess_u8")
     return out

@@ -18,12 +18,16 @@ What changes is how the work is scheduled, not what is computed:
   * ToTensor/Normalize and denormalize/clip/uint8 run on the GPU (emavfi_preprocess_u8 / _postprocess_u8);
   * the ``interpolation_factor`` identical forwards of a pair are computed once and emitted that many
     times (bit-identical to recomputing them);
-  * uint8 frames cross PCIe inside the pre/post-processing kernels themselves: emavfi_preprocess_u8 reads the
-    batch's distinct frames straight out of a pinned host buffer and emavfi_postprocess_u8 writes the result
-    frames straight into one (zero-copy; there is no separate H2D/D2H copy to schedule - copies queued beside
-    kernels that fill every CU were seen to wait tens of milliseconds).  Two buffer slots: the host fills slot
-    k+1 and drains slot k-1 while the GPU works on slot k; consecutive pairs share a frame, so a batch of n
-    pairs reads n+1 frames (frame_interval 1), not 2n.
+  * THREE streams (round 5; the reference: one, with a blocking D2H per frame, inference.py:53): the uint8 frames of batch k + 1
+    travel host -> HBM by hipMemcpyAsync (the SDMA engines: no compute unit involved) and are normalised by a short device kernel
+    on a high-priority side stream while the caller's stream computes batch k; the predictions of batch k - 1 are turned into
+    uint8 by a device kernel and copied HBM -> host on another one - chained by events.  Two buffer slots of pinned host
+    memory: the host fills slot k+1 and drains slot k-1 while the GPU works on slot k; consecutive pairs share a frame, so a
+    batch of n pairs moves n+1 frames (frame_interval 1), not 2n.  Measured beside back-to-back B = 8 x 720p forwards
+    (tools/copy_beside_compute.py, profiles/r05_stream_*): a copy + device kernel leg costs the forward 0.6-1.2 % of its rate,
+    where the round-1..4 form - the pre / post kernels reading / writing the pinned buffers themselves over PCIe
+    (``zero_copy=True`` keeps it) - costs 4.6-5.5 % per leg even on a side stream: a kernel that waits on PCIe holds its
+    wave slots, and the persistent convolution kernels need all of them.
 ``mode="recursive"`` (opt-in, not in the reference, which has no timestep input) replaces the repeated
 identical prediction by recursive midpoints: factor 1 -> [1/2]; factor 3 -> [1/4, 1/2, 3/4]; factor 7 -> eighths.
 ``reference_quirks=False`` drops the de-normalisation of the already-[0,1] model output (appendix A of
@@ -41,7 +45,7 @@ from . import lib as _lib
 
 class FrameInterpolator:
     def __init__(self, model, interpolation_factor: int = 1, frame_interval: int = 1, batch_pairs: int = 8,
-                 reference_quirks: bool = True, mode: str = "reference", device=None, copy_out: bool = True):
+                 reference_quirks: bool = True, mode: str = "reference", device=None, copy_out: bool = True, zero_copy: bool = False):
         if interpolation_factor < 0 or frame_interval < 1 or batch_pairs < 1:
             raise ValueError("interpolation_factor >= 0, frame_interval >= 1, batch_pairs >= 1 required")
         if mode not in ("reference", "recursive"):
@@ -63,6 +67,8 @@ class FrameInterpolator:
         # advanced again - enough for a writer that consumes each frame at once; saves a page-faulting 2.8-6 MB
         # allocation + copy per frame)
         self.copy_out = bool(copy_out)
+        # True: the round-1..4 transport (the pre / post kernels read / write the pinned host buffers in place) instead of SDMA copies
+        self.zero_copy = bool(zero_copy)
 
     # ---- the reference's frame selection (inference.py:158-201), as (pairs, tail) over frame indices
     @staticmethod
@@ -121,7 +127,7 @@ class FrameInterpolator:
             plan.append(("tail", last, bool(last_roundtrip and reference_quirks)))
         return plan
 
-    # ---- buffers: two slots of pinned host memory the kernels read / write in place
+    # ---- buffers: two slots of pinned host memory the kernels read / write in place, the preprocessed frames of a slot in HBM
     def _alloc(self, shape):
         if self._shape == shape:
             return
@@ -134,8 +140,29 @@ class FrameInterpolator:
                 "h_in": torch.empty(2 * nb, H, W, C, dtype=torch.uint8).pin_memory(),
                 "h_pred": torch.empty(nb * nout, H, W, C, dtype=torch.uint8).pin_memory(),
                 "h_src": torch.empty(nb, H, W, C, dtype=torch.uint8).pin_memory(),
-                "consumed": torch.cuda.Event(), "done": torch.cuda.Event(),
+                "x": torch.empty(2 * nb, C, H, W, dtype=torch.float32, device=self.device),
+                # device-side images of the three pinned buffers (the SDMA copies' other end)
+                "d_in": torch.empty(2 * nb, H, W, C, dtype=torch.uint8, device=self.device),
+                "d_pred": torch.empty(nb * nout, H, W, C, dtype=torch.uint8, device=self.device),
+                "d_src": torch.empty(nb, H, W, C, dtype=torch.uint8, device=self.device),
+                # consumed: the preprocess kernel has read h_in (the host may restage it); pre: x is ready; fwd: the forward has read x
+                # and written its predictions; done: the postprocess kernels have written h_pred / h_src (the host may drain them)
+                "consumed": torch.cuda.Event(), "pre": torch.cuda.Event(), "fwd": torch.cuda.Event(), "done": torch.cuda.Event(),
+                "src": torch.cuda.Event(),
             })
+        # high-priority lanes: a 9-frame preprocess needs < 1 % of the CUs' time, the priority gets its workgroups dispatched between
+        # those of the compute kernels (torch: lower number = higher priority)
+        self._pre = _lib.side_stream(self.device, which=2, priority=-1)
+        self._post = _lib.side_stream(self.device, which=3, priority=-1)
+
+    _pool = None
+
+    @classmethod
+    def _copy_pool(cls):
+        if cls._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            cls._pool = ThreadPoolExecutor(max_workers=8, thread_name_prefix="emavfi-stage")
+        return cls._pool
 
     def _stage(self, slot, frames, chunk):
         """Copy the distinct frames of `chunk` into the slot's pinned input buffer.
@@ -150,8 +177,13 @@ class FrameInterpolator:
         # plain single-threaded memcpy: a torch CPU copy_ fans out over the intra-op thread pool, which on a
         # CPU-share-limited box (more threads than granted cores) was seen to stall for 40-160 ms at a time
         h_in = slot["h_in"].numpy()
-        for i, f in enumerate(order):
-            np.copyto(h_in[i], frames[f])
+        if len(order) >= 4 and h_in[0].nbytes >= (1 << 20):
+            # a few plain memcpy threads (numpy releases the GIL inside copyto): the FIRST batch's staging is the one piece of host work
+            # nothing overlaps (2.5-5 ms for nine 720p frames on one thread = 4-6 % of a 64-pair run)
+            list(self._copy_pool().map(lambda t: np.copyto(h_in[t[0]], frames[t[1]]), enumerate(order)))
+        else:
+            for i, f in enumerate(order):
+                np.copyto(h_in[i], frames[f])
         # positions stay on the host: a device index tensor would be a synchronous pageable copy on the
         # main stream, i.e. the host would block behind the compute it has just enqueued
         return len(order), [pos[a] for a, _ in chunk], [pos[b] for _, b in chunk]
@@ -208,7 +240,12 @@ class FrameInterpolator:
                 raise ValueError("FrameInterpolator.run: same-shape uint8 HWC frames expected")
         self._alloc(first.shape)
         main = torch.cuda.current_stream(self.device)
-        chunks = [pairs[i:i + self.batch_pairs] for i in range(0, len(pairs), self.batch_pairs)]
+        # ramp-up: with three or more batches to come the FIRST one is half-size - the GPU starts after five staged frames instead of
+        # nine, and (64 pairs at batch 8: 4 + 7 x 8 + 4) the last one's drain is half as long; every other batch is full.  Per-sample
+        # results do not depend on the batch a pair travels in (tests/test_gpu_parity.py::test_forward_config2_batch16_256)
+        bp = self.batch_pairs
+        head = bp // 2 if (bp >= 2 and len(pairs) > 2 * bp) else 0
+        chunks = ([pairs[:head]] if head else []) + [pairs[i:i + bp] for i in range(head, len(pairs), bp)]
         npred = self.factor if self.mode == "recursive" else 1
 
         def drain(slot, chunk):
@@ -230,14 +267,48 @@ class FrameInterpolator:
             slot = self._slots[ci & 1]
             nup, ia, ib = staged
             n = len(chunk)
-            x = _lib.preprocess_u8(slot["h_in"][:nup], device=self.device)   # distinct frames, read over PCIe, normalised once
-            slot["consumed"].record(main)
+            with torch.cuda.stream(self._pre):
+                # the slot's x was last read by the forward of batch ci - 2 (main) and by the round-trip postprocess of its frames (post)
+                self._pre.wait_event(slot["fwd"])
+                self._pre.wait_event(slot["done"])
+                if self.zero_copy:
+                    x = _lib.preprocess_u8(slot["h_in"][:nup], device=self.device, out=slot["x"][:nup])   # distinct frames, read over PCIe, normalised once
+                    slot["consumed"].record(self._pre)
+                else:
+                    slot["d_in"][:nup].copy_(slot["h_in"][:nup], non_blocking=True)                       # hipMemcpyAsync pinned -> HBM (SDMA)
+                    slot["consumed"].record(self._pre)
+                    x = _lib.preprocess_u8(slot["d_in"][:nup], out=slot["x"][:nup])                       # distinct frames, normalised once
+                slot["pre"].record(self._pre)
+                src_here = self.quirks and not self.zero_copy and all(ia[k + 1] == ia[k] + 1 for k in range(n - 1))
+                if src_here:
+                    # the reference's round trip of every pair's earlier frame (inference.py:187-188) depends on the preprocess only:
+                    # it leaves from this lane, ahead of the forward, instead of queueing behind the predictions at the end of the batch
+                    _lib.postprocess_u8(x[ia[0]:ia[0] + n], denormalize=True, out=slot["d_src"][:n])
+                    slot["h_src"][:n].copy_(slot["d_src"][:n], non_blocking=True)
+                    slot["src"].record(self._pre)
+            main.wait_event(slot["pre"])
             x1, x2 = self._rows(x, ia), self._rows(x, ib)
-            pred = self._predict(x1, x2)                                      # [n, k, 3, H, W]
-            _lib.postprocess_u8(pred.reshape(-1, *pred.shape[2:]), denormalize=self.quirks, out=slot["h_pred"][:n * npred])
-            if self.quirks:
-                _lib.postprocess_u8(x1, denormalize=True, out=slot["h_src"][:n])
-            slot["done"].record(main)
+            pred = self._predict(x1, x2)                                      # [n, k, 3, H, W], on the caller's stream
+            slot["fwd"].record(main)
+            with torch.cuda.stream(self._post):
+                self._post.wait_event(slot["fwd"])
+                flat = pred.reshape(-1, *pred.shape[2:])
+                flat.record_stream(self._post)                                # allocated on the caller's stream, read on this one
+                if self.quirks and (x1.data_ptr() < slot["x"].data_ptr() or x1.data_ptr() >= slot["x"].data_ptr() + slot["x"].numel() * 4):
+                    x1.record_stream(self._post)                              # a gathered copy (non-consecutive rows), not a view of the slot
+                if self.zero_copy:
+                    _lib.postprocess_u8(flat, denormalize=self.quirks, out=slot["h_pred"][:n * npred])
+                    if self.quirks:
+                        _lib.postprocess_u8(x1, denormalize=True, out=slot["h_src"][:n])
+                else:
+                    _lib.postprocess_u8(flat, denormalize=self.quirks, out=slot["d_pred"][:n * npred])
+                    slot["h_pred"][:n * npred].copy_(slot["d_pred"][:n * npred], non_blocking=True)       # HBM -> pinned (SDMA)
+                    if self.quirks and not src_here:
+                        _lib.postprocess_u8(x1, denormalize=True, out=slot["d_src"][:n])
+                        slot["h_src"][:n].copy_(slot["d_src"][:n], non_blocking=True)
+                    if src_here:
+                        self._post.wait_event(slot["src"])                    # `done` covers both lanes' writes into the pinned buffers
+                slot["done"].record(self._post)
             if ci + 1 < len(chunks):                  # host-side staging of the next batch overlaps this batch's compute
                 staged = self._stage(self._slots[(ci + 1) & 1], frames, chunks[ci + 1])
             if prev is not None:                      # emit the previous batch (its slot is reused only after this)
