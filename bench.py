@@ -541,7 +541,7 @@ def profiled_mode(hip, sd, dev, dtype, B, H, W, steps):
     hip.destroy(ev)
     roof["traffic"], roof["traffic_source"] = stored_traffic(roof["kernel"], f"traffic_{dtype}_{B}x{H}x{W}.json")
     res = {"value": round(B * steps / el, 2), "unit": "frames/s", "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,
-           "pairs_per_step": B, "height": H, "width": W, "dtype": dtype, "roofline": roof, "kernels": table[:6],
+           "pairs_per_step": B, "height": H, "width": W, "dtype": dtype, "roofline": roof, "kernels": table[:12],
            "device_ms_per_step_sum_of_kernels": round(total_ms / steps, 3)}
     warp = warp_in_forward(table, agg, dtype, B * H * W)
     if warp:

@@ -266,6 +266,8 @@ struct DeformParams {
     int pack3;     // weights are in the deform_pack3.inl layout (K = 64 per tap + im2col tail, third fragment as an LDS table);
                    // 3: fp32, the deform_f32w.inl layout
     int in_f16, out_f16;  // bf16 storage only: x (and x_tail) / out hold IEEE f16 bit patterns (tensors handed between consecutive packs)
+    void *out16;          // fp32 LDS-window kernel (deform_f32w.inl) only, EMAVFI_AMP16: ALSO write the result's fp16 rounding, channels-last with
+    int out16_ps;         // pixel stride out16_ps (elements) - what the fp16 offset_conv / reconstruction.0 read (was a separate conversion pass)
     unsigned long long *stamps;  // diagnostic build (-DEMAVFI_DEFORM_STAMPS=1) only, else null
 };
 #define DEFORM_STAMP_STRIDE 14

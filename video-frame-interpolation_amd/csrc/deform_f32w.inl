@@ -283,6 +283,12 @@ __global__ __launch_bounds__(256, 2) void deform_f32w_kernel(const DeformParams 
 #pragma unroll
         for (int c = 0; c < 5; ++c)
             if (16 * c + 4 * kb < p.cstore) *reinterpret_cast<f32x4 *>(op + 16 * c + 4 * kb) = acc[c][blk];
+        if (p.out16) {   // EMAVFI_AMP16: the fp16 rounding of the same values (round-to-nearest-even, as Tensor.half() does), in the same launch
+            half_t *oh = reinterpret_cast<half_t *>(p.out16) + (((size_t)b * H + py_y[blk]) * W + px_x) * p.out16_ps;
+#pragma unroll
+            for (int c = 0; c < 5; ++c)
+                if (16 * c + 4 * kb < p.cstore) store4(oh + 16 * c + 4 * kb, acc[c][blk][0], acc[c][blk][1], acc[c][blk][2], acc[c][blk][3]);
+        }
     }
 }
 

@@ -372,7 +372,7 @@ int run_conv(const Plan &P, const Layer &L, const void *packed, const void *in, 
     c.epi = epi; c.nplanes = nplanes; c.bias_mode = bias_table ? 1 : 0;
     c.ck = L.ck; c.nf = L.nf; c.stride = L.stride; c.mfma16 = L.mfma16 ? 1 : 0; c.ring = L.ring;
 #if defined(EMAVFI_DEFORM_STAMPS) && EMAVFI_DEFORM_STAMPS
-    if (L.ring == 4 && !planar) c.out_planar = reinterpret_cast<float *>(debug_stamp_buffer());   // diagnostic build: conv_wreg.inl's stamps (tools/wreg_stamps.py)
+    if (L.ring == 4 && !planar && !getenv("EMAVFI_STAMP_RING")) c.out_planar = reinterpret_cast<float *>(debug_stamp_buffer());   // diagnostic build: conv_wreg.inl's stamps (tools/wreg_stamps.py)
     {   // diagnostic build: the LDS-ring kernels' stamps (tools/ring_stamps.py); EMAVFI_STAMP_RING = ring | tail | head | ringtail | ringfirst
         const char *sel = getenv("EMAVFI_STAMP_RING");
         const char *kind = first ? "ringfirst" : (head && L.ring == 2) ? "head" : (head && L.mfma16) ? "ringtail" : L.ring == 3 ? "tail" : (L.ring == 2 && !second) ? "ring" : "";
@@ -397,7 +397,7 @@ unsigned long long *debug_stamp_buffer()
 
 int run_deform(const Plan &P, const Layer &L, const void *packed, const void *x, int x_ps, float *om, void *out,
                int out_ps, int cstore, int B, int H, int W, hipStream_t s, const void *zeros = nullptr, const Layer *off = nullptr,
-               const void *x_tail = nullptr, int tail_ps = 0, int force_dtype = -1, int in_f16 = 0, int out_f16 = 0)
+               const void *x_tail = nullptr, int tail_ps = 0, int force_dtype = -1, int in_f16 = 0, int out_f16 = 0, void *out16 = nullptr, int out16_ps = 0)
 {
     const int kd = force_dtype >= 0 ? force_dtype : P.dtype;
     DeformParams d{};
@@ -412,12 +412,13 @@ int run_deform(const Plan &P, const Layer &L, const void *packed, const void *x,
     d.zeros = zeros ? zeros : (const char *)packed + P.zero_off;
     d.x_ps = x_ps; d.out_ps = out_ps; d.H = H; d.W = W; d.B = B; d.cstore = cstore; d.cin_real = L.cin_take; d.ck = L.ck; d.nf = L.nf;
     d.cout_real = L.cout; d.pack3 = L.pack3; d.in_f16 = in_f16; d.out_f16 = out_f16;
+    d.out16 = out16; d.out16_ps = out16_ps;
 #if defined(EMAVFI_DEFORM_STAMPS) && EMAVFI_DEFORM_STAMPS
     {   // diagnostic build: EMAVFI_STAMP_PACK=i records only the i-th deformable launch of every 3 (default: every launch,
         // i.e. what is read back is the last pack of a forward)
         static int calls = 0;
         const char *sel = getenv("EMAVFI_STAMP_PACK");
-        if (!sel || (calls % 3) == atoi(sel)) d.stamps = debug_stamp_buffer();
+        if ((!sel || (calls % 3) == atoi(sel)) && !getenv("EMAVFI_STAMP_RING")) d.stamps = debug_stamp_buffer();   // (the ring kernels' stamps share the buffer)
         ++calls;
     }
 #endif
@@ -579,16 +580,24 @@ int attention_block(const Plan &P, int i, const void *packed, const void *x, voi
     }
     return EMAVFI_OK;
 }
-// EMAVFI_AMP16: fp16 offset_conv on the fp16 rounding x16 of the fusion tensor, fp32 deform_conv2d on the fp32 tensor xF -> yF
-int attention_block_amp(const Plan &P, int i, const void *packed, const void *x16, const float *xF, float *yF, float *om, int B, int H, int W,
+// EMAVFI_AMP16: fp16 offset_conv on the fp16 rounding x16 of the fusion tensor, fp32 deform_conv2d on the fp32 tensor xF -> yF; y16 receives
+// the fp16 rounding of yF - from the DCN's own epilogue where the fp32 LDS-window kernel serves the shape (round 5: was a conversion
+// pass per block), else from launch_convert_cl
+bool amp_dcn_writes_fp16(const Plan &P, int i) { return P.dcn32[i].pack3 == 3; }
+int attention_block_amp(const Plan &P, int i, const void *packed, const void *x16, const float *xF, float *yF, void *y16, float *om, int B, int H, int W,
                         hipStream_t s, Recorder &rec)
 {
     const double px = (double)B * H * W, cf = P.mid + 3;
+    const size_t npx = (size_t)B * H * W;
     double fl, by;
     conv_work(P, P.off[i], B, H, W, 4.0, fl, by);
     EMAVFI_STEP(rec, conv_name(P, P.off[i]) + " offset_conv", fl, by, run_conv(P, P.off[i], packed, x16, P.fps, H, W, om, 32, 0, 32, EPI_OM, B, s));
-    EMAVFI_STEP(rec, "deform<f32,ck=80,nf=3> dcn_v2 (fp32 under autocast)", 2.0 * 9.0 * cf * cf * px, px * (2.0 * cf * 4.0 + 27.0 * 4.0) + 9.0 * cf * cf * 4.0,
-                run_deform(P, P.dcn32[i], packed, xF, P.fpad, om, yF, P.fpad, P.fpad, B, H, W, s, nullptr, nullptr, nullptr, 0, EMAVFI_F32));
+    const bool both = amp_dcn_writes_fp16(P, i) && y16 != nullptr;
+    EMAVFI_STEP(rec, both ? "deform<f32,ck=80,nf=3> dcn_v2 (fp32 under autocast; writes fp32 + its fp16 rounding)" : "deform<f32,ck=80,nf=3> dcn_v2 (fp32 under autocast)",
+                2.0 * 9.0 * cf * cf * px, px * (2.0 * cf * 4.0 + 27.0 * 4.0 + (both ? cf * 2.0 : 0.0)) + 9.0 * cf * cf * 4.0,
+                run_deform(P, P.dcn32[i], packed, xF, P.fpad, om, yF, P.fpad, P.fpad, B, H, W, s, nullptr, nullptr, nullptr, 0, EMAVFI_F32, 0, 0,
+                           both ? y16 : nullptr, P.fps));
+    if (!both && y16) EMAVFI_STEP(rec, "fusion_round", 0, px * cf * 6.0, launch_convert_cl(yF, y16, npx, P.fpad, P.fps, 0, P.fpad, 0, s));
     return EMAVFI_OK;
 }
 
@@ -812,18 +821,16 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
         // flow and cat(feat, warped) promotes to fp32, so the fusion tensor exists twice: fp32 (fuF: what the fp32
         // deform_conv2d reads and writes, never rounded between blocks) and its fp16 rounding (fu: what the fp16
         // offset_conv / reconstruction.0 read).
-        const double cf = mid + 3;
         float *xF = f.fuF0, *yF = f.fuF1;
-        EMAVFI_STEP(rec, "warp_fused<f32>", 24.0 * px, px * (8.0 + 8.0 * C),
-                    launch_warp_fused(frame2, f.flow, xF, B, C, H, W, P.fpad, mid, EMAVFI_F32, s));
+        // (round 5: the warp writes the fp32 values AND their fp16 rounding - was the conversion pass fusion_round_warped)
+        EMAVFI_STEP(rec, "warp_fused<f32>", 24.0 * px, px * (8.0 + 8.0 * C + 2.0 * C),
+                    launch_warp_fused(frame2, f.flow, xF, B, C, H, W, P.fpad, mid, EMAVFI_F32, s, f.fu0, P.fps));
         EMAVFI_STEP(rec, "fusion_widen_feat", 0, px * mid * 6.0, launch_convert_cl(f.fu0, xF, npx, P.fps, P.fpad, 0, mid, 1, s));
-        EMAVFI_STEP(rec, "fusion_round_warped", 0, px * 16 * 6.0, launch_convert_cl(xF, f.fu0, npx, P.fpad, P.fps, mid, P.fpad - mid, 0, s));
         if (!rec.dry && taps && taps[3])
             EMAVFI_TRY(launch_cl_to_nchw(xF, taps[3], B, C, H, W, P.fpad, mid, EMAVFI_F32, s), "tap warped");
         EMAVFI_STAGE_EVENT(rec, 0);
         for (int i = 0; i < P.nb; ++i) {
-            if (const int rc = attention_block_amp(P, i, packed, x, xF, yF, f.om, B, H, W, s, rec); rc != EMAVFI_OK) return rc;
-            EMAVFI_STEP(rec, "fusion_round", 0, px * cf * 6.0, launch_convert_cl(yF, y, npx, P.fpad, P.fps, 0, P.fpad, 0, s));
+            if (const int rc = attention_block_amp(P, i, packed, x, xF, yF, y, f.om, B, H, W, s, rec); rc != EMAVFI_OK) return rc;
             if (!rec.dry && taps && taps[5 + i])
                 EMAVFI_TRY(launch_cl_to_nchw(yF, taps[5 + i], B, mid + 3, H, W, P.fpad, 0, EMAVFI_F32, s), "tap fused");
             void *t = x; x = y; y = t;
@@ -1308,7 +1315,7 @@ static int mdcn_impl(const float *x, const float *offset_weight, const float *of
     if (P.amp) {
         EMAVFI_TRY(launch_nchw_to_cl(x, m.xF, B, C, H, W, P.fpad, EMAVFI_F32, s), "mdcn layout in (fp32)");
         EMAVFI_TRY(launch_nchw_to_cl(x, m.xcl, B, C, H, W, P.fps, EMAVFI_F16, s), "mdcn layout in (fp16 rounding)");
-        if (const int rc = attention_block_amp(P, 0, m.blob, m.xcl, m.xF, m.yF, m.om, B, H, W, s, rec); rc != EMAVFI_OK) return rc;
+        if (const int rc = attention_block_amp(P, 0, m.blob, m.xcl, m.xF, m.yF, nullptr, m.om, B, H, W, s, rec); rc != EMAVFI_OK) return rc;
         EMAVFI_TRY(launch_cl_to_nchw(m.yF, y, B, C, H, W, P.fpad, 0, EMAVFI_F32, s), "mdcn layout out");
         return EMAVFI_OK;
     }

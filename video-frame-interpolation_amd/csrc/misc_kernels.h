@@ -63,8 +63,10 @@ int launch_pool_partial(const void *src, float *part, int B, int npix, int cp, i
 int launch_ctx_finish(const float *part, const float *ctxw, float *ctx_out, float *table, int B, int m, int cp, int nparts,
                       int npix, int coutpad, int round16, hipStream_t s);
 int launch_warp_nchw(const float *frame2, const float *flow, float *out, int B, int C, int H, int W, hipStream_t s);
+// dst16 / ps16 (fp32 variant only, EMAVFI_AMP16): also write the fp16 rounding of the same values into channels [coff, ps16) of a second
+// channels-last tensor
 int launch_warp_fused(const float *frame2, const float *flow, void *dst, int B, int C, int H, int W, int ps, int coff, int dtype,
-                      hipStream_t s);
+                      hipStream_t s, void *dst16 = nullptr, int ps16 = 0);
 int launch_preprocess_u8(const unsigned char *src, float *dst, int B, int H, int W, int C, const float *mean, const float *stdv,
                          hipStream_t s);
 int launch_postprocess_u8(const float *src, unsigned char *dst, int B, int H, int W, int C, const double *mean, const double *stdv,

@@ -688,7 +688,7 @@ __device__ const float g_zero_page[64] = {0};
 template <int C, typename T>
 __global__ __launch_bounds__(256) void warp_tiled_kernel(const float *__restrict__ frame2, const float *__restrict__ flow,
                                                          float *__restrict__ out, int B, int H, int W, void *cl_dst, int ps,
-                                                         int coff)
+                                                         int coff, void *cl_dst16 = nullptr, int ps16 = 0)
 {
     constexpr int TH = 32, TW = 64, R = 8, WR = TH + 2 * R + 1, WC = 84, PCS = WC / 4;
     constexpr int NPIECE = C * WR * PCS, NINST = (NPIECE + 63) / 64;
@@ -825,6 +825,23 @@ __global__ __launch_bounds__(256) void warp_tiled_kernel(const float *__restrict
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 T *o = reinterpret_cast<T *>(cl_dst) + ((size_t)b * plane + pix + q) * ps + coff;
+                if constexpr (std::is_same<T, float>::value) {
+                    // EMAVFI_AMP16: the fp16 rounding of the same values into channels [coff, ps16) of a second (fp16) fusion tensor, in the
+                    // same launch (was a conversion pass of its own: fusion_round_warped)
+                    if (cl_dst16) {
+                        half_t *o16 = reinterpret_cast<half_t *>(cl_dst16) + ((size_t)b * plane + pix + q) * ps16 + coff;
+                        if (ps16 - coff == 16 && (coff & 7) == 0 && (ps16 & 7) == 0) {   // mid_channels 64: channels 64..79 as two 16-byte stores
+                            typedef __attribute__((ext_vector_type(8))) half_t h8;
+                            const half_t z = (half_t)0.0f;
+                            *reinterpret_cast<h8 *>(o16) = h8{(half_t)v[0][q], C > 1 ? (half_t)v[C > 1 ? 1 : 0][q] : z, C > 2 ? (half_t)v[C > 2 ? 2 : 0][q] : z, z, z, z, z, z};
+                            *reinterpret_cast<h8 *>(o16 + 8) = h8{z, z, z, z, z, z, z, z};
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < C; ++c) o16[c] = (half_t)v[c][q];
+                            for (int c = C; c < ps16 - coff; ++c) o16[c] = (half_t)0.0f;
+                        }
+                    }
+                }
                 if (ps - coff == 16 && (coff & 7) == 0) {  // mid_channels 64: channels 64..79, aligned
                     store4(o, v[0][q], C > 1 ? v[C > 1 ? 1 : 0][q] : 0.0f, C > 2 ? v[C > 2 ? 2 : 0][q] : 0.0f, 0.0f);
                     store4(o + 4, 0.0f, 0.0f, 0.0f, 0.0f);
@@ -871,7 +888,8 @@ int launch_warp_nchw(const float *frame2, const float *flow, float *out, int B, 
 // past coff + C are the zero padding.
 template <typename T>
 __global__ __launch_bounds__(256) void warp_fused_kernel(const float *__restrict__ frame2, const float *__restrict__ flow,
-                                                         T *__restrict__ dst, int B, int C, int H, int W, int ps, int coff)
+                                                         T *__restrict__ dst, int B, int C, int H, int W, int ps, int coff,
+                                                         half_t *__restrict__ dst16 = nullptr, int ps16 = 0)
 {
     const size_t plane = (size_t)H * W, total = (size_t)B * plane;
     const float wden = (float)max(W - 1, 1), hden = (float)max(H - 1, 1);
@@ -880,21 +898,26 @@ __global__ __launch_bounds__(256) void warp_fused_kernel(const float *__restrict
         const int y = (int)(pix / W), x = (int)(pix - (size_t)y * W);
         const WarpTap t = warp_tap(x, y, flow[(b * 2) * plane + pix], flow[(b * 2 + 1) * plane + pix], H, W, wden, hden);
         T *o = dst + i * ps + coff;
-        for (int c = 0; c < ps - coff; ++c) o[c] = (T)(c < C ? warp_sample(frame2 + (b * C + c) * plane, t) : 0.0f);
+        for (int c = 0; c < ps - coff; ++c) {
+            const float v = c < C ? warp_sample(frame2 + (b * C + c) * plane, t) : 0.0f;
+            o[c] = (T)v;
+            if (dst16 && c < ps16 - coff) dst16[i * ps16 + coff + c] = (half_t)v;
+        }
     }
 }
 int launch_warp_fused(const float *frame2, const float *flow, void *dst, int B, int C, int H, int W, int ps, int coff, int dtype,
-                      hipStream_t s)
+                      hipStream_t s, void *dst16, int ps16)
 {
+    if (dst16 && (dtype != 0 || ps16 - coff > ps - coff)) return (int)hipErrorInvalidValue;   // the second (fp16) destination belongs to the fp32 variant
     if ((W & 3) == 0 && C == 3) {
         const int nwg = ((W + 63) / 64) * ((H + 31) / 32) * B;
-        if (dtype == 0) warp_tiled_kernel<3, float><<<nwg, 256, 0, s>>>(frame2, flow, nullptr, B, H, W, dst, ps, coff);
+        if (dtype == 0) warp_tiled_kernel<3, float><<<nwg, 256, 0, s>>>(frame2, flow, nullptr, B, H, W, dst, ps, coff, dst16, ps16);
         else if (dtype == 2) warp_tiled_kernel<3, half_t><<<nwg, 256, 0, s>>>(frame2, flow, nullptr, B, H, W, dst, ps, coff);
         else warp_tiled_kernel<3, bf16_t><<<nwg, 256, 0, s>>>(frame2, flow, nullptr, B, H, W, dst, ps, coff);
         return (int)hipGetLastError();
     }
     const int grid = (int)std::min<size_t>(((size_t)B * H * W + 255) / 256, 256 * 64);
-    if (dtype == 0) warp_fused_kernel<float><<<grid, 256, 0, s>>>(frame2, flow, (float *)dst, B, C, H, W, ps, coff);
+    if (dtype == 0) warp_fused_kernel<float><<<grid, 256, 0, s>>>(frame2, flow, (float *)dst, B, C, H, W, ps, coff, (half_t *)dst16, ps16);
     else if (dtype == 2) warp_fused_kernel<half_t><<<grid, 256, 0, s>>>(frame2, flow, (half_t *)dst, B, C, H, W, ps, coff);
     else warp_fused_kernel<bf16_t><<<grid, 256, 0, s>>>(frame2, flow, (bf16_t *)dst, B, C, H, W, ps, coff);
     return (int)hipGetLastError();
