@@ -141,3 +141,45 @@ def test_config5_1080p_runs_deterministically():
         outs[mode] = a
     mse = (outs["fp32"].double() - outs["bf16"].double()).pow(2).mean().item()
     assert mse < 10 ** (-5.0)  # PSNR of bf16 against the exact-fp32 frame > 50 dB (measured ~59 dB)
+
+
+def test_amp16_launch_enumeration_has_no_rounding_passes():
+    """Round 5: in the autocast-policy mode the fp32 DCN's epilogue and the warp write the fp16 roundings themselves -
+    the per-block `fusion_round` passes and `fusion_round_warped` are gone at the reference width (the widening of `feat` stays)."""
+    names = [n for n, _, _ in lib.forward_launches(3, 64, 3, 2, 64, 96, "amp16")]
+    assert not any(n.startswith("fusion_round") for n in names), names
+    assert sum(n.startswith("fusion_widen_feat") for n in names) == 1
+    assert sum("writes fp32 + its fp16 rounding" in n for n in names) == 3
+    # a width the fp32 LDS-window kernel does not serve keeps the separate pass
+    small = [n for n, _, _ in lib.forward_launches(3, 8, 3, 2, 64, 96, "amp16")]
+    assert sum(n.startswith("fusion_round") for n in small) == 3
+
+
+def test_fixup_census_restates_the_pack_kernels_window_test():
+    """bench.py's also_pack_vs_offset_spread reports which deformable samples leave deform_pack3_kernel's staged window; its vectorised
+    census is checked here against a per-sample loop that follows csrc/deform_pack3.inl line by line (tile origin - 3, clamp to
+    [-2, size + 1], floor, corner row / column in [0, 21]; a wave = 4 rows x 16 columns of a 16 x 16 tile)."""
+    import math
+    import bench
+    g = torch.Generator().manual_seed(3)
+    H, W = 37, 50
+    raw = torch.randn(1, 27, H, W, generator=g) * 2.5
+    got = bench.fixup_census(raw, H, W)
+    off = torch.cat([raw[:, 0:9], raw[:, 18:27]], 1)[0]
+    out = 0
+    groups = set()
+    for y in range(H):
+        for x in range(W):
+            ty0, tx0 = y // 16 * 16 - 3, x // 16 * 16 - 3
+            for k in range(9):
+                i, j = divmod(k, 3)
+                py = min(max(float(y - 1 + i) + off[2 * k, y, x].item(), -2.0), H + 1.0)
+                px = min(max(float(x - 1 + j) + off[2 * k + 1, y, x].item(), -2.0), W + 1.0)
+                ly, lx = math.floor(py) - ty0, math.floor(px) - tx0
+                if not (0 <= ly <= 21 and 0 <= lx <= 21):
+                    out += 1
+                    groups.add((k, y // 4, x // 16))
+    Hp, Wp = (H + 15) // 16 * 16, (W + 15) // 16 * 16
+    assert abs(got["samples_outside_window"] - out / (9 * H * W)) < 1e-5
+    assert abs(got["wave_taps_in_fixup_loop"] - len(groups) / (9 * (Hp // 4) * (Wp // 16))) < 1e-5
+    assert out > 0 and len(groups) > 0

@@ -584,20 +584,21 @@ int attention_block(const Plan &P, int i, const void *packed, const void *x, voi
 // the fp16 rounding of yF - from the DCN's own epilogue where the fp32 LDS-window kernel serves the shape (round 5: was a conversion
 // pass per block), else from launch_convert_cl
 bool amp_dcn_writes_fp16(const Plan &P, int i) { return P.dcn32[i].pack3 == 3; }
-int attention_block_amp(const Plan &P, int i, const void *packed, const void *x16, const float *xF, float *yF, void *y16, float *om, int B, int H, int W,
-                        hipStream_t s, Recorder &rec)
+int attention_block_amp(const Plan &P, int i, const void *packed, const void *x16, const float *xF, float *yF, bool want16, void *y16, float *om, int B,
+                        int H, int W, hipStream_t s, Recorder &rec)
 {
     const double px = (double)B * H * W, cf = P.mid + 3;
     const size_t npx = (size_t)B * H * W;
     double fl, by;
     conv_work(P, P.off[i], B, H, W, 4.0, fl, by);
     EMAVFI_STEP(rec, conv_name(P, P.off[i]) + " offset_conv", fl, by, run_conv(P, P.off[i], packed, x16, P.fps, H, W, om, 32, 0, 32, EPI_OM, B, s));
-    const bool both = amp_dcn_writes_fp16(P, i) && y16 != nullptr;
+    // (want16, not the pointer, decides: the enumeration-only pass has no buffers and must list the launches the real pass runs)
+    const bool both = amp_dcn_writes_fp16(P, i) && want16;
     EMAVFI_STEP(rec, both ? "deform<f32,ck=80,nf=3> dcn_v2 (fp32 under autocast; writes fp32 + its fp16 rounding)" : "deform<f32,ck=80,nf=3> dcn_v2 (fp32 under autocast)",
                 2.0 * 9.0 * cf * cf * px, px * (2.0 * cf * 4.0 + 27.0 * 4.0 + (both ? cf * 2.0 : 0.0)) + 9.0 * cf * cf * 4.0,
                 run_deform(P, P.dcn32[i], packed, xF, P.fpad, om, yF, P.fpad, P.fpad, B, H, W, s, nullptr, nullptr, nullptr, 0, EMAVFI_F32, 0, 0,
                            both ? y16 : nullptr, P.fps));
-    if (!both && y16) EMAVFI_STEP(rec, "fusion_round", 0, px * cf * 6.0, launch_convert_cl(yF, y16, npx, P.fpad, P.fps, 0, P.fpad, 0, s));
+    if (!both && want16) EMAVFI_STEP(rec, "fusion_round", 0, px * cf * 6.0, launch_convert_cl(yF, y16, npx, P.fpad, P.fps, 0, P.fpad, 0, s));
     return EMAVFI_OK;
 }
 
@@ -830,7 +831,7 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
             EMAVFI_TRY(launch_cl_to_nchw(xF, taps[3], B, C, H, W, P.fpad, mid, EMAVFI_F32, s), "tap warped");
         EMAVFI_STAGE_EVENT(rec, 0);
         for (int i = 0; i < P.nb; ++i) {
-            if (const int rc = attention_block_amp(P, i, packed, x, xF, yF, y, f.om, B, H, W, s, rec); rc != EMAVFI_OK) return rc;
+            if (const int rc = attention_block_amp(P, i, packed, x, xF, yF, true, y, f.om, B, H, W, s, rec); rc != EMAVFI_OK) return rc;
             if (!rec.dry && taps && taps[5 + i])
                 EMAVFI_TRY(launch_cl_to_nchw(yF, taps[5 + i], B, mid + 3, H, W, P.fpad, 0, EMAVFI_F32, s), "tap fused");
             void *t = x; x = y; y = t;
@@ -1315,7 +1316,7 @@ static int mdcn_impl(const float *x, const float *offset_weight, const float *of
     if (P.amp) {
         EMAVFI_TRY(launch_nchw_to_cl(x, m.xF, B, C, H, W, P.fpad, EMAVFI_F32, s), "mdcn layout in (fp32)");
         EMAVFI_TRY(launch_nchw_to_cl(x, m.xcl, B, C, H, W, P.fps, EMAVFI_F16, s), "mdcn layout in (fp16 rounding)");
-        if (const int rc = attention_block_amp(P, 0, m.blob, m.xcl, m.xF, m.yF, nullptr, m.om, B, H, W, s, rec); rc != EMAVFI_OK) return rc;
+        if (const int rc = attention_block_amp(P, 0, m.blob, m.xcl, m.xF, m.yF, false, nullptr, m.om, B, H, W, s, rec); rc != EMAVFI_OK) return rc;
         EMAVFI_TRY(launch_cl_to_nchw(m.yF, y, B, C, H, W, P.fpad, 0, EMAVFI_F32, s), "mdcn layout out");
         return EMAVFI_OK;
     }
