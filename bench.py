@@ -326,9 +326,12 @@ def fixup_census(raw, H, W):
     pad = torch.zeros(n, 9, Hp, Wp, dtype=torch.bool, device=raw.device)
     pad[:, :, :H, :W] = out
     groups = pad.view(n, 9, Hp // 4, 4, Wp // 16, 16).any(dim=5).any(dim=3)   # (wave, tap): 4 rows x 16 columns
+    halves = pad.view(n, 9, Hp // 4, 2, 2, Wp // 16, 16).any(dim=6).any(dim=4)   # the wave's two fragment rows (2 image rows x 16 columns each)
+    one_row = (halves.sum(dim=3) == 1).float().sum().item() / max(1.0, groups.float().sum().item())
     a = off.abs().flatten()
     q = a[torch.randint(0, a.numel(), (1 << 20,), device=a.device, generator=torch.Generator(device=a.device).manual_seed(0))].float()
     return {"samples_outside_window": round(out.float().mean().item(), 5), "wave_taps_in_fixup_loop": round(groups.float().mean().item(), 5),
+            "fixup_wave_taps_with_one_fragment_row_parked": round(one_row, 4),
             "abs_offset_px_p50": round(q.quantile(0.5).item(), 3), "abs_offset_px_p99": round(q.quantile(0.99).item(), 3),
             "abs_offset_px_max": round(a.max().item(), 2)}
 
