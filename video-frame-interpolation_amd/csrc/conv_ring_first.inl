@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringfirst_kernel(const FirstPa
     // stage A's weights stay in LDS (five more reads per row; 20 registers for the second set of frame values in flight)
     for (int i = tid; i < 5 * 2 * 64; i += 256) reinterpret_cast<u4_t *>(smem + C::WA_OFF)[i] = reinterpret_cast<const u4_t *>(fp.w)[i];
     if (tid < 32) reinterpret_cast<f32x4 *>(smem + C::BIAS_OFF)[tid] = reinterpret_cast<const f32x4 *>(tid < 16 ? fp.bias : p.bias)[tid & 15];
+    for (int i = tid; i < C::NFR * C::FROW / 16; i += 256) reinterpret_cast<u4_t *>(smem + C::FR_OFF)[i] = u4_t{0u, 0u, 0u, 0u};   // the frame pixels' pad channels
     // stage A's five operand reads: tap slot 2 kg + h of this lane half (slot 9: zero weights, any finite data)
     int ady[5], adx[5];
 #pragma unroll
@@ -72,32 +73,38 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringfirst_kernel(const FirstPa
         const int a0 = ys - 1;                    // first stage-A row; its ring slot is 0
         const int ox0 = tx * C::TWO - 1;          // image column of stage A's column 0; frame-ring column 0 is ox0 - 1
         const float *g1 = fp.f1 + (size_t)b * 3 * plane, *g2 = fp.f2 + (size_t)b * 3 * plane;
-        // one frame row: every thread loads six values of pixel min(tid, 65) of the row - UNCONDITIONALLY, from coordinates clamped
-        // into the image (a branch around the loads makes hipcc's vmcnt bookkeeping pessimistic: it then waits for them at the next
-        // register reuse instead of at frame_put) ...
-        const int fgx = ox0 - 1 + min(tid, C::FW - 1);
+        // one frame row: thread t loads TWO values - channel pair (t % 3) of pixel min(t / 3, 65): (f1 c0, f1 c1) | (f1 c2, f2 c0) |
+        // (f2 c1, f2 c2) - UNCONDITIONALLY, from coordinates clamped into the image (a branch around the loads makes hipcc's vmcnt
+        // bookkeeping pessimistic: it then waits for them at the next register reuse instead of at frame_put) ...
+        // (round 5, tools/ring_stamps.py: every thread used to load all six values of pixel min(t, 65) and threads < 66 wrote whole
+        // pixels - waves 0 and 1 carried the conversion and the LDS writes, waves 2 and 3 loaded 6 values for nothing and then waited
+        // ~180 cycles per step at the barrier.  Same values, same conversion: still bit-identical to the two launches.)
+        const int fpix = min(tid / 3, C::FW - 1), fpart = tid - 3 * (tid / 3);
+        const int fgx = ox0 - 1 + fpix;
         const int fgxc = min(max(fgx, 0), W - 1);
-        auto frame_load = [&](int gy, float (&v)[6]) {
+        const float *fpa = (fpart == 0 ? g1 : fpart == 1 ? g1 + 2 * plane : g2 + plane) + fgxc;
+        const float *fpb = (fpart == 0 ? g1 + plane : fpart == 1 ? g2 : g2 + 2 * plane) + fgxc;
+        auto frame_load = [&](int gy, float (&v)[2]) {
 #if defined(EMAVFI_RF_ABL) && (EMAVFI_RF_ABL & 1)   // timing-only: no frame loads
-            for (int c = 0; c < 6; ++c) v[c] = (float)gy * 0.001f + c;
+            for (int c = 0; c < 2; ++c) v[c] = (float)gy * 0.001f + c;
             return;
 #endif
-            const size_t o = (size_t)min(max(gy, 0), H - 1) * W + fgxc;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { v[c] = g1[c * plane + o]; v[3 + c] = g2[c * plane + o]; }
+            const size_t o = (size_t)min(max(gy, 0), H - 1) * W;
+            v[0] = fpa[o]; v[1] = fpb[o];
         };
-        // ... and threads < 66 write it (zero outside the image) as one 16-byte pixel into ring slot (gy - a0 + 1) & 3
-        auto frame_put = [&](int gy, const float (&v)[6]) {
+        // ... and threads < 3 x 66 write their pair (zero outside the image) as 4 bytes of the 16-byte pixel in ring slot (gy - a0 + 1) & 3
+        // (the pixel's last 4 bytes - channels 6, 7 - are zeroed once per kernel, below)
+        auto frame_put = [&](int gy, const float (&v)[2]) {
             const bool in = (unsigned)gy < (unsigned)H && (unsigned)fgx < (unsigned)W;
-            if (tid < C::FW) {
-                const vec px = {(T)(in ? v[0] : 0.0f), (T)(in ? v[1] : 0.0f), (T)(in ? v[2] : 0.0f), (T)(in ? v[3] : 0.0f), (T)(in ? v[4] : 0.0f), (T)(in ? v[5] : 0.0f), (T)0.0f, (T)0.0f};
-                *reinterpret_cast<vec *>(smem + C::FR_OFF + ((gy - a0 + 1) & 3) * C::FROW + tid * 16) = px;
+            if (tid < 3 * C::FW) {
+                const pair_t px = {(T)(in ? v[0] : 0.0f), (T)(in ? v[1] : 0.0f)};
+                *reinterpret_cast<unsigned *>(smem + C::FR_OFF + ((gy - a0 + 1) & 3) * C::FROW + fpix * 16 + fpart * 4) = __builtin_bit_cast(unsigned, px);
             }
         };
         __syncthreads();   // the previous item's last reads of the rings (and the bias / stage-A weight tables' writes)
-        float fold[6];     // frame row t + 2, loaded during step t - 1, written at the end of step t: two steps for the round trip
+        float fold[2];     // frame row t + 2, loaded during step t - 1, written at the end of step t: two steps for the round trip
         {
-            float v[6];
+            float v[2];
 #pragma unroll 1
             for (int k = -1; k <= 1; ++k) { frame_load(a0 + k, v); frame_put(a0 + k, v); }
             frame_load(a0 + 2, fold);
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringfirst_kernel(const FirstPa
             RING_STAMP(ts0);
             __syncthreads();   // stage A's row t - 1, stage B's staged row t - 3 and frame row t + 1 are visible
             RING_STAMP(ts1);
-            float fnew[6];
+            float fnew[2];
             frame_load(t + 3, fnew);
             store_row(t - 3, t - 3 >= ys);
             RING_STAMP(ts2);
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringfirst_kernel(const FirstPa
             RING_STAMP(ts4);
             frame_put(t + 2, fold);
 #pragma unroll
-            for (int c = 0; c < 6; ++c) fold[c] = fnew[c];
+            for (int c = 0; c < 2; ++c) fold[c] = fnew[c];
             RING_STAMP(ts5);
             RING_STAMP_ADD(0, ts0, ts1); RING_STAMP_ADD(1, ts1, ts2); RING_STAMP_ADD(2, ts2, ts3); RING_STAMP_ADD(3, ts3, ts4); RING_STAMP_ADD(4, ts4, ts5);
             RING_STAMP_STEP();
