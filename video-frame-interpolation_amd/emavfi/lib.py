@@ -219,13 +219,18 @@ class _Hip:
         self._events = {}
 
     def event(self, key):
+        """One event per key, created on first use and kept for the life of the process (keys are (device, caller stream, purpose): a
+        handful per stream that ever ran a pipelined forward)."""
         e = self._events.get(key)
         if e is None:
-            h = c_void_p()
-            rc = self.rt.hipEventCreateWithFlags(ctypes.byref(h), 2)   # hipEventDisableTiming
-            if rc != 0:
-                raise RuntimeError(f"hipEventCreateWithFlags failed ({rc})")
-            e = self._events[key] = h
+            with _lock:
+                e = self._events.get(key)
+                if e is None:
+                    h = c_void_p()
+                    rc = self.rt.hipEventCreateWithFlags(ctypes.byref(h), 2)   # hipEventDisableTiming
+                    if rc != 0:
+                        raise RuntimeError(f"hipEventCreateWithFlags failed ({rc})")
+                    e = self._events[key] = h
         return e
 
     def record(self, event, stream):

@@ -23,6 +23,7 @@ import math
 import os
 import tempfile
 from collections import OrderedDict
+import ctypes
 from ctypes import POINTER, c_void_p, cast
 
 import torch
@@ -396,7 +397,6 @@ class EMA_VFI(nn.Module):
                     stage = (c_void_p * 3)(*[front if i == self.pipeline_stagger else None for i in range(3)])
                     evp = None
                     if _events is not None:
-                        import ctypes
                         evp = cast(c_void_p(_events[0].value + k * per * ctypes.sizeof(c_void_p)), POINTER(c_void_p))
                     _lib.check(L.emavfi_forward_staged(C, self.mid_channels, self.num_blocks, packed.data_ptr(), packed.numel(),
                                                        f1[b0:b1].data_ptr(), f2[b0:b1].data_ptr(), out[b0:b1].data_ptr(), ws.data_ptr(), ws.numel(),
