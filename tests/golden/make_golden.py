@@ -226,6 +226,34 @@ def large_odd():
     np.savez_compressed(os.path.join(OUT, "large_odd.npz"), **arrays)
 
 
+def large_offsets():
+    """mid_channels 64 with LARGE deformable offsets (round 5): synthetic_state_dict(offset_std = 3, offset_bias = 3) makes the three
+    packs' offsets span about +-8 px (the benchmark's recipe: +-2), so that most (wave, tap) groups of the HIP pack kernels leave their
+    staged window (R = 2) and take the fix-up loop - which round 5 rewrote.  B = 1, 120 x 200 (7.5 x 12.5 tiles of 16 x 16), natural
+    input; samples of every stage of the reference's forward, and the offsets' quantiles for the record."""
+    arrays = {}
+    recipe = (3.0, 3.0)
+    sd = synth.synthetic_state_dict(seed=0, offset_std=recipe[0], offset_bias=recipe[1])
+    tag, B, H, W, kind, seed = "off", 1, 120, 200, "natural", 6
+    f1, f2 = synth.synthetic_frames(seed, B, H, W, kind)
+    t0 = time.time()
+    taps = run_reference(sd, f1, f2, 64)
+    raw = torch.cat([taps[f"raw_{i}"] for i in range(3)], 0)
+    off = torch.cat([raw[:, 0:9], raw[:, 18:27]], 1).abs().flatten()
+    print(f"  large {tag}: reference forward {time.time() - t0:.1f}s, |offset| p50 {off.quantile(0.5):.2f} p99 {off.quantile(0.99):.2f} max {off.max():.2f}, "
+          f"out [{taps['out'].min():.3f},{taps['out'].max():.3f}]")
+    arrays[f"{tag}.meta"] = np.array([B, H, W, seed, 0], dtype=np.int64)
+    arrays[f"{tag}.recipe"] = np.array(recipe, dtype=np.float64)
+    arrays[f"{tag}.abs_offset_quantiles"] = np.array([off.quantile(0.5).item(), off.quantile(0.99).item(), off.max().item()], dtype=np.float64)
+    for k in ("feat", "ctx", "flow", "warped", "fused_0", "fused_1", "fused_2", "out"):
+        v = taps[k].contiguous().view(-1)
+        pos = sample_positions(seed, f"sample.{tag}.{k}", v.numel(), min(4096, v.numel()))
+        arrays[f"{tag}.pos.{k}"] = pos
+        arrays[f"{tag}.val.{k}"] = v[torch.from_numpy(pos)].numpy()
+        arrays[f"{tag}.stats.{k}"] = stage_stats(taps[k])
+    np.savez_compressed(os.path.join(OUT, "large_offsets.npz"), **arrays)
+
+
 class DeformConv2dAutocastStandIn(DeformConv2dStandIn):
     """torchvision registers an Autocast kernel for deform_conv2d (torchvision/csrc/ops/autocast/deform_conv2d_kernel.cpp, restated):
     autocast is switched off inside, input / weight / offset / mask / bias are cast to float, the op runs in fp32 and the result is
@@ -316,6 +344,8 @@ if __name__ == "__main__":
         large1080()
     if "odd" in which:
         large_odd()
+    if "offsets" in which:
+        large_offsets()
     if "amp" in which:
         amp("amp_mid8_23x37", 8, 2, 23, 37, "stress", 12)
         amp("amp_mid64_40x56", 64, 1, 40, 56, "natural", 13)
