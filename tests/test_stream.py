@@ -192,6 +192,16 @@ def test_stream_matches_reference_loop(factor, interval, batch):
     model = EMA_VFI(mid_channels=8, compute_dtype="fp32").cuda().eval()
     model.load_state_dict(sd)
     got = list(FrameInterpolator(model, factor, interval, batch_pairs=batch).run(frames))
+    # the two transports of the harness - SDMA copies + device kernels (default, round 5) and kernels that read / write the pinned
+    # buffers themselves (zero_copy=True, rounds 1-4) - emit the same bytes; so does a longer stream, whose first batch is half-size
+    # (ramp-up) and whose source-frame round trips leave from the pre lane
+    zc = list(FrameInterpolator(model, factor, interval, batch_pairs=batch, zero_copy=True).run(frames))
+    assert len(zc) == len(got) and all(np.array_equal(a, b) for a, b in zip(zc, got))
+    if interval == 1:
+        long_frames = frames * 3
+        a = list(FrameInterpolator(model, factor, interval, batch_pairs=2).run(long_frames))
+        b = list(FrameInterpolator(model, factor, interval, batch_pairs=len(long_frames), zero_copy=True).run(long_frames))
+        assert len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))
     ref = ref_loop(frames, lambda a, b: oracle.forward(sd, a, b), factor, interval)
     assert len(got) == len(ref)
     assert len(got) == FrameInterpolator(model, factor, interval).count_outputs(len(frames))
