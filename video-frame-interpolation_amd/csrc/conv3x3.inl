@@ -739,7 +739,6 @@ template <typename T, int CK, int NF, int NB> static int launch_conv_persist16(c
 #include "conv_ring.inl"
 #include "conv_ring2.inl"
 #include "conv_ring_tail.inl"
-#include "conv_ring16.inl"
 
 // weights packed for the 16x16x32 shape (ConvParams::mfma16): 64 -> 64 (four blocks), 64 -> 32 (two), 64 / 32 -> planes (one)
 template <typename T> static int launch_conv_mfma16(const ConvParams &p, hipStream_t s)
@@ -984,7 +983,6 @@ template <typename T> static int launch_conv16(const ConvParams &p, hipStream_t 
     if (p.mfma16) return launch_conv_mfma16<T>(p, s);
     if (p.ring == 1) return launch_conv_s2ring<T>(p, s);
     if (p.ring == 4) return launch_conv_wreg<T>(p, s);
-    if (p.ring == 5) return launch_conv_ring16<T>(p, s);   // experiment: the 64 -> 64 ring kernel on v_mfma_f32_16x16x32 (stage entry only)
     if (p.ring >= 2) return p.w2 ? launch_conv_ring2<T>(p, s) : launch_conv_ring<T>(p, s);
     if (!no_persistent && p.stride == 1 && p.nchunk == 1 && p.npass == 1) {
         // measured at B=8 x 720p in bf16 (us per launch, tile-per-workgroup -> persistent): 64->64 670 -> 644,

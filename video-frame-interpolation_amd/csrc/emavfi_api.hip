@@ -1116,14 +1116,7 @@ int emavfi_postprocess_u8(const float *frames_nchw, unsigned char *out_hwc, int 
 static bool single_conv_layer(Layer &L, int Cin, int Cout, int stride, int esize)
 {
     L = mk(0, Cout, Cin, stride);
-    if (!conv_geometry(L, esize, read_layout_env())) return false;   // stage-level entry: packs and runs inside one call
-    // EXPERIMENT (round 5, conv_ring16.inl): EMAVFI_CONV_RING16=1 runs the plain 64 -> 64 ring layer of THIS entry on v_mfma_f32_16x16x32
-    // (ring = 5: the 16x16x32 weight packing, its own kernel).  The forward's plan never sets it.
-    if (L.ring == 2) {
-        const char *e = getenv("EMAVFI_CONV_RING16");
-        if (e && e[0] == '1') L.ring = 5;
-    }
-    return true;
+    return conv_geometry(L, esize, read_layout_env());   // stage-level entry: packs and runs inside one call
 }
 
 size_t emavfi_conv3x3_workspace_bytes(int B, int Cin, int Cout, int H, int W, int stride, int dtype)
@@ -1171,8 +1164,8 @@ int emavfi_conv3x3(const float *x, const float *weight, const float *bias, float
     L.w_off = (char *)wp - (char *)workspace;
     L.b_off = (char *)bp - (char *)workspace;
     PackDesc d{L.cout, L.cin_raw, 0, L.cin_take, L.ck, L.nchunk, L.nf, L.npass, 0, 0};
-    d.mfma16 = (L.mfma16 || L.ring == 5) ? 1 : 0;
-    d.ring = L.ring == 5 ? 0 : L.ring;
+    d.mfma16 = L.mfma16 ? 1 : 0;
+    d.ring = L.ring;
     if (hipMemsetAsync(zpage, 0, 256, s) != hipSuccess) return fail(EMAVFI_E_LAUNCH, "conv3x3: zero page memset failed");
     EMAVFI_TRY(launch_pack_conv(weight, bias, wp, bp, d, dtype, s), "conv3x3 pack");
     EMAVFI_TRY(launch_nchw_to_cl(x, xcl, B, Cin, H, W, L.cin_pad, dtype, s), "conv3x3 layout in");
