@@ -9,7 +9,7 @@ dev = "cuda:0"
 sd = synth.synthetic_state_dict(seed=0)
 for dt in ("bf16", "fp32"):
     m = EMA_VFI(compute_dtype=dt).to(dev).eval(); m.load_state_dict(sd)
-    for B, H, W in ((1, 256, 256), (1, 720, 1280), (16, 256, 256)):
+    for B, H, W in ((1, 256, 256), (1, 720, 1280), (16, 256, 256), (8, 720, 1280)):
         f1, f2 = synth.fast_frames(5, B, H, W, device=dev)
         with torch.no_grad():
             side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
