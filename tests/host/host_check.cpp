@@ -102,6 +102,10 @@ int main()
     void *evs[2] = {nullptr, nullptr};
     CHECK(emavfi_forward_profiled(3, 64, 3, fake, 0, ff, ff, fo, fake, 0, 1, 8, 8, EMAVFI_F32, nullptr, 0, nullptr) == EMAVFI_E_ARG);
     CHECK(emavfi_forward_profiled(3, 64, 3, nullptr, 0, ff, ff, fo, fake, 0, 1, 8, 8, EMAVFI_F32, evs, 2, nullptr) == EMAVFI_E_ARG);
+    // the staged form (round 5): the same guards with stage / launch events present or absent
+    CHECK(emavfi_forward_staged(3, 64, 3, nullptr, 0, ff, ff, fo, fake, 0, 1, 8, 8, EMAVFI_F32, nullptr, nullptr, 0, nullptr) == EMAVFI_E_ARG);
+    CHECK(emavfi_forward_staged(3, 64, 3, fake, 1000, ff, ff, fo, fake, (size_t)1 << 40, 1, 64, 64, EMAVFI_BF16, evs, evs, 2, nullptr) == EMAVFI_E_ARG);
+    CHECK(strstr(emavfi_last_error(), "packed blob has 1000 bytes") != nullptr);
     CHECK(emavfi_warp(nullptr, nullptr, nullptr, 1, 3, 8, 8, nullptr) == EMAVFI_E_ARG);
     CHECK(emavfi_warp(ff, ff, fo, 0, 3, 8, 8, nullptr) == EMAVFI_E_ARG);
     CHECK(emavfi_warp((const float *)(uintptr_t)260, ff, fo, 1, 3, 8, 8, nullptr) == EMAVFI_E_ARG);
@@ -126,6 +130,8 @@ int main()
     CHECK(emavfi_mdcn_workspace_bytes(1, 67, 32, 32, EMAVFI_F32, EMAVFI_MDCN_IN_F16) == 0 && emavfi_mdcn_workspace_bytes(1, 67, 32, 32, EMAVFI_BF16, 8) == 0);
     CHECK(emavfi_mdcn(nullptr, ff, ff, ff, ff, fo, 1, 67, 8, 8, EMAVFI_BF16, 0, fake, 0, nullptr) == EMAVFI_E_ARG);
     CHECK(emavfi_mdcn(ff, ff, ff, ff, nullptr, fo, 1, 67, 8, 8, EMAVFI_BF16, 0, fake, 16, nullptr) == EMAVFI_E_WORKSPACE);
+    CHECK(emavfi_mdcn_profiled(ff, ff, ff, ff, ff, fo, 1, 67, 8, 8, EMAVFI_BF16, 0, fake, 16, nullptr, 0, nullptr) == EMAVFI_E_ARG);
+    CHECK(emavfi_mdcn_profiled(ff, ff, ff, ff, nullptr, fo, 1, 67, 8, 8, EMAVFI_BF16, 0, fake, 16, evs, 2, nullptr) == EMAVFI_E_WORKSPACE);
     for (int dt : dtypes) CHECK(emavfi_context_workspace_bytes(2, 64, 75, 131, dt) > 0 && emavfi_reconstruct_workspace_bytes(2, 8, 23, 37, dt) > 0);
     CHECK(emavfi_context_workspace_bytes(1, 7, 32, 32, EMAVFI_BF16) == 0 && emavfi_reconstruct_workspace_bytes(0, 64, 32, 32, EMAVFI_BF16) == 0);
     {
