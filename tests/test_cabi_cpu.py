@@ -213,8 +213,9 @@ def test_ring_kernels_issue_a_fixed_number_of_vmem_instructions_per_step(tmp_pat
             assert (dma, stores, other) == (3, 2 if head else 3, 0), (name, dma, stores, other)
             assert n == (2 if head else 9), (name, n)
             seen[name] = n
-    # bf16 and f16 instances of: 64 -> 64, the same storing the other 16-bit type (ALT), TAIL (67 -> 64), HEAD (+ flow head), reconstruction.1 + .2
-    assert len(seen) == 10, sorted(seen)
+    # bf16 and f16 instances of: 64 -> 64, the same storing the other 16-bit type (ALT), TAIL (67 -> 64), HEAD (+ flow head): 8;
+    # reconstruction.1 + .2: bf16 and f16 x (round16, tanh head) = 8 (round 5: both became template arguments)
+    assert len(seen) == 16, sorted(seen)
 
 
 def _loops_of(body):
@@ -276,8 +277,8 @@ def test_ring_kernels_prime_their_rings_with_the_steady_state_pattern(tmp_path):
             assert count(prime) == want_prime, (name, "priming loop", count(prime))
             assert n == (3 if ring2 else 2 if head else 9), (name, n)
             seen[name] = n
-    # ring: 8 instances (bf16 / f16 x {64 -> 64, ALT, TAIL, HEAD}); ringtail: 2; ring2: 4 (bf16 / f16 x ALT)
-    assert len(seen) == 14, sorted(seen)
+    # ring: 8 instances (bf16 / f16 x {64 -> 64, ALT, TAIL, HEAD}); ringtail: 8 (bf16 / f16 x round16 x tanh head); ring2: 4 (bf16 / f16 x ALT)
+    assert len(seen) == 20, sorted(seen)
 
 
 def _vregs(text):

@@ -4,13 +4,15 @@
 //
 // The two layers ran as conv3x3_persist16_kernel (373 us) + conv_light_kernel (179 us) and moved 2.1 GB for 1.0 GB of input and
 // output: the 32-channel tensor between them was written and read back.  Here it exists only as an LDS ring of four rows:
-//   * stage A (64 -> 32) on v_mfma_f32_16x16x32 with the 18 (tap, k32) steps SPLIT between the two waves of a column block: wave
-//     (cb, kh) computes steps 9 kh .. 9 kh + 8 for both 16-channel output blocks and both 16-pixel halves of its 32 pixels -
-//     72 weight registers, 18 operand reads and 36 MFMAs per row; a step's operand read feeds four MFMAs (the 64 -> 64 ring kernel:
-//     one), which is what keeps this kernel off the LDS floor the fused flow head sits on.  The wave keeps the partial sums of
-//     "its" output block (kh) and hands the other block's to its partner through LDS; one step later each wave adds what it
-//     received, bias, ReLU, rounds to T and writes 16 channels of its 32 pixels into the row ring (zero outside the image);
-//   * stage B (32 -> 3, three steps behind): wave w computes the 16 columns [16 w, 16 w + 16) of the strip's 62, nine MFMAs with the
+//   * stage A (64 -> 32) on v_mfma_f32_16x16x32: wave w computes ALL 32 output channels (two 16-channel blocks) of the strip's columns
+//     [16 w, 16 w + 16) - 18 (tap, k32) steps, 144 weight registers, 18 operand reads and 36 MFMAs per row, an operand read feeding
+//     two MFMAs - adds the bias, applies the ReLU, rounds to T and writes its 16 pixels x 32 channels into the row ring (zero outside
+//     the image) in the SAME step.  (Rounds 3-4 split the 18 steps between the two waves of a 32-column block - 72 weight registers
+//     per wave - and handed the partner's half of the sums over through LDS, finished one step later: 16 KiB of LDS, two more LDS
+//     round trips per step and one more step of lag in a kernel whose step is a chain of LDS round trips.  Round 5, after the stamps
+//     of profiles/r05_ring_stamps.txt - 40 % matrix-pipe occupancy at 1.98 GHz, i.e. NOT clock-bound like the rest of the family -
+//     removed the hand-off: the registers were there.)
+//   * stage B (32 -> 3, two steps behind): wave w computes the 16 columns [16 w, 16 w + 16) of the strip's 62, nine MFMAs with the
 //     weights in 36 registers; tanh, (t + 1) / 2, three planar fp32 stores;
 //   * both LDS images are UNPADDED and XOR-swizzled for the 16x16x32 operand pattern: the input ring (128-byte pixels, unit u of
 //     pixel c at u ^ swz16(c) - the DMA's lanes fetch the permuted piece) and the row ring (64-byte pixels, unit u at
@@ -21,13 +23,15 @@
 #endif
 template <typename T> struct RingTailCfg {
     static constexpr int TW = 64, TWO = TW - 2, IW = TW + 2, IN_PX = 128, ROWSLOT = IW * 8, ROWINST = (ROWSLOT + 63) / 64, ROWB = ROWINST * 1024;
-    static constexpr int D = 3, RING = D + 2, MID_PX = 64, MID = TW * MID_PX, NMID = 4, PART = 4 * 2048;
-    static constexpr int MID_OFF = RING * ROWB, PART_OFF = MID_OFF + NMID * MID, SCRATCH_OFF = PART_OFF + 2 * PART, LDS_BYTES = SCRATCH_OFF + 1024;
+    static constexpr int D = 3, RING = D + 2, MID_PX = 64, MID = TW * MID_PX, NMID = 4;
+    static constexpr int MID_OFF = RING * ROWB, SCRATCH_OFF = MID_OFF + NMID * MID, LDS_BYTES = SCRATCH_OFF + 1024;
     static constexpr int NDMA = (ROWINST + 3) / 4, NSTORE = 3, VMWAIT = NSTORE + (NDMA + NSTORE) * (D - 2);
     static_assert(sizeof(T) == 2 && 2 * LDS_BYTES <= 160 * 1024 && NDMA == 3, "16-bit types; two workgroups per CU");
 };
 
-template <typename T>
+template <typename T, bool R16, bool TANH>   // ConvParams::round16 (EMAVFI_AMP16) and epi2 == EPI_PLANAR_TANH01 as template arguments: the run-time
+                                             // tests put ocml's branchy tanhf into every instance's row loop and made hipcc duplicate a store
+                                             // into both arms of a branch - the code-object tests count the loop's VMEM instructions
 __global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvParams p, const int nseg, const int seg_rows)
 {
     using C = RingTailCfg<T>;
@@ -40,30 +44,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvPara
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const unsigned lds0 = (unsigned)(size_t)(lchar_t *)smem;
     const int j = lane & 15, kb = lane >> 4;
-    const int cb = wave_u >> 1, kh = wave_u & 1;
     const int ntx = (p.Wout + C::TWO - 1) / C::TWO, nstrip = ntx * p.B, nitems = nstrip * nseg;
     const char *zeros = (const char *)p.zeros;
     const unsigned pixbytes = (unsigned)p.in_ps * (unsigned)sizeof(T);
     const unsigned rowbytes = (unsigned)p.Win * pixbytes;
     const auto s4 = [](int c) { return ((c >> 2) & 1) << 1; };   // the row ring's unit permutation
 
-    // ---- stage A: this wave's nine (tap, k32) steps; [0] = the output block it finalizes (kh), [1] = its partner's
+    // ---- stage A: this wave's 18 (tap, k32) steps for both 16-channel output blocks
     // (weights: the 16x16x32 packing [tap][k32][cout16 block 0..1][lane (i, kb)][8])
-    vec wr[9][2];
-    int xoA[9], dyA[9];
+    vec wr[18][2];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        const int s = kh * 9 + i, tap = s >> 1, k32 = s & 1, dy = tap / 3, dx = tap - 3 * dy;
-        const char *wb = (const char *)p.w + ((tap * 2 + k32) * 2) * 1024 + lane * 16;
-        wr[i][0] = *reinterpret_cast<const vec *>(wb + kh * 1024);
-        wr[i][1] = *reinterpret_cast<const vec *>(wb + (1 - kh) * 1024);
-        dyA[i] = dy;
-        // operand of pixel half 0: pixel c = 32 cb + j + dx, unit (4 k32 + kb) ^ swz16(c) (half 1: + 16 pixels = 2048 bytes, same permutation)
-        xoA[i] = (cb * 32 + j + dx) * C::IN_PX + (((k32 * 4 + kb) ^ swz16(j + dx)) << 4);
+    for (int s = 0; s < 18; ++s) {
+        const char *wb = (const char *)p.w + (s * 2) * 1024 + lane * 16;
+        wr[s][0] = *reinterpret_cast<const vec *>(wb);
+        wr[s][1] = *reinterpret_cast<const vec *>(wb + 1024);
     }
-    float ba[4];   // bias of output channels 16 kh + 4 kb .. + 3 (the accumulator rows of this lane)
+    // operand of step (tap, k32): pixel c = 16 w + j + dx, unit (4 k32 + kb) ^ swz16(c); six distinct lane offsets (dx, k32)
+    int xoA[6];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) ba[e] = p.bias[kh * 16 + kb * 4 + e];
+    for (int i = 0; i < 6; ++i) {
+        const int dx = i >> 1, k32 = i & 1;
+        xoA[i] = (wave * 16 + j + dx) * C::IN_PX + (((k32 * 4 + kb) ^ swz16(j + dx)) << 4);
+    }
+    float ba[2][4];   // bias of output channels 16 blk + 4 kb .. + 3 (the accumulator rows of this lane)
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ba[blk][e] = p.bias[blk * 16 + kb * 4 + e];
     // ---- stage B: the head's nine taps (K = 32 each), block 0 of its packing; bias of rows 0..2 (lanes kb == 0)
     vec hw[9];
 #pragma unroll
@@ -110,15 +117,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvPara
         const int hc = wave * 16 + j, hx = tx * C::TWO + hc;
         const unsigned soff = (hc < C::TWO && hx < p.Wout && kb == 0) ? (unsigned)hx * 4u : 0x80000000u;
         const size_t plane = (size_t)p.Hout * p.Wout;
-        f32x4 keep[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};   // this wave's own-block partial sums of the previous stage-A row
-
-        // stage A, first half: row y's partial sums over this wave's nine steps; the partner's block goes to LDS
-        auto partial_a = [&](int y, int s0) {
-            f32x4 acc[2][2];
+        // stage A: row y of the 64 -> 32 layer for this wave's 16 columns, all 32 channels: 18 operand reads, 36 MFMAs, then bias, ReLU,
+        // rounding and the row-ring write (zero outside the image: the rows are the head convolution's padding)
+        auto stage_a = [&](int y, int s0) {
+            f32x4 acc[2];
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int pb = 0; pb < 2; ++pb) acc[n][pb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            for (int blk = 0; blk < 2; ++blk) acc[blk] = f32x4{ba[blk][0], ba[blk][1], ba[blk][2], ba[blk][3]};
             // LDS byte offsets, not pointers: a row-base array indexed by a run-time dy loses its address space and the reads become
             // flat_load (vmcnt AND lgkmcnt: the counted wait would be wrong - tests/test_cabi_cpu.py checks the code object)
             int xs[3];
@@ -127,12 +131,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvPara
                 int sl = s0 + dy; sl = sl >= C::RING ? sl - C::RING : sl;
                 xs[dy] = sl * C::ROWB;
             }
-            int xrow[9];
-#pragma unroll
-            for (int i = 0; i < 9; ++i) xrow[i] = (dyA[i] == 0 ? xs[0] : dyA[i] == 1 ? xs[1] : xs[2]) + xoA[i];
             constexpr int AH = 4;
             vec xq[AH + 1];
-            auto xread = [&](int q) { return *reinterpret_cast<const __attribute__((address_space(3))) vec *>((lchar_t *)smem + xrow[q >> 1] + (q & 1) * 2048); };
+            auto xread = [&](int q) {   // step q: tap q >> 1 (dy = tap / 3, dx = tap % 3), k32 = q & 1
+                const int tap = q >> 1, dy = tap / 3, dx = tap - 3 * dy;
+                return *reinterpret_cast<const __attribute__((address_space(3))) vec *>((lchar_t *)smem + xs[dy] + xoA[dx * 2 + (q & 1)]);
+            };
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < AH; ++q) xq[q] = xread(q);
@@ -140,36 +144,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvPara
             for (int q = 0; q < 18; ++q) {
                 if (q + AH < 18) xq[(q + AH) % (AH + 1)] = xread(q + AH);
                 if (!(EMAVFI_RT_ABL & 4) || q == 0) {
-                    mma_k32(acc[0][q & 1], wr[q >> 1][0], xq[q % (AH + 1)]);
-                    mma_k32(acc[1][q & 1], wr[q >> 1][1], xq[q % (AH + 1)]);
+                    mma_k32(acc[0], wr[q][0], xq[q % (AH + 1)]);
+                    mma_k32(acc[1], wr[q][1], xq[q % (AH + 1)]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            lchar_t *pp = (lchar_t *)smem + C::PART_OFF + (y & 1) * C::PART + wave * 2048 + lane * 16;
-            *reinterpret_cast<__attribute__((address_space(3))) f32x4 *>(pp) = acc[1][0];
-            *reinterpret_cast<__attribute__((address_space(3))) f32x4 *>(pp + 1024) = acc[1][1];
-            keep[0] = acc[0][0]; keep[1] = acc[0][1];
-        };
-        // stage A, second half (one step later): own sums + the partner's + bias, ReLU, T; 16 channels of 32 pixels into the row ring
-        auto finish_a = [&](int y) {
-            const lchar_t *pp = (lchar_t *)smem + C::PART_OFF + (y & 1) * C::PART + (wave ^ 1) * 2048 + lane * 16;
-            const bool rowin = (unsigned)y < (unsigned)p.Hout;
+            const int c = wave * 16 + j;
+            const bool inside = (unsigned)y < (unsigned)p.Hout && (unsigned)(ox0 + c) < (unsigned)p.Wout;
+            const unsigned keepm = inside ? ~0u : 0u;
 #pragma unroll
-            for (int pb = 0; pb < 2; ++pb) {
-                const f32x4 r = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>(pp + pb * 1024);
+            for (int blk = 0; blk < 2; ++blk) {
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = (keep[pb][e] + r[e]) + ba[e];
-                    if (p.epi == EPI_RELU) v[e] = fmaxf(v[e], 0.0f);
-                }
+                for (int e = 0; e < 4; ++e) v[e] = p.epi == EPI_RELU ? fmaxf(acc[blk][e], 0.0f) : acc[blk][e];
                 typedef __attribute__((ext_vector_type(2))) T pair_t;
                 const pair_t lo = {(T)v[0], (T)v[1]}, hi = {(T)v[2], (T)v[3]};
-                const int c = cb * 32 + pb * 16 + j;
-                const bool inside = rowin && (unsigned)(ox0 + c) < (unsigned)p.Wout;
-                const unsigned keepm = inside ? ~0u : 0u;
-                // channels 16 kh + 4 kb .. + 3 = bytes 32 kh + 8 kb of the 64-byte pixel: unit 2 kh + (kb >> 1), half kb & 1
-                lchar_t *mp = (lchar_t *)smem + C::MID_OFF + ((y - a0) & 3) * C::MID + c * C::MID_PX + (((2 * kh + (kb >> 1)) ^ s4(c)) << 4) + (kb & 1) * 8;
+                // channels 16 blk + 4 kb .. + 3 = bytes 32 blk + 8 kb of the 64-byte pixel: unit 2 blk + (kb >> 1), half kb & 1
+                lchar_t *mp = (lchar_t *)smem + C::MID_OFF + ((y - a0) & 3) * C::MID + c * C::MID_PX + (((2 * blk + (kb >> 1)) ^ s4(c)) << 4) + (kb & 1) * 8;
                 *reinterpret_cast<__attribute__((address_space(3))) u2_t *>(mp) = u2_t{__builtin_bit_cast(unsigned, lo) & keepm, __builtin_bit_cast(unsigned, hi) & keepm};
             }
         };
@@ -189,12 +180,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvPara
 #pragma unroll
             for (int i = 0; i < C::NSTORE; ++i) {
                 float o = v[i];
-                if (p.epi2 == EPI_PLANAR_TANH01) {   // ema_vfi.py:106,146 (round16: every op rounds as an fp16 tensor op does under autocast)
-                    if (p.round16) { o = (float)(half_t)o; o = (float)(half_t)((float)(half_t)tanhf(o) + 1.0f) / 2.0f; }
+                if constexpr (TANH) {   // ema_vfi.py:106,146 (round16: every op rounds as an fp16 tensor op does under autocast)
+                    if constexpr (R16) {
+                        // tanh in fp32, then the fp16 roundings of the tensor ops (what a CUDA fp16 tanh does): 1 - 2 / (1 + exp(2x)) on v_exp_f32 +
+                        // v_rcp_f32 (a few fp32 ulp: invisible behind the rounding to fp16 except on exact ties; the cancellation near 0
+                        // disappears in the `+ 1`), branch-free - ocml's tanhf brought branches into the row loop that scattered its blocks
+                        o = (float)(half_t)o;
+                        const float th = 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * o));
+                        o = (float)(half_t)((float)(half_t)th + 1.0f) / 2.0f;
+                    }
                     // (tanh(x) + 1) / 2 = 1 / (1 + exp(-2x)): v_exp_f32 + v_rcp_f32 (2 ulp) instead of ocml's branchy tanhf, which cost this
                     // kernel as much as its MFMAs (three calls per pixel on all 64 lanes of the wave)
                     else o = __frcp_rn(1.0f + __expf(-2.0f * o));
-                } else if (p.round16) o = (float)(half_t)o;
+                } else if constexpr (R16) o = (float)(half_t)o;
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(orow + (i < p.nplanes ? i : 0) * plane, 0, (real && i < p.nplanes) ? 0x7ffffff0 : 0, 0x00020000);
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rs, soff, 0, 0);
             }
@@ -218,13 +216,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvPara
                 dma_row(y + C::D, sl, y + C::D <= a1 + 1);
             }
             RING_STAMP(ts2);
-            // one basic block: the head's and finish_a's LDS round trips overlap (finish_a(a0 - 1) at the first step turns garbage into
-            // row-ring slot 3, which finish_a(a0 + 3) rewrites before any head row reads it)
-            head_row(y - 3, y - 3 >= ys);
+            // the head row two steps behind (its three row-ring rows y - 3 .. y - 1 were written before this step's barrier), then row y
+            head_row(y - 2, y - 2 >= ys);
             RING_STAMP(ts3);
-            finish_a(y - 1);
             RING_STAMP(ts4);
-            partial_a(y, s0);
+            stage_a(y, s0);
             s0 = s0 + 1 >= C::RING ? 0 : s0 + 1;
             RING_STAMP(ts5);
             RING_STAMP_ADD(0, ts0, ts1); RING_STAMP_ADD(1, ts1, ts2); RING_STAMP_ADD(2, ts2, ts3); RING_STAMP_ADD(3, ts3, ts4); RING_STAMP_ADD(4, ts4, ts5);
@@ -232,29 +228,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvPara
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        finish_a(a1);
-        head_row(a1 - 2, a1 - 2 >= ys);
-        __syncthreads();
-        head_row(a1 - 1, true);
-        __syncthreads();   // the next item's first rows overwrite the rings and the partial sums
+        head_row(a1 - 1, true);   // (a1 = ye: the segment's last head row, from the rows ye - 2 .. ye)
+        __syncthreads();          // the next item's first rows overwrite the rings
     }
     RING_STAMP_WRITE(p, 14, 4);
 }
 
-template <typename T> static int launch_conv_ringtail(const ConvParams &p, hipStream_t s)
+template <typename T, bool R16, bool TANH> static int launch_conv_ringtail_t(const ConvParams &p, hipStream_t s)
 {
     using C = RingTailCfg<T>;
-    if (!p.mfma16 || p.ck != 64 || p.nf != 1 || p.stride != 1 || p.bias_mode != 0 || (p.epi != EPI_NONE && p.epi != EPI_RELU) || !p.head_w || !p.head_bias ||
-        !p.out_planar || p.nplanes < 1 || p.nplanes > 3)
-        return -2;
     static PerDeviceOnce once;   // (the library is re-entrant and serves several devices per process)
-    if (const hipError_t e_ = set_lds_limit(once, reinterpret_cast<const void *>(&conv3x3_ringtail_kernel<T>), C::LDS_BYTES); e_ != hipSuccess) return (int)e_;
+    if (const hipError_t e_ = set_lds_limit(once, reinterpret_cast<const void *>(&conv3x3_ringtail_kernel<T, R16, TANH>), C::LDS_BYTES); e_ != hipSuccess) return (int)e_;
     const int ncu = device_cu_count();
     if (ncu <= 0) return (int)hipErrorInvalidDevice;
     const int nstrip = ((p.Wout + C::TWO - 1) / C::TWO) * p.B, grid = ((emavfi_switches() & SW_RING_ONE_WG) ? 1 : 2) * ncu;   // (SW_RING_ONE_WG: measurement switch, common.h)
     int nseg, seg_rows;
     conv_ring_segments(nstrip, p.Hout, grid, &nseg, &seg_rows);
     const int nitems = nstrip * nseg;
-    conv3x3_ringtail_kernel<T><<<nitems < grid ? nitems : grid, 256, C::LDS_BYTES, s>>>(p, nseg, seg_rows);
+    conv3x3_ringtail_kernel<T, R16, TANH><<<nitems < grid ? nitems : grid, 256, C::LDS_BYTES, s>>>(p, nseg, seg_rows);
     return (int)hipGetLastError();
+}
+
+template <typename T> static int launch_conv_ringtail(const ConvParams &p, hipStream_t s)
+{
+    if (!p.mfma16 || p.ck != 64 || p.nf != 1 || p.stride != 1 || p.bias_mode != 0 || (p.epi != EPI_NONE && p.epi != EPI_RELU) || !p.head_w || !p.head_bias ||
+        !p.out_planar || p.nplanes < 1 || p.nplanes > 3)
+        return -2;
+    if (p.epi2 != EPI_PLANAR && p.epi2 != EPI_PLANAR_TANH01) return -2;
+    const bool tanh01 = p.epi2 == EPI_PLANAR_TANH01;
+    if (p.round16) return tanh01 ? launch_conv_ringtail_t<T, true, true>(p, s) : launch_conv_ringtail_t<T, true, false>(p, s);
+    return tanh01 ? launch_conv_ringtail_t<T, false, true>(p, s) : launch_conv_ringtail_t<T, false, false>(p, s);
 }
