@@ -15,7 +15,7 @@ SEGS = {
     "ring": ["W  counted wait + barrier", "I  DMA issue + stores of row y-1", "M  bias + 36 MFMAs (operands 4 ahead)", "E  epilogue (ReLU, round, staging writes)", "-"],
     "tail": ["W  counted wait + barrier", "I  DMA issue + stores of row y-1", "M  bias + 3 tail + 36 MFMAs", "E  epilogue", "-"],
     "head": ["W  counted wait + barrier", "I+H  DMA issue + head_finish + head_partial", "M  bias + 36 MFMAs", "E  epilogue -> row ring", "H  head_partial alone (16-20 MFMAs 16x16x32)"],
-    "ringtail": ["W  counted wait + barrier", "I  DMA issue", "B  head_row (9 MFMAs, exp/rcp, 3 stores)", "F  finish_a (partner sums, ReLU, row ring)", "A  partial_a (36 MFMAs 16x16x32, 18 reads)"],
+    "ringtail": ["W  counted wait + barrier", "I  DMA issue", "B  head_row (9 MFMAs, exp/rcp, 3 stores)", "-", "A  stage_a (36 MFMAs 16x16x32, 18 reads, bias / ReLU / round, row-ring write)"],
     "ringfirst": ["W  barrier", "I  frame loads + stores of row t-3", "A  stage A (5 MFMAs + epilogue -> row ring)", "B  stage B (36 MFMAs + epilogue -> staging)", "P  frame_put"],
 }
 KIND = {"ring": 10, "tail": 11, "head": 12, "ringtail": 14, "ringfirst": 15}
@@ -47,7 +47,7 @@ def one(kind):
     steps = v[:, 7]
     per = v[:, :5] / steps[:, None]
     tot = v[:, 5]
-    step_total = per[:, :4].sum(1) if kind in ("ring", "tail", "head") else per.sum(1)
+    step_total = per[:, :4].sum(1) if kind in ("ring", "tail", "head") else per.sum(1)   # (head: segment 4 is a part of segment 1)
     print(f"== {kind}: {len(v)} waves, {np.median(steps):.0f} row steps per wave, kernel {np.median(tot):.0f} cycles per wave (s_memtime ticks = 100 MHz x? -> shares matter)")
     for i, name in enumerate(SEGS[kind]):
         if name == "-":
