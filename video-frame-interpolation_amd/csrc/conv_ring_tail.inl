@@ -17,7 +17,8 @@
 //   * both LDS images are UNPADDED and XOR-swizzled for the 16x16x32 operand pattern: the input ring (128-byte pixels, unit u of
 //     pixel c at u ^ swz16(c) - the DMA's lanes fetch the permuted piece) and the row ring (64-byte pixels, unit u at
 //     u ^ (((c >> 2) & 1) << 1)); both conflict-free on paper (tools/lds_swizzle_search.py);
-//   * per step and wave exactly 3 DMA + 3 store instructions: the counted wait is vmcnt(3 + 6 (D - 2)) = 9 at D = 3.
+//   * per step and wave exactly 3 DMA + 1 store instruction (round 5: the head's three planes leave in ONE store): the counted wait is
+//     vmcnt(1 + 4 (D - 2)) = 5 at D = 3.
 #ifndef EMAVFI_RT_ABL
 #define EMAVFI_RT_ABL 0   // timing-only ablations (diagnostic builds): 1 every DMA reads the zero page, 2 no head, 4 no stage-A MFMAs
 #endif
@@ -25,7 +26,7 @@ template <typename T> struct RingTailCfg {
     static constexpr int TW = 64, TWO = TW - 2, IW = TW + 2, IN_PX = 128, ROWSLOT = IW * 8, ROWINST = (ROWSLOT + 63) / 64, ROWB = ROWINST * 1024;
     static constexpr int D = 3, RING = D + 2, MID_PX = 64, MID = TW * MID_PX, NMID = 4;
     static constexpr int MID_OFF = RING * ROWB, SCRATCH_OFF = MID_OFF + NMID * MID, LDS_BYTES = SCRATCH_OFF + 1024;
-    static constexpr int NDMA = (ROWINST + 3) / 4, NSTORE = 3, VMWAIT = NSTORE + (NDMA + NSTORE) * (D - 2);
+    static constexpr int NDMA = (ROWINST + 3) / 4, NSTORE = 1, VMWAIT = NSTORE + (NDMA + NSTORE) * (D - 2);
     static_assert(sizeof(T) == 2 && 2 * LDS_BYTES <= 160 * 1024 && NDMA == 3, "16-bit types; two workgroups per CU");
 };
 
@@ -71,11 +72,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvPara
     for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
         for (int e = 0; e < 4; ++e) ba[blk][e] = p.bias[blk * 16 + kb * 4 + e];
-    // ---- stage B: the head's nine taps (K = 32 each), block 0 of its packing; bias of rows 0..2 (lanes kb == 0)
+    // ---- stage B: the head's nine taps (K = 32 each), block 0 of its packing.  Output channel c is fed to the matrix core as row 4 c of
+    // the 16-row block (rows 4 c + 1 .. + 3 and 12 .. 15 read a zero row of the blob), so that the accumulator's register 0 of lane
+    // (j, kb) IS channel kb of pixel j: one bias add, one exp / rcp sequence and ONE store instruction serve all three planes (with
+    // the channels in rows 0..2 they sat in registers 0..2 of the kb == 0 lanes: three epilogues on 16 useful lanes, three stores)
     vec hw[9];
+    {
+        const int i = lane & 15, srow = ((i & 3) == 0 && (i >> 2) < p.nplanes) ? (i >> 2) : 15;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) hw[t] = *reinterpret_cast<const vec *>((const char *)p.head_w + t * 2048 + lane * 16);
-    const float hb0 = p.head_bias[0], hb1 = p.nplanes > 1 ? p.head_bias[1] : 0.0f, hb2 = p.nplanes > 2 ? p.head_bias[2] : 0.0f;
+        for (int t = 0; t < 9; ++t) hw[t] = *reinterpret_cast<const vec *>((const char *)p.head_w + t * 2048 + (kb * 16 + srow) * 16);
+    }
+    const float hb = kb < p.nplanes ? p.head_bias[kb < p.nplanes ? kb : 0] : 0.0f;
     int hxo[3];
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) hxo[dx] = (wave * 16 + j + dx) * C::MID_PX + ((kb ^ s4(wave * 16 + j + dx)) << 4);
@@ -113,9 +120,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvPara
                 asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "m0");
             }
         };
-        // the head's stores: wave w owns head columns [16 w, 16 w + 16); output rows 0..2 of a pixel live in the lanes with kb == 0
+        // the head's store: wave w owns head columns [16 w, 16 w + 16); lane (j, kb) holds channel kb of column 16 w + j: plane kb
         const int hc = wave * 16 + j, hx = tx * C::TWO + hc;
-        const unsigned soff = (hc < C::TWO && hx < p.Wout && kb == 0) ? (unsigned)hx * 4u : 0x80000000u;
+        const unsigned soff = (hc < C::TWO && hx < p.Wout && kb < p.nplanes) ? (unsigned)hx * 4u + (unsigned)kb * (unsigned)(p.Hout * p.Wout) * 4u : 0x80000000u;
         const size_t plane = (size_t)p.Hout * p.Wout;
         // stage A: row y of the 64 -> 32 layer for this wave's 16 columns, all 32 channels: 18 operand reads, 36 MFMAs, then bias, ReLU,
         // rounding and the row-ring write (zero outside the image: the rows are the head convolution's padding)
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvPara
                 *reinterpret_cast<__attribute__((address_space(3))) u2_t *>(mp) = u2_t{__builtin_bit_cast(unsigned, lo) & keepm, __builtin_bit_cast(unsigned, hi) & keepm};
             }
         };
-        // stage B: head row yb from the stage-A rows yb - 1 .. yb + 1; NSTORE = 3 stores (planes 0..2)
+        // stage B: head row yb from the stage-A rows yb - 1 .. yb + 1; NSTORE = 1 store (lane (j, kb): plane kb)
         auto head_row = [&](int yb, bool real) {
             f32x4 hacc[3] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
             int mr[3];
@@ -175,27 +182,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvPara
             for (int t = 0; t < 9; ++t) hxv[t] = *reinterpret_cast<const __attribute__((address_space(3))) vec *>((lchar_t *)smem + mr[t / 3] + hxo[t % 3]);
 #pragma unroll
             for (int t = 0; t < ((EMAVFI_RT_ABL & 2) ? 1 : 9); ++t) mma_k32(hacc[t % 3], hw[t], hxv[t]);
-            float v[3] = {(hacc[0][0] + hacc[1][0]) + hacc[2][0] + hb0, (hacc[0][1] + hacc[1][1]) + hacc[2][1] + hb1, (hacc[0][2] + hacc[1][2]) + hacc[2][2] + hb2};
+            float o = (hacc[0][0] + hacc[1][0]) + hacc[2][0] + hb;
             float *orow = p.out_planar + (size_t)b * p.nplanes * plane + (size_t)(real ? yb : ys) * p.Wout;
-#pragma unroll
-            for (int i = 0; i < C::NSTORE; ++i) {
-                float o = v[i];
-                if constexpr (TANH) {   // ema_vfi.py:106,146 (round16: every op rounds as an fp16 tensor op does under autocast)
-                    if constexpr (R16) {
-                        // tanh in fp32, then the fp16 roundings of the tensor ops (what a CUDA fp16 tanh does): 1 - 2 / (1 + exp(2x)) on v_exp_f32 +
-                        // v_rcp_f32 (a few fp32 ulp: invisible behind the rounding to fp16 except on exact ties; the cancellation near 0
-                        // disappears in the `+ 1`), branch-free - ocml's tanhf brought branches into the row loop that scattered its blocks
-                        o = (float)(half_t)o;
-                        const float th = 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * o));
-                        o = (float)(half_t)((float)(half_t)th + 1.0f) / 2.0f;
-                    }
-                    // (tanh(x) + 1) / 2 = 1 / (1 + exp(-2x)): v_exp_f32 + v_rcp_f32 (2 ulp) instead of ocml's branchy tanhf, which cost this
-                    // kernel as much as its MFMAs (three calls per pixel on all 64 lanes of the wave)
-                    else o = __frcp_rn(1.0f + __expf(-2.0f * o));
-                } else if constexpr (R16) o = (float)(half_t)o;
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(orow + (i < p.nplanes ? i : 0) * plane, 0, (real && i < p.nplanes) ? 0x7ffffff0 : 0, 0x00020000);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rs, soff, 0, 0);
-            }
+            if constexpr (TANH) {   // ema_vfi.py:106,146 (round16: every op rounds as an fp16 tensor op does under autocast)
+                if constexpr (R16) {
+                    // tanh in fp32, then the fp16 roundings of the tensor ops (what a CUDA fp16 tanh does): 1 - 2 / (1 + exp(2x)) on v_exp_f32 +
+                    // v_rcp_f32 (a few fp32 ulp: invisible behind the rounding to fp16 except on exact ties; the cancellation near 0
+                    // disappears in the `+ 1`), branch-free - ocml's tanhf brought branches into the row loop that scattered its blocks
+                    o = (float)(half_t)o;
+                    const float th = 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * o));
+                    o = (float)(half_t)((float)(half_t)th + 1.0f) / 2.0f;
+                }
+                // (tanh(x) + 1) / 2 = 1 / (1 + exp(-2x)): v_exp_f32 + v_rcp_f32 (2 ulp) instead of ocml's branchy tanhf, which cost this
+                // kernel as much as its MFMAs
+                else o = __frcp_rn(1.0f + __expf(-2.0f * o));
+            } else if constexpr (R16) o = (float)(half_t)o;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(orow, 0, real ? 0x7ffffff0 : 0, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rs, soff, 0, 0);
         };
         // input rows a0 - 1 .. a0 + D - 1 -> slots 0 .. D, each followed by NSTORE dropped stores: the steady state's instruction pattern
 #pragma unroll 1
