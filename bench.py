@@ -275,7 +275,7 @@ def stream_legs(sd, dev, B, H, W):
                                        "compute stream); median of three runs of the 64-pair stream; PCIe-inclusive, never part of `value`"}
     # a long stream, where pipeline fill / drain no longer counts: the steady-state cost of the harness
     long_frames = [frames[i % 65] for i in range(257)]
-    n2, el2 = run(long_frames, 17, reps=1, interpolation_factor=1, batch_pairs=B, copy_out=False)
+    n2, el2 = run(long_frames, 25, reps=3, interpolation_factor=1, batch_pairs=B, copy_out=False)
     out["also_stream_pcie"]["long_stream_256_pairs"] = round(256 / el2, 2)
     a, b = synth.fast_frames(7, 4, 1080, 1920, device=dev)
     with torch.no_grad():
