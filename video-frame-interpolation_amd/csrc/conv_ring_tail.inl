@@ -72,15 +72,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvPara
     for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
         for (int e = 0; e < 4; ++e) ba[blk][e] = p.bias[blk * 16 + kb * 4 + e];
-    // ---- stage B: the head's nine taps (K = 32 each), block 0 of its packing.  Output channel c is fed to the matrix core as row 4 c of
-    // the 16-row block (rows 4 c + 1 .. + 3 and 12 .. 15 read a zero row of the blob), so that the accumulator's register 0 of lane
-    // (j, kb) IS channel kb of pixel j: one bias add, one exp / rcp sequence and ONE store instruction serve all three planes (with
-    // the channels in rows 0..2 they sat in registers 0..2 of the kb == 0 lanes: three epilogues on 16 useful lanes, three stores)
-    vec hw[9];
+    // ---- stage B: the 32 -> 3 head with its VERTICAL taps on the matrix core's rows.  Row 4 c + dy of the 16-row A operand of the MFMA for
+    // horizontal tap dx holds W[c][dy][dx][0..31] (c < 3, dy < 3; the other rows read a zero row of the blob), the B operand is the
+    // row ring's newest row rho, 16 pixels shifted by dx: ONE MFMA per dx adds row rho's contribution to the three output rows it
+    // belongs to - register dy of the accumulator of lane (j, kb = c) is output row rho + 1 - dy, channel c, pixel j.  After the three
+    // MFMAs register 2 is a finished row; the accumulator then rotates (2 <- 1 <- 0 <- 0).  Three operand reads and three MFMAs per head
+    // row instead of nine and nine, 12 weight registers instead of 36, and still one epilogue and ONE store for the three planes.
+    vec hw[3];
     {
-        const int i = lane & 15, srow = ((i & 3) == 0 && (i >> 2) < p.nplanes) ? (i >> 2) : 15;
+        const int i = lane & 15, c = i >> 2, dy = i & 3;
+        const bool realrow = c < p.nplanes && dy < 3;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) hw[t] = *reinterpret_cast<const vec *>((const char *)p.head_w + t * 2048 + (kb * 16 + srow) * 16);
+        for (int dx = 0; dx < 3; ++dx)
+            hw[dx] = *reinterpret_cast<const vec *>((const char *)p.head_w + (realrow ? dy * 3 + dx : 0) * 2048 + (kb * 16 + (realrow ? c : 15)) * 16);
     }
     const float hb = kb < p.nplanes ? p.head_bias[kb < p.nplanes ? kb : 0] : 0.0f;
     int hxo[3];
@@ -171,18 +175,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvPara
                 *reinterpret_cast<__attribute__((address_space(3))) u2_t *>(mp) = u2_t{__builtin_bit_cast(unsigned, lo) & keepm, __builtin_bit_cast(unsigned, hi) & keepm};
             }
         };
-        // stage B: head row yb from the stage-A rows yb - 1 .. yb + 1; NSTORE = 1 store (lane (j, kb): plane kb)
+        // stage B: the row ring's row rho (written in the step before) enters the head; head row rho - 1 = yb is finished by it.
+        // NSTORE = 1 store (lane (j, kb): plane kb)
+        f32x4 hacc = {0.0f, 0.0f, 0.0f, 0.0f};   // per item: register dy = the pending sums of output row (newest row consumed) + 1 - dy
         auto head_row = [&](int yb, bool real) {
-            f32x4 hacc[3] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
-            int mr[3];
+            const int mr = C::MID_OFF + ((yb + 1 - a0) & 3) * C::MID;
+            vec hxv[3];
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy) mr[dy] = C::MID_OFF + ((yb - 1 + dy - a0) & 3) * C::MID;
-            vec hxv[9];
+            for (int dx = 0; dx < 3; ++dx) hxv[dx] = *reinterpret_cast<const __attribute__((address_space(3))) vec *>((lchar_t *)smem + mr + hxo[dx]);
+            hacc = f32x4{0.0f, hacc[0], hacc[1], 0.0f};
 #pragma unroll
-            for (int t = 0; t < 9; ++t) hxv[t] = *reinterpret_cast<const __attribute__((address_space(3))) vec *>((lchar_t *)smem + mr[t / 3] + hxo[t % 3]);
-#pragma unroll
-            for (int t = 0; t < ((EMAVFI_RT_ABL & 2) ? 1 : 9); ++t) mma_k32(hacc[t % 3], hw[t], hxv[t]);
-            float o = (hacc[0][0] + hacc[1][0]) + hacc[2][0] + hb;
+            for (int dx = 0; dx < ((EMAVFI_RT_ABL & 2) ? 1 : 3); ++dx) mma_k32(hacc, hw[dx], hxv[dx]);
+            float o = hacc[2] + hb;
             float *orow = p.out_planar + (size_t)b * p.nplanes * plane + (size_t)(real ? yb : ys) * p.Wout;
             if constexpr (TANH) {   // ema_vfi.py:106,146 (round16: every op rounds as an fp16 tensor op does under autocast)
                 if constexpr (R16) {
@@ -204,7 +208,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvPara
 #pragma unroll 1
         for (int k = 0; k <= C::D; ++k) {
             dma_row(a0 - 1 + k, k, a0 - 1 + k <= a1 + 1);
-            head_row(ys, false);
+            // (the store of the steady-state pattern, dropped: a buffer of zero records.  NOT head_row: its accumulator carries state)
+            const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(p.out_planar, 0, 0, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b32(0u, rs0, soff, 0, 0);
         }
         int s0 = 0;   // ring slot of input row y - 1
 #pragma unroll 1
