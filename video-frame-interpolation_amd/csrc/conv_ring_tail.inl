@@ -19,6 +19,9 @@
 //     u ^ (((c >> 2) & 1) << 1)); both conflict-free on paper (tools/lds_swizzle_search.py);
 //   * per step and wave exactly 3 DMA + 1 store instruction (round 5: the head's three planes leave in ONE store): the counted wait is
 //     vmcnt(1 + 4 (D - 2)) = 5 at D = 3.
+#ifndef EMAVFI_RT_AHEAD
+#define EMAVFI_RT_AHEAD 4   // stage A's operand reads run this many ahead of their MFMAs
+#endif
 #ifndef EMAVFI_RT_ABL
 #define EMAVFI_RT_ABL 0   // timing-only ablations (diagnostic builds): 1 every DMA reads the zero page, 2 no head, 4 no stage-A MFMAs
 #endif
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvPara
                 int sl = s0 + dy; sl = sl >= C::RING ? sl - C::RING : sl;
                 xs[dy] = sl * C::ROWB;
             }
-            constexpr int AH = 4;
+            constexpr int AH = EMAVFI_RT_AHEAD;
             vec xq[AH + 1];
             auto xread = [&](int q) {   // step q: tap q >> 1 (dy = tap / 3, dx = tap % 3), k32 = q & 1
                 const int tap = q >> 1, dy = tap / 3, dx = tap - 3 * dy;
