@@ -191,17 +191,19 @@ def test_ring_kernels_issue_a_fixed_number_of_vmem_instructions_per_step(tmp_pat
     exactly 3 DMA + 2 store instructions per row step and nothing else that counts.  hipcc is free to
     break that silently (a branch over an all-inactive store, a spill, a hoisted load), so the shipped code objects are checked:
     between the counted wait and the drain behind the row loop there are three global_load_lds, three buffer stores (the fused head
-    kernel: two; the fused reconstruction tail: one) and no other vector-memory instruction, and N is stores + (3 + stores) (D - 2) (D = 3; the
+    kernel and the fused reconstruction tail: one) and no other vector-memory instruction, and N is stores + (3 + stores) (D - 2) (D = 3; the
     fused head kernel: D = 2)."""
     import re
     seen = {}
     for dis in _device_disassembly(tmp_path):
         for name, body in re.findall(r"<(_Z(?:19conv3x3_ring|23conv3x3_ringtail)_kernel\w+)>:\n(.*?)(?=\n\n|\Z)", dis, re.S):
             lines = body.splitlines()
-            tops = [i for i, l in enumerate(lines) if re.search(r"s_waitcnt vmcnt\((\d+)\) lgkmcnt\(0\)", l) and "vmcnt(0)" not in l]
+            # the row loop's counted wait: the one in front of a barrier (hipcc's own waits for the weight loads of the kernel's
+            # prologue look the same where N is small, but no barrier follows them)
+            tops = [i for i, l in enumerate(lines) if re.search(r"s_waitcnt vmcnt\((\d+)\) lgkmcnt\(0\)", l) and "vmcnt(0)" not in l
+                    and "s_barrier" in " ".join(lines[i:i + 4])]
             assert len(tops) == 1, (name, "one counted wait (the row loop's) expected", len(tops))
             n = int(re.search(r"vmcnt\((\d+)\)", lines[tops[0]]).group(1))
-            assert "s_barrier" in " ".join(lines[tops[0]:tops[0] + 4]), name
             # the loop body runs from the counted wait to the drain behind the loop, or to the end of the function where hipcc
             # laid the exit block out in front of the loop
             drain = next((i for i in range(tops[0] + 1, len(lines)) if re.search(r"s_waitcnt vmcnt\(0\)\s*$", lines[i].split("//")[0].rstrip())), len(lines))
@@ -211,8 +213,8 @@ def test_ring_kernels_issue_a_fixed_number_of_vmem_instructions_per_step(tmp_pat
             other = len(re.findall(r"\b(?:global_load_dword|global_store|buffer_load|flat_load|flat_store|scratch_)", region))
             m = re.search(r"ring_kernelI\w+?Lb(\d)ELb(\d)ELb(\d)E", name)   # <T, TAIL, HEAD, ALT>
             head, tail = bool(m) and m.group(2) == "1", "ringtail" in name   # (ringtail: ONE store - the frame's three planes leave together -, D = 3)
-            assert (dma, stores, other) == (3, 1 if tail else 2 if head else 3, 0), (name, dma, stores, other)
-            assert n == (5 if tail else 2 if head else 9), (name, n)
+            assert (dma, stores, other) == (3, 1 if tail or head else 3, 0), (name, dma, stores, other)
+            assert n == (5 if tail else 1 if head else 9), (name, n)
             seen[name] = n
     # bf16 and f16 instances of: 64 -> 64, the same storing the other 16-bit type (ALT), TAIL (67 -> 64), HEAD (+ flow head): 8;
     # reconstruction.1 + .2: bf16 and f16 x (round16, tanh head) = 8 (round 5: both became template arguments)
@@ -251,7 +253,11 @@ def test_ring_kernels_prime_their_rings_with_the_steady_state_pattern(tmp_path):
     for dis in _device_disassembly(tmp_path):
         for name, body in re.findall(r"<(_Z(?:19conv3x3_ring|20conv3x3_ring2|23conv3x3_ringtail)_kernel\w+)>:\n(.*?)(?=\n\n|\Z)", dis, re.S):
             ins, loops = _loops_of(body)
-            waits = [a for a, t in ins if re.match(r"s_waitcnt vmcnt\(\d+\) lgkmcnt\(0\)", t) and "vmcnt(0)" not in t]
+            # (the counted wait stands in front of a barrier; hipcc's own waits for the prologue's weight loads do not)
+            waits = [k for k, (a, t) in enumerate(ins) if re.match(r"s_waitcnt vmcnt\(\d+\) lgkmcnt\(0\)", t) and "vmcnt(0)" not in t]
+            if len(waits) > 1:
+                waits = [k for k in waits if any(t2 == "s_barrier" for _, t2 in ins[k + 1:k + 4])]
+            waits = [ins[k][0] for k in waits]
             assert len(waits) == 1, (name, len(waits))
             n = int(re.search(r"vmcnt\((\d+)\)", next(t for a, t in ins if a == waits[0])).group(1))
             def bars(l):
@@ -270,13 +276,13 @@ def test_ring_kernels_prime_their_rings_with_the_steady_state_pattern(tmp_path):
                 return dma, st, other
             m = re.search(r"ring_kernelI\w+?Lb(\d)ELb(\d)ELb(\d)E", name)
             ring2, head = "ring2" in name, bool(m) and m.group(2) == "1"
-            want_row = (3, 3, 0) if ring2 else (3, 1 if "ringtail" in name else 2 if head else 3, 0)
+            want_row = (3, 3, 0) if ring2 else (3, 1 if "ringtail" in name or head else 3, 0)
             want_prime = (3, 0, 0) if ring2 else want_row
             assert count(row) == want_row, (name, "row loop", count(row))
             if ring2:   # both roles' contractions are in it: 2 x 36 MFMAs
                 assert sum("v_mfma" in t for a, t in ins if row[0] <= a <= row[1]) == 72, name
             assert count(prime) == want_prime, (name, "priming loop", count(prime))
-            assert n == (3 if ring2 else 5 if "ringtail" in name else 2 if head else 9), (name, n)
+            assert n == (3 if ring2 else 5 if "ringtail" in name else 1 if head else 9), (name, n)
             seen[name] = n
     # ring: 8 instances (bf16 / f16 x {64 -> 64, ALT, TAIL, HEAD}); ringtail: 8 (bf16 / f16 x round16 x tanh head); ring2: 4 (bf16 / f16 x ALT)
     assert len(seen) == 20, sorted(seen)

@@ -19,9 +19,9 @@
 //     operands straight from the ninth piece of the ring pixels (two ds_read_b64);
 //   * outputs go through a double-buffered LDS row (64 pixels x 128 bytes) so that a store instruction writes whole lines;
 //   * HEAD (motion_estimation.1 + .2, ema_vfi.py:90-92): the 64 -> 64 rows are NOT stored; they go (zeroed outside the image: the
-//     next convolution's padding) into a second LDS ring of four rows, and two steps behind them the same workgroup computes
-//     the 64 -> <= 2 planar head (the flow) from that ring on v_mfma_f32_16x16x32, its 18 k-steps split over the four waves (the
-//     weights of a wave's steps are 20 registers; the partial sums meet in LDS one step later).  A strip then
+//     next convolution's padding) into a second LDS ring of two rows, and one step behind them the same workgroup feeds each row
+//     to the 64 -> <= 2 planar head (the flow) on v_mfma_f32_16x16x32 with the head's VERTICAL taps on the MFMA's rows (six MFMAs
+//     per wave and row add the row's contribution to the three head rows it belongs to; see the kernel).  A strip then
 //     yields 62 head columns for 64 computed ones and a segment computes two extra rows; in exchange one launch, 0.94 GB of
 //     writes and 0.94 GB of reads per B = 8 x 720p disappear (DMA depth 2 instead of 3: the two rings fill the 80 KiB);
 //   * work items = (strip, vertical segment), dealt round-robin to 2 workgroups per CU; the host picks the segment height so
@@ -40,16 +40,16 @@ template <typename T, bool TAIL, bool HEAD> struct ConvRingCfg {
     static constexpr int TWO = HEAD ? TW - 2 : TW;   // columns a strip contributes to the launch's output
     static constexpr int D = HEAD ? 2 : EMAVFI_RING_DEPTH, RING = D + 2;
     // !HEAD: two output staging rows, 144-byte pixels (conflict-free for the 32x32 epilogue's writes and the 8-lanes-per-pixel store reads).
-    // HEAD: the ring of four 64 -> 64 rows, UNPADDED 128-byte pixels whose 16-byte unit u of pixel c lies at u ^ swz16(c): the head's
+    // HEAD: the ring of two 64 -> 64 rows (one being written, one being read by the head), UNPADDED 128-byte pixels whose 16-byte unit u of pixel c lies at u ^ swz16(c): the head's
     // 16x16x32 operand reads (lane (j, kb): unit 4 k32 + kb of pixel c0 + j) are conflict-free that way; at 144 bytes every service
     // group of every read had a two-way conflict (20.3 % of the kernel's LDS cycles; tools/lds_swizzle_search.py)
-    static constexpr int STG_PX = HEAD ? 128 : 128 + 16, STG = TW * STG_PX, NSTG = HEAD ? 4 : 2;
+    static constexpr int STG_PX = HEAD ? 128 : 128 + 16, STG = TW * STG_PX, NSTG = 2;
     static constexpr int STG_OFF = RING * ROWB, BIAS_OFF = STG_OFF + NSTG * STG, BIAS_BYTES = HEAD ? 256 : 16 * 64 * 4;
-    static constexpr int HW_OFF = BIAS_OFF + BIAS_BYTES, HW_BYTES = HEAD ? 2 * 2048 : 0;   // head partial sums [row parity][wave][block][pixel][2] floats
+    static constexpr int HW_OFF = BIAS_OFF + BIAS_BYTES, HW_BYTES = HEAD ? 512 : 0;   // (HEAD: columns 62, 63 of the head read two pixels past a row)
     static constexpr int SCRATCH_OFF = HW_OFF + HW_BYTES, LDS_BYTES = SCRATCH_OFF + 1024;
-    // stores per step and wave: HEAD the head's two planes; else two for the row's 512 16-byte units + one for the 64 pad units of
+    // stores per step and wave: HEAD one (lane (j, kb): plane kb of head pixel j); else two for the row's 512 16-byte units + one for the 64 pad units of
     // ConvParams::out_fill (all lanes out of range when it is off: the count must not depend on it)
-    static constexpr int NDMA = (ROWINST + 3) / 4, NSTORE = HEAD ? 2 : 3, VMWAIT = NSTORE + (NDMA + NSTORE) * (D - 2);
+    static constexpr int NDMA = (ROWINST + 3) / 4, NSTORE = HEAD ? 1 : 3, VMWAIT = NSTORE + (NDMA + NSTORE) * (D - 2);
     static constexpr int WMAIN = 9 * 4 * 2 * 1024;   // bytes of [tap][kg][fragment][lane][8]; the tail [j 3][fragment][lane][8] follows
     static_assert(sizeof(T) == 2 && 2 * LDS_BYTES <= 160 * 1024 && !(TAIL && HEAD), "16-bit types; two workgroups per CU");
 };
@@ -91,25 +91,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
             for (int j = 0; j < 3; ++j) wt[j] = *reinterpret_cast<const vec *>(wb + C::WMAIN + j * 2048);
         }
     }
-    // ---- HEAD: the 18 k-steps (tap, k32) of the 64 -> 2 head are split over the four waves (wave w: steps w, w + 4, .., < 18), each
-    // for all four 16-pixel blocks of the strip: the step's weights are 4 registers of the wave (20 in all) instead of an LDS read per
-    // MFMA - the fused kernel is LDS-bandwidth-bound - and the waves' partial sums meet in LDS one step later (head_finish).
+    // ---- HEAD: the 64 -> 2 head with its VERTICAL taps on the matrix core's rows (as conv_ring_tail.inl's head).  Row 4 c + dy of the
+    // 16-row A operand of the MFMA for (horizontal tap dx, k32) holds W[c][dy][dx][32 k32 ..] (c < 2, dy < 3; the other rows read a
+    // zero row of the blob), the B operand is the newest 64 -> 64 row rho, 16 pixels shifted by dx: SIX MFMAs add row rho's
+    // contribution to the three head rows it belongs to - register dy of lane (j, kb = c) is head row rho + 1 - dy, plane c, pixel j;
+    // register 2 is then a finished row and the accumulator rotates.  Wave w owns head columns [16 w, 16 w + 16): 6 operand reads and
+    // 6 MFMAs per wave and step (was 18 + 18 and a round trip of partial sums through LDS), 24 weight registers, ONE store.
     // Weights: block 0 of the 16x16x32 packing [tap][k32][cout16 block 0..1][lane (i, kb)][8] (rows >= 2 are zero in the blob).
-    float hb0 = 0.0f, hb1 = 0.0f;   // the head's bias (loaded once: a global load inside the row loop would make hipcc wait vmcnt(0),
-                                    // i.e. for the whole DMA ring)
-    vec hwr[HEAD ? 5 : 1];
-    int hxo[HEAD ? 5 : 1], hdy[HEAD ? 5 : 1];
+    float hb = 0.0f;   // the head's bias (loaded once: a global load inside the row loop would make hipcc wait vmcnt(0), i.e. for the
+                       // whole DMA ring)
+    vec hwr[HEAD ? 6 : 1];
+    int hxo[HEAD ? 6 : 1];
     if constexpr (HEAD) {
-        hb0 = p.head_bias[0]; hb1 = p.nplanes > 1 ? p.head_bias[1] : 0.0f;
-        const int j = lane & 15, kb = lane >> 4;
+        const int j = lane & 15, kb = lane >> 4, c = j >> 2, dy = j & 3;
+        const bool realrow = c < p.nplanes && dy < 3;
+        hb = kb < p.nplanes ? p.head_bias[kb < p.nplanes ? kb : 0] : 0.0f;
 #pragma unroll
-        for (int sl = 0; sl < 5; ++sl) {
-            const int tk = min(wave_u + 4 * sl, 17), tap = tk >> 1, k32 = tk & 1, dy = tap / 3, dx = tap - 3 * dy;
-            hwr[sl] = *reinterpret_cast<const vec *>((const char *)p.head_w + tk * 2048 + lane * 16);
-            hdy[sl] = dy;
-            // byte offset of this lane's operand inside a row for column block 0: pixel c = j + dx, unit (4 k32 + kb) ^ swz16(c)
-            // (block n adds 16 pixels = 2048 bytes: swz16 has period 8 pixels)
-            hxo[sl] = ((j + dx) * C::STG_PX + ((kb ^ swz16(j + dx)) << 4)) ^ (k32 * 64);
+        for (int q = 0; q < 6; ++q) {
+            const int dx = q >> 1, k32 = q & 1;
+            hwr[q] = *reinterpret_cast<const vec *>((const char *)p.head_w + (realrow ? (dy * 3 + dx) * 2 + k32 : 0) * 2048 + (kb * 16 + (realrow ? c : 15)) * 16);
+            // byte offset of this lane's operand inside a row: pixel c = 16 wave + j + dx, unit (4 k32 + kb) ^ swz16(c) (swz16 has
+            // period 8 pixels)
+            hxo[q] = wave * 2048 + (((j + dx) * C::STG_PX + ((kb ^ swz16(j + dx)) << 4)) ^ (k32 * 64));
         }
     }
     // ---- lane constants of the row DMA: instruction jn covers 16-byte slots [64 jn, 64 jn + 64) of a ring row
@@ -178,11 +181,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
             }
             soff[2] = (p.out_fill && tid < npx) ? (unsigned)tid * (unsigned)p.out_ps * (unsigned)sizeof(T) + 128u : 0x80000000u;
         } else {
-            // the head: wave w owns head columns [16 w, 16 w + 16) of the strip's 62; lanes kb == 0 hold output rows 0..3 of a pixel
-            const int hc = wave * 16 + (lane & 15), hx = tx * C::TWO + hc;
-            const bool hok = hc < C::TWO && hx < p.Wout && (lane >> 4) == 0;
-#pragma unroll
-            for (int i = 0; i < C::NSTORE; ++i) soff[i] = (hok && i < p.nplanes) ? (unsigned)hx * 4u : 0x80000000u;
+            // the head: wave w owns head columns [16 w, 16 w + 16) of the strip's 62; lane (j, kb) holds plane kb of pixel j
+            const int hc = wave * 16 + (lane & 15), hx = tx * C::TWO + hc, kb = lane >> 4;
+            const bool hok = hc < C::TWO && hx < p.Wout && kb < p.nplanes;
+            soff[0] = hok ? ((unsigned)hx + (unsigned)kb * (unsigned)p.Hout * (unsigned)p.Wout) * 4u : 0x80000000u;
         }
         auto store_row = [&](int y, bool real) {
             lchar_t *stg = (lchar_t *)smem + C::STG_OFF + (y & 1) * C::STG;
@@ -196,65 +198,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
             }
             __builtin_amdgcn_raw_buffer_store_b128(u4_t{0u, 0u, 0u, 0u}, rs, soff[2], 0, 0);
         };
-        // head row yb from the 64 -> 64 rows yb - 1 .. yb + 1 (mid-ring slots (row - a0) & 3): this wave's k-steps, all four blocks
-        auto head_partial = [&](int yb) {
+        // HEAD: the 64 -> 64 row rho = yb + 1 (mid-ring slot (rho - a0) & 1, written in the step before) enters the head; head row yb is
+        // finished by it.  hacc: register dy = the pending sums of head row rho + 1 - dy (rows below ys are never stored: whatever the
+        // registers and the ring hold when an item starts only reaches those)
+        f32x4 hacc = {0.0f, 0.0f, 0.0f, 0.0f};
+        auto head_row = [&](int yb, bool real) {
             if constexpr (HEAD) {
-                f32x4 hp[4];
+                const lchar_t *mr = (const lchar_t *)smem + C::STG_OFF + ((yb + 1 - a0) & 1) * C::STG;
+                vec hxv[6];
 #pragma unroll
-                for (int n = 0; n < 4; ++n) hp[n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                const char *xs[5];
+                for (int q = 0; q < 6; ++q) hxv[q] = *reinterpret_cast<const __attribute__((address_space(3))) vec *>(mr + hxo[q]);
+                hacc = f32x4{0.0f, hacc[0], hacc[1], 0.0f};
 #pragma unroll
-                for (int sl = 0; sl < 5; ++sl) xs[sl] = smem + C::STG_OFF + ((yb - 1 + hdy[sl] - a0) & 3) * C::STG + hxo[sl];
-                // 16 (read, MFMA) pairs, operands four pairs ahead (fenced like the main loop's); four independent chains
-                constexpr int HA = 4;
-                vec hx[HA + 1];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < HA; ++q) hx[q] = *reinterpret_cast<const vec *>(xs[q >> 2] + (q & 3) * 2048);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    if (q + HA < 16) hx[(q + HA) % (HA + 1)] = *reinterpret_cast<const vec *>(xs[(q + HA) >> 2] + ((q + HA) & 3) * 2048);
-                    mma_k32(hp[q & 3], hwr[q >> 2], hx[q % (HA + 1)]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (wave_u + 16 < 18) {   // waves 0 and 1 own a fifth k-step
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) hx[n] = *reinterpret_cast<const vec *>(xs[4] + n * 2048);
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) mma_k32(hp[n], hwr[4], hx[n]);
-                }
-                if (lane < 16) {   // output rows 0..1 of a pixel live in the lanes with kb == 0
-                    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-                    char *pp = smem + C::HW_OFF + (yb & 1) * 2048 + (wave * 4 * 16 + lane) * 8;
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) *reinterpret_cast<f32x2_t *>(pp + n * 128) = f32x2_t{hp[n][0], hp[n][1]};
-                }
-            }
-        };
-        // one step later: wave b adds the four partial sums of block b and stores the row (NSTORE = 2 stores: planes 0 and 1)
-        auto head_finish = [&](int yb, bool real) {
-            if constexpr (HEAD) {
-                typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-                const char *pp = smem + C::HW_OFF + (yb & 1) * 2048 + (wave * 16 + (lane & 15)) * 8;
-                const f32x2_t p0 = *reinterpret_cast<const f32x2_t *>(pp), p1 = *reinterpret_cast<const f32x2_t *>(pp + 512);
-                const f32x2_t p2 = *reinterpret_cast<const f32x2_t *>(pp + 1024), p3 = *reinterpret_cast<const f32x2_t *>(pp + 1536);
-                float v[2] = {((p0[0] + p1[0]) + (p2[0] + p3[0])) + hb0, ((p0[1] + p1[1]) + (p2[1] + p3[1])) + hb1};
-                const size_t plane = (size_t)p.Hout * p.Wout;
-                float *orow = p.out_planar + (size_t)b * p.nplanes * plane + (size_t)(real ? yb : ys) * p.Wout;
-#pragma unroll
-                for (int i = 0; i < C::NSTORE; ++i) {
-                    float o = v[i];
-                    if (p.round16) o = (float)(half_t)o;
-                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(orow + (i < p.nplanes ? i : 0) * plane, 0, real ? 0x7ffffff0 : 0, 0x00020000);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rs, soff[i], 0, 0);
-                }
+                for (int q = 0; q < 6; ++q) mma_k32(hacc, hwr[q], hxv[q]);
+                float o = hacc[2] + hb;
+                if (p.round16) o = (float)(half_t)o;
+                float *orow = p.out_planar + (size_t)b * p.nplanes * p.Hout * p.Wout + (size_t)(real ? yb : ys) * p.Wout;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(orow, 0, real ? 0x7ffffff0 : 0, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rs, soff[0], 0, 0);
             }
         };
         // input rows a0 - 1 .. a0 + D - 1 -> slots 0 .. D, each followed by NSTORE dropped stores: the steady state's instruction pattern
 #pragma unroll 1
         for (int k = 0; k <= C::D; ++k) {
             dma_row(a0 - 1 + k, k, a0 - 1 + k <= a1 + 1);
-            if constexpr (HEAD) head_finish(ys, false); else store_row(ys, false);
+            if constexpr (HEAD) {   // (the store of the steady-state pattern, dropped.  NOT head_row: its accumulator carries state)
+                const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(p.out_planar, 0, 0, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b32(0u, rs0, soff[0], 0, 0);
+            } else
+                store_row(ys, false);
         }
         int s0 = 0;   // ring slot of input row y - 1
 #pragma unroll 1
@@ -270,9 +242,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
                 dma_row(y + C::D, sl, y + C::D <= a1 + 1);
             }
             if constexpr (HEAD) {
-                head_finish(y - 3, y - 3 >= ys && !(EMAVFI_RING_ABL & 2));
                 RING_STAMP(ts1b);
-                head_partial(y - 2);
+                head_row(y - 2, y - 2 >= ys && !(EMAVFI_RING_ABL & 2));
                 RING_STAMP_ADD(4, ts1b, ring_stamp());
             } else
                 store_row(y - 1, y > a0 && !(EMAVFI_RING_ABL & 2));
@@ -340,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
             // rows, zero outside the image: they are the head convolution's padding)
             {
                 typedef __attribute__((ext_vector_type(2))) T pair_t;
-                const int slot = HEAD ? ((y - a0) & 3) : (y & 1);
+                const int slot = HEAD ? ((y - a0) & 1) : (y & 1);
                 const bool inside = !HEAD || ((unsigned)y < (unsigned)p.Hout && (unsigned)xg < (unsigned)p.Wout);
                 lchar_t *stg = (lchar_t *)smem + C::STG_OFF + slot * C::STG + (cb * 32 + r) * C::STG_PX;
                 const int usw = HEAD ? swz16(cb * 32 + r) : 0;
@@ -369,11 +340,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the next item primes the same slots)
         __syncthreads();
         if constexpr (HEAD) {
-            head_finish(a1 - 2, a1 - 2 >= ys);   // (a1 = ye: rows ye - 2 and ye - 1 are still to come)
-            head_partial(a1 - 1);
-            __syncthreads();
-            head_finish(a1 - 1, true);
-            __syncthreads();                     // the next item's first rows overwrite the ring of 64 -> 64 rows and the partial sums
+            head_row(a1 - 1, true);   // (a1 = ye: the segment's last head row, from the 64 -> 64 rows ye - 2 .. ye)
+            __syncthreads();          // the next item's first rows overwrite the ring of 64 -> 64 rows
         } else
             store_row(a1, true);
     }
