@@ -35,10 +35,76 @@
 #ifndef EMAVFI_RING_AHEAD
 #define EMAVFI_RING_AHEAD 4
 #endif
+// ---- what a workgroup of a persistent ring kernel computes: pieces (strip, output rows [ys, ye)).
+//   * chunked (nseg == 0; round 5, the default): the launch's nstrip * Hout output rows, strip after strip, are cut into gridDim.x equal
+//     contiguous ranges - a workgroup walks down ONE range, i.e. one or two pieces.  Every piece primes its rings and reads (or, in the
+//     fused kernels, computes) two halo rows once: 720p on 512 workgroups is 1.4 pieces of ~225 rows per workgroup instead of five
+//     segments of 45 rows;
+//   * segments (nseg > 0; EMAVFI_RING_CHUNK=0): every strip is cut into nseg segments of seg_rows rows, dealt round-robin
+//     (conv_ring_segments picks nseg so that the items fill whole rounds).
+struct RingWork {
+    int left, strip0, y0;              // chunked: rows left in this workgroup's range, the next piece's strip and first row
+    int cur, end, stride;              // segments: the next item, the item count, the grid size (0 = chunked)
+    int hout, nstrip, seg_rows;
+    __device__ RingWork(int nstrip_, int hout_, int nseg, int seg_rows_) : hout(hout_), nstrip(nstrip_), seg_rows(seg_rows_)
+    {
+        if (nseg == 0) {   // seg_rows = (nstrip * hout) / gridDim.x (the host's division); the first `rem` workgroups take one row more
+            const int g = (int)blockIdx.x, q = seg_rows_, rem = nstrip * hout - q * (int)gridDim.x;
+            const unsigned first = (unsigned)(g * q + min(g, rem));
+            left = q + (g < rem ? 1 : 0);
+            strip0 = (int)(first / (unsigned)hout);
+            y0 = (int)first - strip0 * hout;
+            cur = end = stride = 0;
+        } else {
+            cur = (int)blockIdx.x;
+            end = nstrip * nseg;
+            stride = (int)gridDim.x;
+            left = strip0 = y0 = 0;
+        }
+    }
+    __device__ bool next(int &strip, int &ys, int &ye)
+    {
+        if (stride == 0) {
+            if (left <= 0) return false;
+            strip = strip0;
+            ys = y0;
+            ye = min(hout, y0 + left);
+            left -= ye - ys;
+            ++strip0;
+            y0 = 0;
+            return true;
+        }
+        if (cur >= end) return false;
+        strip = cur % nstrip;
+        ys = (cur / nstrip) * seg_rows;
+        ye = min(ys + seg_rows, hout);
+        cur += stride;
+        return true;
+    }
+};
+static void conv_ring_segments(int nstrip, int Hout, int grid, int *nseg_out, int *seg_rows_out);
+// grid size and (nseg, seg_rows) of a persistent ring launch
+static int conv_ring_work(int nstrip, int Hout, int grid, int *nseg, int *seg_rows)
+{
+    if (!(emavfi_switches() & SW_NO_RING_CHUNK) && (long)nstrip * Hout < (1l << 30)) {
+        const int total = nstrip * Hout, by8 = (total + 7) / 8;   // (tiny launches: at least eight rows per workgroup)
+        const int nwg = by8 < grid ? by8 : grid;
+        *nseg = 0;
+        *seg_rows = total / nwg;
+        return nwg;
+    }
+    conv_ring_segments(nstrip, Hout, grid, nseg, seg_rows);
+    const int nitems = nstrip * *nseg;
+    return nitems < grid ? nitems : grid;
+}
+
+#ifndef EMAVFI_HEAD_DEPTH
+#define EMAVFI_HEAD_DEPTH 2
+#endif
 template <typename T, bool TAIL, bool HEAD> struct ConvRingCfg {
     static constexpr int PSTR = 144, SP = 9, TW = 64, IW = TW + 2, ROWSLOT = IW * SP, ROWINST = (ROWSLOT + 63) / 64, ROWB = ROWINST * 1024;
     static constexpr int TWO = HEAD ? TW - 2 : TW;   // columns a strip contributes to the launch's output
-    static constexpr int D = HEAD ? 2 : EMAVFI_RING_DEPTH, RING = D + 2;
+    static constexpr int D = HEAD ? EMAVFI_HEAD_DEPTH : EMAVFI_RING_DEPTH, RING = D + 2;
     // !HEAD: two output staging rows, 144-byte pixels (conflict-free for the 32x32 epilogue's writes and the 8-lanes-per-pixel store reads).
     // HEAD: the ring of two 64 -> 64 rows (one being written, one being read by the head), UNPADDED 128-byte pixels whose 16-byte unit u of pixel c lies at u ^ swz16(c): the head's
     // 16x16x32 operand reads (lane (j, kb): unit 4 k32 + kb of pixel c0 + j) are conflict-free that way; at 144 bytes every service
@@ -71,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
     const unsigned lds0 = (unsigned)(size_t)(lchar_t *)smem;
     const int r = lane & 31, h = lane >> 5;
     const int frag = wave & 1, cb = wave >> 1;
-    const int ntx = (p.Wout + C::TWO - 1) / C::TWO, nstrip = ntx * p.B, nitems = nstrip * nseg;
+    const int ntx = (p.Wout + C::TWO - 1) / C::TWO, nstrip = ntx * p.B;
     const char *zeros = (const char *)p.zeros;
     const int npieces = TAIL ? 9 : 8;   // pieces of an input pixel that are read (a 64-channel layer never reads the ninth)
     const unsigned pixbytes = (unsigned)p.in_ps * (unsigned)sizeof(T);
@@ -135,11 +201,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
     }
 
     RING_STAMP_DECL;
+    RingWork work(nstrip, p.Hout, nseg, seg_rows);
+    int strip, ys, ye;
 #pragma unroll 1
-    for (int item = (int)blockIdx.x; item < nitems; item += (int)gridDim.x) {
-        const int strip = item % nstrip, seg = item / nstrip;
+    while (work.next(strip, ys, ye)) {
         const int b = strip / ntx, tx = strip - b * ntx;
-        const int ys = seg * seg_rows, ye = min(ys + seg_rows, p.Hout);
         // rows of the 64 -> 64 convolution this item computes: [a0, a1] (HEAD: one more on either side for the head's taps)
         const int a0 = HEAD ? ys - 1 : ys, a1 = HEAD ? ye : ye - 1;
         const char *gin = (const char *)p.in + (size_t)b * p.Hin * p.Win * p.in_ps * sizeof(T);
@@ -196,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
                 const u4_t v = *reinterpret_cast<const __attribute__((address_space(3))) u4_t *>(stg + px * C::STG_PX + ch * 16);
                 __builtin_amdgcn_raw_buffer_store_b128(v, rs, soff[i], 0, 0);
             }
-            __builtin_amdgcn_raw_buffer_store_b128(u4_t{0u, 0u, 0u, 0u}, rs, soff[2], 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(u4_t{0u, 0u, 0u, 0u}, rs, soff[C::NSTORE - 1], 0, 0);
         };
         // HEAD: the 64 -> 64 row rho = yb + 1 (mid-ring slot (rho - a0) & 1, written in the step before) enters the head; head row yb is
         // finished by it.  hacc: register dy = the pending sums of head row rho + 1 - dy (rows below ys are never stored: whatever the
@@ -310,7 +376,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
             // ---- optional ReLU; this wave's 32 channels of its 32 pixels into the row's staging buffer (HEAD: the ring of 64 -> 64
             // rows, zero outside the image: they are the head convolution's padding)
             {
-                typedef __attribute__((ext_vector_type(2))) T pair_t;
                 const int slot = HEAD ? ((y - a0) & 1) : (y & 1);
                 const bool inside = !HEAD || ((unsigned)y < (unsigned)p.Hout && (unsigned)xg < (unsigned)p.Wout);
                 lchar_t *stg = (lchar_t *)smem + C::STG_OFF + slot * C::STG + (cb * 32 + r) * C::STG_PX;
@@ -372,18 +437,22 @@ template <typename T, bool TAIL, bool HEAD, bool ALT = false> static int launch_
     if (ncu <= 0) return (int)hipErrorInvalidDevice;
     const int nstrip = ((p.Wout + C::TWO - 1) / C::TWO) * p.B, grid = ((emavfi_switches() & SW_RING_ONE_WG) ? 1 : 2) * ncu;   // (SW_RING_ONE_WG: measurement switch, common.h)
     int nseg, seg_rows;
-    conv_ring_segments(nstrip, p.Hout, grid, &nseg, &seg_rows);
-    const int nitems = nstrip * nseg;
-    conv3x3_ring_kernel<T, TAIL, HEAD, ALT><<<nitems < grid ? nitems : grid, 256, C::LDS_BYTES, s>>>(p, nseg, seg_rows);
+    const int nwg = conv_ring_work(nstrip, p.Hout, grid, &nseg, &seg_rows);
+    conv3x3_ring_kernel<T, TAIL, HEAD, ALT><<<nwg, 256, C::LDS_BYTES, s>>>(p, nseg, seg_rows);
     return (int)hipGetLastError();
 }
 
+template <typename T, bool TAIL, bool ALT> static int launch_conv_ringv_t(const ConvParams &p, hipStream_t s);
 template <typename T> static int launch_conv_ring(const ConvParams &p, hipStream_t s)
 {
     if (p.stride != 1 || p.nchunk != 1 || p.npass != 1 || p.nf != 2 || p.bias_mode > 1 || (p.epi != EPI_NONE && p.epi != EPI_RELU)) return -2;
     if (p.head_w) {   // + a planar head of <= 2 channels computed from the rows in LDS (NSTORE stores per step = its planes)
         if (p.ring != 2 || p.bias_mode != 0 || !p.head_bias || !p.out_planar || p.nplanes < 1 || p.nplanes > 2) return -2;
         return launch_conv_ring_t<T, false, true>(p, s);
+    }
+    if (emavfi_switches() & SW_RING_V) {   // conv_ring_v.inl: the vertical taps on the accumulators
+        if (p.out_alt) return p.ring == 2 ? launch_conv_ringv_t<T, false, true>(p, s) : -2;
+        if (p.ring != 3) return launch_conv_ringv_t<T, false, false>(p, s);
     }
     if (p.out_alt) return p.ring == 2 ? launch_conv_ring_t<T, false, false, true>(p, s) : -2;
     return p.ring == 3 ? launch_conv_ring_t<T, true, false>(p, s) : launch_conv_ring_t<T, false, false>(p, s);

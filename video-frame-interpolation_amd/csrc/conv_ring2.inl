@@ -43,7 +43,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring2_kernel(const ConvParams 
     const unsigned lds0 = (unsigned)(size_t)(lchar_t *)smem;
     const int r = lane & 31, h = lane >> 5;
     const int frag = wave & 1, cb = wave >> 1;
-    const int ntx = (p.Wout + C::TWO - 1) / C::TWO, nstrip = ntx * p.B, nitems = nstrip * nseg;
+    const int ntx = (p.Wout + C::TWO - 1) / C::TWO, nstrip = ntx * p.B;
     const char *zeros = (const char *)p.zeros;
     const unsigned pixbytes = (unsigned)p.in_ps * (unsigned)sizeof(T);
     const unsigned rowbytes = (unsigned)p.Win * pixbytes;
@@ -68,11 +68,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring2_kernel(const ConvParams 
         xcol[i] = (q < C::ROWSLOT && pc < 8) ? (unsigned)px : 0x40000000u;   // the ninth piece / slots past the row: the zero page
     }
 
+    RingWork work(nstrip, p.Hout, nseg, seg_rows);
+    int strip, ys, ye;
 #pragma unroll 1
-    for (int item = (int)blockIdx.x; item < nitems; item += (int)gridDim.x) {
-        const int strip = item % nstrip, seg = item / nstrip;
+    while (work.next(strip, ys, ye)) {
         const int b = strip / ntx, tx = strip - b * ntx;
-        const int ys = seg * seg_rows, ye = min(ys + seg_rows, p.Hout);
         const int a0 = ys - 1, a1 = ye;                      // layer A's rows [a0, a1]: one more on either side for B's taps
         const char *gin = (const char *)p.in + (size_t)b * p.Hin * p.Win * p.in_ps * sizeof(T);
         const int ox0 = tx * C::TWO - 1;                     // image column of A's column 0
@@ -263,9 +263,8 @@ template <typename T, bool ALT> static int launch_conv_ring2_t(const ConvParams 
     if (ncu <= 0) return (int)hipErrorInvalidDevice;
     const int nstrip = ((p.Wout + C::TWO - 1) / C::TWO) * p.B, grid = ncu;   // one 8-wave workgroup per CU
     int nseg, seg_rows;
-    conv_ring_segments(nstrip, p.Hout, grid, &nseg, &seg_rows);
-    const int nitems = nstrip * nseg;
-    conv3x3_ring2_kernel<T, ALT><<<nitems < grid ? nitems : grid, 512, C::LDS_BYTES, s>>>(p, nseg, seg_rows);
+    const int nwg = conv_ring_work(nstrip, p.Hout, grid, &nseg, &seg_rows);
+    conv3x3_ring2_kernel<T, ALT><<<nwg, 512, C::LDS_BYTES, s>>>(p, nseg, seg_rows);
     return (int)hipGetLastError();
 }
 

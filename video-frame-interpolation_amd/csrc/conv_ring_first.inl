@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringfirst_kernel(const FirstPa
     const int frag = wave & 1, cb = wave >> 1;
     const int H = p.Hout, W = p.Wout;
     const size_t plane = (size_t)H * W;
-    const int ntx = (W + C::TWO - 1) / C::TWO, nstrip = ntx * p.B, nitems = nstrip * nseg;
+    const int ntx = (W + C::TWO - 1) / C::TWO, nstrip = ntx * p.B;
     const bool relu = p.epi == EPI_RELU;
 
     // ---- this wave's fragment of both layers' weights
@@ -65,11 +65,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringfirst_kernel(const FirstPa
     }
 
     RING_STAMP_DECL;
+    RingWork work(nstrip, H, nseg, seg_rows);
+    int strip, ys, ye;
 #pragma unroll 1
-    for (int item = (int)blockIdx.x; item < nitems; item += (int)gridDim.x) {
-        const int strip = item % nstrip, seg = item / nstrip;
+    while (work.next(strip, ys, ye)) {
         const int b = strip / ntx, tx = strip - b * ntx;
-        const int ys = seg * seg_rows, ye = min(ys + seg_rows, H);
         const int a0 = ys - 1;                    // first stage-A row; its ring slot is 0
         const int ox0 = tx * C::TWO - 1;          // image column of stage A's column 0; frame-ring column 0 is ox0 - 1
         const float *g1 = fp.f1 + (size_t)b * 3 * plane, *g2 = fp.f2 + (size_t)b * 3 * plane;
@@ -257,8 +257,7 @@ template <typename T> static int launch_conv_ringfirst_t(const FirstParams &fp, 
     if (ncu <= 0) return (int)hipErrorInvalidDevice;
     const int nstrip = ((p.Wout + C::TWO - 1) / C::TWO) * p.B, grid = ((emavfi_switches() & SW_RING_ONE_WG) ? 1 : 2) * ncu;   // (SW_RING_ONE_WG: measurement switch, common.h)
     int nseg, seg_rows;
-    conv_ring_segments(nstrip, p.Hout, grid, &nseg, &seg_rows);
-    const int nitems = nstrip * nseg;
-    conv3x3_ringfirst_kernel<T><<<nitems < grid ? nitems : grid, 256, C::LDS_BYTES, s>>>(fp, p, nseg, seg_rows);
+    const int nwg = conv_ring_work(nstrip, p.Hout, grid, &nseg, &seg_rows);
+    conv3x3_ringfirst_kernel<T><<<nwg, 256, C::LDS_BYTES, s>>>(fp, p, nseg, seg_rows);
     return (int)hipGetLastError();
 }

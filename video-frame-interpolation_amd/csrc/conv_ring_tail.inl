@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvPara
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const unsigned lds0 = (unsigned)(size_t)(lchar_t *)smem;
     const int j = lane & 15, kb = lane >> 4;
-    const int ntx = (p.Wout + C::TWO - 1) / C::TWO, nstrip = ntx * p.B, nitems = nstrip * nseg;
+    const int ntx = (p.Wout + C::TWO - 1) / C::TWO, nstrip = ntx * p.B;
     const char *zeros = (const char *)p.zeros;
     const unsigned pixbytes = (unsigned)p.in_ps * (unsigned)sizeof(T);
     const unsigned rowbytes = (unsigned)p.Win * pixbytes;
@@ -103,11 +103,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvPara
     }
 
     RING_STAMP_DECL;
+    RingWork work(nstrip, p.Hout, nseg, seg_rows);
+    int strip, ys, ye;
 #pragma unroll 1
-    for (int item = (int)blockIdx.x; item < nitems; item += (int)gridDim.x) {
-        const int strip = item % nstrip, seg = item / nstrip;
+    while (work.next(strip, ys, ye)) {
         const int b = strip / ntx, tx = strip - b * ntx;
-        const int ys = seg * seg_rows, ye = min(ys + seg_rows, p.Hout);
         const int a0 = ys - 1, a1 = ye;             // stage-A rows of this item
         const int ox0 = tx * C::TWO - 1, ix0 = ox0 - 1;
         const char *gin = (const char *)p.in + (size_t)b * p.Hin * p.Win * p.in_ps * sizeof(T);
@@ -255,9 +255,8 @@ template <typename T, bool R16, bool TANH> static int launch_conv_ringtail_t(con
     if (ncu <= 0) return (int)hipErrorInvalidDevice;
     const int nstrip = ((p.Wout + C::TWO - 1) / C::TWO) * p.B, grid = ((emavfi_switches() & SW_RING_ONE_WG) ? 1 : 2) * ncu;   // (SW_RING_ONE_WG: measurement switch, common.h)
     int nseg, seg_rows;
-    conv_ring_segments(nstrip, p.Hout, grid, &nseg, &seg_rows);
-    const int nitems = nstrip * nseg;
-    conv3x3_ringtail_kernel<T, R16, TANH><<<nitems < grid ? nitems : grid, 256, C::LDS_BYTES, s>>>(p, nseg, seg_rows);
+    const int nwg = conv_ring_work(nstrip, p.Hout, grid, &nseg, &seg_rows);
+    conv3x3_ringtail_kernel<T, R16, TANH><<<nwg, 256, C::LDS_BYTES, s>>>(p, nseg, seg_rows);
     return (int)hipGetLastError();
 }
 

@@ -43,8 +43,10 @@ void init_switches()
         if (off("EMAVFI_CONV_LIGHT")) v |= SW_NO_CONV_LIGHT;
         if (off("EMAVFI_CONV_RING2")) v |= SW_NO_RING2;
         if (off("EMAVFI_CONV_POOLFUSE")) v |= SW_NO_POOLFUSE;
+        if (off("EMAVFI_RING_CHUNK")) v |= SW_NO_RING_CHUNK;
         if (getenv("EMAVFI_NO_PERSISTENT_CONV") != nullptr) v |= SW_NO_PERSISTENT_CONV;
         if (const char *e = getenv("EMAVFI_RING_ONE_WG"); e && e[0] == '1') v |= SW_RING_ONE_WG;
+        if (const char *e = getenv("EMAVFI_RING_V"); e && e[0] == '1') v |= SW_RING_V;
         g_switches.store(v, std::memory_order_relaxed);
     });
 }
