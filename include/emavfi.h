@@ -251,11 +251,12 @@ int emavfi_reconstruct(const float *fused, const float *const *params, float *ou
                        void *workspace, size_t workspace_bytes, void *stream);
 
 /* Test hook: the A/B switches of the launch sequence (EMAVFI_CONV_FIRST / _FIRSTRING / _HEAD / _TAILFUSE / _LIGHT / _RING2 /
- * _POOLFUSE = 0, EMAVFI_NO_PERSISTENT_CONV) are read from the environment ONCE per process into one word; this replaces it by
+ * _POOLFUSE = 0, EMAVFI_RING_CHUNK = 0, EMAVFI_NO_PERSISTENT_CONV) are read from the environment ONCE per process into one word; this replaces it by
  * (word & and_mask) | or_mask and returns the previous value (bits: 1 no conv_first, 2 no fused first two layers, 4 no fused flow
  * head, 8 no fused reconstruction tail, 16 no planar-head kernel, 32 no persistent conv, 64 no two-layer ring fusions, 128
  * context_encoding.2 stores its output instead of fusing the average pool, 256 (EMAVFI_RING_ONE_WG=1, a measurement switch) the
- * persistent LDS-ring kernels launch one workgroup per CU instead of two).  None of them changes the packed layout.  Not for
+ * persistent LDS-ring kernels launch one workgroup per CU instead of two, 512 (EMAVFI_RING_CHUNK=0) they walk 45-row segments dealt
+ * round-robin instead of one contiguous range of rows per workgroup).  None of them changes the packed layout.  Not for
  * production callers. */
 int emavfi_debug_switches(int and_mask, int or_mask);
 

@@ -726,6 +726,29 @@ def test_fused_flow_head_equals_the_two_launch_path(dtype, shape, switch):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(2, 75, 131), (1, 1, 7), (1, 2, 62), (3, 9, 200), (1, 17, 124), (5, 40, 125), (1, 360, 640), (2, 720, 1280)])
+def test_ring_kernels_row_ranges_equal_their_segments(dtype, shape, switch):
+    """Round 5: a workgroup of a persistent LDS-ring kernel walks ONE contiguous range of the launch's rows (csrc/conv_ring.inl,
+    RingWork: 512 equal ranges over all strips, a range may end one strip and start the next) instead of 45-row segments dealt
+    round-robin (EMAVFI_RING_CHUNK=0).  The decomposition must not be visible: every output row is computed from the same operands in
+    the same order, so the whole forward - all five ring kernels are on its path - is BIT-identical, flow and frame.  Shapes: fewer
+    rows than workgroups (ranges of < 8 rows are merged by the host), ranges that cross strips and samples, one-row images, 720p."""
+    B, H, W = shape
+    sd = synth.synthetic_state_dict(seed=6)
+    f1, f2 = (t.to(DEV) for t in synth.synthetic_frames(37, B, H, W, "natural"))
+    res = []
+    for segments in (False, True):
+        switch(lib.SW_NO_RING_CHUNK, segments)
+        m = make_model(sd, dtype=dtype)
+        with torch.no_grad():
+            out, taps = m(f1, f2, return_taps=True)
+        res.append((out.clone(), taps["flow"].clone()))
+    switch(lib.SW_NO_RING_CHUNK, False)
+    assert torch.isfinite(res[0][0]).all()
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][0], res[1][0])
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("shape", [(2, 75, 131), (1, 1, 7), (1, 2, 62), (1, 3, 63), (1, 17, 124), (3, 40, 125), (1, 360, 640)])
 def test_fused_first_two_layers_equal_the_two_launch_path(dtype, shape, switch):
     """16-bit modes at mid_channels 64 run cat + feat_ext_conv1 + ReLU + conv_block_0 + ReLU as ONE launch: feat_ext_conv1's rows

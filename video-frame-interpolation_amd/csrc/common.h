@@ -289,9 +289,8 @@ enum {
     SW_NO_POOLFUSE = 128,        // EMAVFI_CONV_POOLFUSE=0: context_encoding.2 stores its output and avg_pool_partial reads it back
     SW_RING_ONE_WG = 256,        // EMAVFI_RING_ONE_WG=1 (measurement, round 5): the persistent LDS-ring kernels launch ONE workgroup per CU instead
                                  // of two, leaving half of every CU's LDS to a kernel of another stream (the pipelined forward's pack kernel)
-    SW_NO_RING_CHUNK = 1024,     // EMAVFI_RING_CHUNK=0: the persistent ring kernels walk (strip, 45-row segment) items dealt round-robin instead of
+    SW_NO_RING_CHUNK = 512,      // EMAVFI_RING_CHUNK=0: the persistent ring kernels walk (strip, 45-row segment) items dealt round-robin instead of
                                  // one contiguous range of rows per workgroup (conv_ring.inl, RingWork)
-    SW_RING_V = 512,             // EMAVFI_RING_V=1: conv_ring_v.inl (vertical taps on the accumulators) for the 64 -> 64 / 67 -> 64 layers
 };
 unsigned emavfi_switches();
 

@@ -737,7 +737,6 @@ template <typename T, int CK, int NF, int NB> static int launch_conv_persist16(c
 
 #include "conv_light.inl"
 #include "conv_ring.inl"
-#include "conv_ring_v.inl"
 #include "conv_ring2.inl"
 #include "conv_ring_tail.inl"
 

@@ -442,17 +442,12 @@ template <typename T, bool TAIL, bool HEAD, bool ALT = false> static int launch_
     return (int)hipGetLastError();
 }
 
-template <typename T, bool TAIL, bool ALT> static int launch_conv_ringv_t(const ConvParams &p, hipStream_t s);
 template <typename T> static int launch_conv_ring(const ConvParams &p, hipStream_t s)
 {
     if (p.stride != 1 || p.nchunk != 1 || p.npass != 1 || p.nf != 2 || p.bias_mode > 1 || (p.epi != EPI_NONE && p.epi != EPI_RELU)) return -2;
     if (p.head_w) {   // + a planar head of <= 2 channels computed from the rows in LDS (NSTORE stores per step = its planes)
         if (p.ring != 2 || p.bias_mode != 0 || !p.head_bias || !p.out_planar || p.nplanes < 1 || p.nplanes > 2) return -2;
         return launch_conv_ring_t<T, false, true>(p, s);
-    }
-    if (emavfi_switches() & SW_RING_V) {   // conv_ring_v.inl: the vertical taps on the accumulators
-        if (p.out_alt) return p.ring == 2 ? launch_conv_ringv_t<T, false, true>(p, s) : -2;
-        if (p.ring != 3) return launch_conv_ringv_t<T, false, false>(p, s);
     }
     if (p.out_alt) return p.ring == 2 ? launch_conv_ring_t<T, false, false, true>(p, s) : -2;
     return p.ring == 3 ? launch_conv_ring_t<T, true, false>(p, s) : launch_conv_ring_t<T, false, false>(p, s);

@@ -46,7 +46,6 @@ void init_switches()
         if (off("EMAVFI_RING_CHUNK")) v |= SW_NO_RING_CHUNK;
         if (getenv("EMAVFI_NO_PERSISTENT_CONV") != nullptr) v |= SW_NO_PERSISTENT_CONV;
         if (const char *e = getenv("EMAVFI_RING_ONE_WG"); e && e[0] == '1') v |= SW_RING_ONE_WG;
-        if (const char *e = getenv("EMAVFI_RING_V"); e && e[0] == '1') v |= SW_RING_V;
         g_switches.store(v, std::memory_order_relaxed);
     });
 }

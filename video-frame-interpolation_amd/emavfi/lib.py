@@ -15,7 +15,7 @@ F32, BF16, F16, AMP16 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_TANH01 = 0, 1, 2
 MDCN_IN_F16, MDCN_OUT_F16, MDCN_SPLIT_TAIL = 1, 2, 4
 # emavfi_debug_switches bits (include/emavfi.h)
-SW_NO_CONV_FIRST, SW_NO_FIRSTRING, SW_NO_HEAD, SW_NO_TAILFUSE, SW_NO_CONV_LIGHT, SW_NO_PERSISTENT_CONV, SW_NO_RING2, SW_NO_POOLFUSE, SW_RING_ONE_WG = 1, 2, 4, 8, 16, 32, 64, 128, 256
+SW_NO_CONV_FIRST, SW_NO_FIRSTRING, SW_NO_HEAD, SW_NO_TAILFUSE, SW_NO_CONV_LIGHT, SW_NO_PERSISTENT_CONV, SW_NO_RING2, SW_NO_POOLFUSE, SW_RING_ONE_WG, SW_NO_RING_CHUNK = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 DTYPES = {"fp32": F32, "f32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16,
           "fp16": F16, "f16": F16, "float16": F16, "half": F16,
           # the reference's forward under torch.cuda.amp.autocast(), op policy restated (include/emavfi.h, EMAVFI_AMP16)
