@@ -214,7 +214,17 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
     unsigned xbase[2];
 #pragma unroll
     for (int m = 0; m < 2; ++m) xbase[m] = (unsigned)(((wrow[m] + R) * C::TC + fr_col + R) * C::PSB + h * 16);
-    const unsigned w3lane = (unsigned)(C::W3_OFF + (min(r, 3) * 2 + h) * 16);
+    // The third output fragment (channels 64..66) runs on v_mfma_f32_16x16x32 (round 5: half the matrix-pipe cycles of the 32x32x16 it
+    // replaces, 4 accumulator registers per row instead of 16) on the SAME B register: read as a 16x16x32 operand, lane
+    // L = 32 h + r supplies column j = r & 15, K slice kb = 2 h + (r >> 4) - the two pixel halves of the fragment row sit in
+    // different K slices.  The A operand separates them again: row 4 ph + c holds W[64 + c][slice h] in K slice 2 h + ph and zeros in
+    // the other pixel half's slices, so D[4 ph + c][j] is channel 64 + c of pixel 16 ph + j - lane L < 32 ends with channels
+    // 64..67 of ITS OWN pixel in its four registers.  Same LDS table (rows 0..2 | zero row, two halves), another lane mapping.
+    const int a3i = lane & 15, a3kb = lane >> 4;
+    const bool a3real = (a3i >> 2) < 2 && (a3i & 3) < 3 && (a3kb & 1) == (a3i >> 2);
+    const int a3row = a3real ? (a3i & 3) : 3, a3half = a3kb >> 1;
+    const unsigned w3lane = (unsigned)(C::W3_OFF + (a3row * 2 + a3half) * 16);
+    const int t3lane16 = (a3half * 32 + a3row) * 16;   // the same operand out of a 32x32x16 fragment of the blob (its row 3 is a zero row)
     DEFORM_STAMP(ts_converted);
     __syncthreads();  // hipcc drains the DMA (vmcnt(0)) ahead of the barrier
     DEFORM_STAMP(ts_window);
@@ -297,13 +307,17 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
     f16x8 wq[2][2];  // [kg & 1][n]
 #pragma unroll
     for (int n = 0; n < 2; ++n) wq[0][n] = *reinterpret_cast<const f16x8 *>(wbase_g + n * 1024 + lane16);
-    f32x16 acc[2][3];
+    f32x16 acc[2][2];
+    f32x4 acc3[2];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 2; ++m) {
 #pragma unroll
-        for (int n = 0; n < 3; ++n)
+        for (int n = 0; n < 2; ++n)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[m][n][i] = p.bias[n * 32 + acc_channel(i, h)];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc3[m][e] = lane < 32 ? p.bias[64 + e] : 0.0f;
+    }
     DEFORM_STAMP(ts_offconv);
 
     // ---- sampling geometry of ALL NINE taps up front (fp32, compare-free clamps: NaN -> -2; positions <= -1 or >= size sample
@@ -385,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
         constexpr int j = decltype(jc)::value;
         f16x8 wt[3];
 #pragma unroll
-        for (int n = 0; n < 3; ++n) wt[n] = *reinterpret_cast<const f16x8 *>(wtl + (j * 3 + n) * 1024 + lane16);
+        for (int n = 0; n < 3; ++n) wt[n] = *reinterpret_cast<const f16x8 *>(wtl + (j * 3 + n) * 1024 + (n < 2 ? lane16 : t3lane16));
         unsigned bm[2][4];
 #pragma unroll
         for (int u = 0; u < 2; ++u)
@@ -399,7 +413,8 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
         for (int m = 0; m < 2; ++m) {
             const f16x8 xf = __builtin_bit_cast(f16x8, u32x4_t{bm[m][0], bm[m][1], bm[m][2], bm[m][3]});
 #pragma unroll
-            for (int n = 0; n < 3; ++n) mma_kg(acc[m][n], wt[n], xf);
+            for (int n = 0; n < 2; ++n) mma_kg(acc[m][n], wt[n], xf);
+            mma_k32(acc3[m], wt[2], xf);
         }
     };
     tail_mma(std::integral_constant<int, 0>{}); tail_mma(std::integral_constant<int, 1>{}); tail_mma(std::integral_constant<int, 2>{});
@@ -473,7 +488,7 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
             for (int q = 0; q < 2; ++q) a[q] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d[2][q]), bcast_half<0>(wb), a[q]);
             PACK3_PIN(a);
             // ---- MFMA 2 | blend ops 10..15, then the weight fragments of the next k-group (behind the MFMAs that read wq[(kg+1)&1])
-            if (!(EMAVFI_P3_ABL & 64)) mma_kg(acc[pm][2], w3_prev, xf_prev);   // (ablation bit 6: no third-fragment MFMA in the tap loop - results wrong in channels 64..66 only)
+            if (!(EMAVFI_P3_ABL & 64)) mma_k32(acc3[pm], w3_prev, xf_prev);   // (ablation bit 6: no third-fragment MFMA in the tap loop - results wrong in channels 64..66 only)
 #pragma unroll
             for (int q = 2; q < 4; ++q) a[q] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d[2][q]), bcast_half<0>(wb), a[q]);
 #pragma unroll
@@ -500,7 +515,7 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
     // the last step (k-group 3, row 1) of the last tap
     mma_kg(acc[1][0], wq[1][0], xf_prev);
     mma_kg(acc[1][1], wq[1][1], xf_prev);
-    mma_kg(acc[1][2], w3_prev, xf_prev);
+    mma_k32(acc3[1], w3_prev, xf_prev);
 
     // ---- fix-up: the marked taps' samples that left the window, gathered from global memory with clamped corners and
     // validity-masked weights (the value deform_kernel computes); every other lane takes part with zero weights
@@ -612,7 +627,7 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
                     const f16x8 xf = __builtin_bit_cast(f16x8, u32x4_t{xd[0], xd[1], xd[2], xd[3]});
                     mma_kg(acc[m][0], wfb[kg & 1][0], xf);
                     mma_kg(acc[m][1], wfb[kg & 1][1], xf);
-                    mma_kg(acc[m][2], w3f, xf);
+                    mma_k32(acc3[m], w3f, xf);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -638,13 +653,14 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
                 }
                 f16x8 wt[3];
 #pragma unroll
-                for (int n = 0; n < 3; ++n) wt[n] = *reinterpret_cast<const f16x8 *>(wtl + (j * 3 + n) * 1024 + lane16);
+                for (int n = 0; n < 3; ++n) wt[n] = *reinterpret_cast<const f16x8 *>(wtl + (j * 3 + n) * 1024 + (n < 2 ? lane16 : t3lane16));
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     const u32x4_t bq = u ? u32x4_t{0u, 0u, tm[m][0], tm[m][1]} : u32x4_t{tm[m][0], tm[m][1], 0u, 0u};
                     const f16x8 xf = __builtin_bit_cast(f16x8, bq);
 #pragma unroll
-                    for (int n = 0; n < 3; ++n) mma_kg(acc[m][n], wt[n], xf);
+                    for (int n = 0; n < 2; ++n) mma_kg(acc[m][n], wt[n], xf);
+                    mma_k32(acc3[m], wt[2], xf);
                 }
             }
         }
@@ -656,15 +672,26 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
     for (int m = 0; m < 2; ++m) {
         if (!in_img[m]) continue;
         TS *op = reinterpret_cast<TS *>(p.out) + (((size_t)b * H + py_y[m]) * W + px_x) * p.out_ps;
+        // the third fragment: lanes < 32 hold channels 64..67 of their own pixel; 68..71 have zero weights (their bias alone)
+        auto store_third = [&](auto *o16) {
+            typedef typename std::remove_pointer<decltype(o16)>::type O;
+            typedef __attribute__((ext_vector_type(2))) O pair_t;
+            if (p.cstore > 64 && h == 0) {
+                const pair_t q0 = {(O)acc3[m][0], (O)acc3[m][1]}, q1 = {(O)acc3[m][2], (O)acc3[m][3]};
+                const pair_t q2 = {(O)p.bias[68], (O)p.bias[69]}, q3 = {(O)p.bias[70], (O)p.bias[71]};
+                *reinterpret_cast<uint4 *>(o16 + 64) = make_uint4(__builtin_bit_cast(unsigned, q0), __builtin_bit_cast(unsigned, q1),
+                                                                  __builtin_bit_cast(unsigned, q2), __builtin_bit_cast(unsigned, q3));
+            }
+        };
         if (std::is_same<TS, bf16_t>::value && p.out_f16) {
             half_t *oh = reinterpret_cast<half_t *>(op);
 #pragma unroll
-            for (int n = 0; n < 3; ++n)
-                if (p.cstore - n * 32 > 0) store_frag(oh + n * 32, acc[m][n], h, p.cstore - n * 32, [](float v, int) { return v; });
+            for (int n = 0; n < 2; ++n) store_frag(oh + n * 32, acc[m][n], h, p.cstore - n * 32, [](float v, int) { return v; });
+            store_third(oh);
         } else {
 #pragma unroll
-            for (int n = 0; n < 3; ++n)
-                if (p.cstore - n * 32 > 0) store_frag(op + n * 32, acc[m][n], h, p.cstore - n * 32, [](float v, int) { return v; });
+            for (int n = 0; n < 2; ++n) store_frag(op + n * 32, acc[m][n], h, p.cstore - n * 32, [](float v, int) { return v; });
+            store_third(op);
         }
     }
 #if EMAVFI_DEFORM_STAMPS
