@@ -14,8 +14,8 @@ sys.path.insert(0, os.path.join(ROOT, "video-frame-interpolation_amd"))
 SEGS = {
     "ring": ["W  counted wait + barrier", "I  DMA issue + stores of row y-1", "M  bias + 36 MFMAs (operands 4 ahead)", "E  epilogue (ReLU, round, staging writes)", "-"],
     "tail": ["W  counted wait + barrier", "I  DMA issue + stores of row y-1", "M  bias + 3 tail + 36 MFMAs", "E  epilogue", "-"],
-    "head": ["W  counted wait + barrier", "I+H  DMA issue + head_finish + head_partial", "M  bias + 36 MFMAs", "E  epilogue -> row ring", "H  head_partial alone (16-20 MFMAs 16x16x32)"],
-    "ringtail": ["W  counted wait + barrier", "I  DMA issue", "B  head_row (9 MFMAs, exp/rcp, 3 stores)", "-", "A  stage_a (36 MFMAs 16x16x32, 18 reads, bias / ReLU / round, row-ring write)"],
+    "head": ["W  counted wait + barrier", "I+H  DMA issue + head_row", "M  bias + 36 MFMAs", "E  epilogue -> row ring", "H  head_row alone (6 reads, 6 MFMAs 16x16x32 with the vertical taps on their rows, 1 store)"],
+    "ringtail": ["W  counted wait + barrier", "I  DMA issue", "B  head_row (3 reads, 3 MFMAs with the vertical taps on their rows, exp / rcp, 1 store)", "-", "A  stage_a (36 MFMAs 16x16x32, 18 reads, bias / ReLU / round, row-ring write)"],
     "ringfirst": ["W  barrier", "I  frame loads + stores of row t-3", "A  stage A (5 MFMAs + epilogue -> row ring)", "B  stage B (36 MFMAs + epilogue -> staging)", "P  frame_put"],
 }
 KIND = {"ring": 10, "tail": 11, "head": 12, "ringtail": 14, "ringfirst": 15}
