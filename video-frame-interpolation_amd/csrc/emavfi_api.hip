@@ -380,6 +380,12 @@ int run_conv(const Plan &P, const Layer &L, const void *packed, const void *in, 
         if (sel && kind[0] && strcmp(sel, kind) == 0) c.stamps = debug_stamp_buffer();
     }
 #endif
+#if defined(EMAVFI_DEFORM_STAMPS) && EMAVFI_DEFORM_STAMPS
+    if (const char *rep = getenv("EMAVFI_DEBUG_REPEAT_CONV"))   // diagnostic build: as EMAVFI_DEBUG_REPEAT_PACK, for the plain layers
+        if (!first && !(L.f16_of_bf16 && !L.deform))
+            for (int i = 1; i < atoi(rep); ++i)
+                if (const int rc = P.dtype == EMAVFI_F32 ? launch_conv3x3_f32(c, s) : P.dtype == EMAVFI_F16 ? launch_conv3x3_f16(c, s) : launch_conv3x3_bf16(c, s)) return rc;
+#endif
     if (first) return P.dtype == EMAVFI_F16 ? launch_conv_ringfirst_f16(*first, c, s) : launch_conv_ringfirst_bf16(*first, c, s);
     if (L.f16_of_bf16 && !L.deform) return launch_conv3x3_f16(c, s);   // feat16: f16 activations in, bf16-rounded weights stored as f16
     return P.dtype == EMAVFI_F32 ? launch_conv3x3_f32(c, s) : P.dtype == EMAVFI_F16 ? launch_conv3x3_f16(c, s) : launch_conv3x3_bf16(c, s);
@@ -422,6 +428,13 @@ int run_deform(const Plan &P, const Layer &L, const void *packed, const void *x,
         if ((!sel || (calls % 3) == atoi(sel)) && !getenv("EMAVFI_STAMP_RING")) d.stamps = debug_stamp_buffer();   // (the ring kernels' stamps share the buffer)
         ++calls;
     }
+#endif
+#if defined(EMAVFI_DEFORM_STAMPS) && EMAVFI_DEFORM_STAMPS
+    // diagnostic build: EMAVFI_DEBUG_REPEAT_PACK=n launches the kernel n times back to back (same operands, same result: the input is
+    // not the output) - what the board's power and clock are under THIS kernel alone (tools/power_per_kernel.py)
+    if (const char *rep = getenv("EMAVFI_DEBUG_REPEAT_PACK"))
+        for (int i = 1; i < atoi(rep); ++i)
+            if (const int rc = kd == EMAVFI_F32 ? launch_deform_f32(d, s) : kd == EMAVFI_F16 ? launch_deform_f16(d, s) : launch_deform_bf16(d, s)) return rc;
 #endif
     return kd == EMAVFI_F32 ? launch_deform_f32(d, s) : kd == EMAVFI_F16 ? launch_deform_f16(d, s) : launch_deform_bf16(d, s);
 }
