@@ -27,8 +27,9 @@
 #pragma once
 #include "deform_pack.inl"
 
-// timing-only ablations (wrong results): bit 0 no weight-fragment loads in the tap loop, 1 undeformed (conflict-free) gathers,
-// 2 no blend, 3 no MFMAs in the tap loop, 4 no window DMA, 5 no offset_conv MFMAs
+// timing-only ablations (wrong results; the tap loop's, bits 0-3, 6, 7, leave the offsets alone: every sample stays in the window):
+// bit 0 no weight-fragment loads in the tap loop, 1 undeformed (conflict-free) gathers, 2 no blend beyond its first four multiplies,
+// 3 no 32x32x16 MFMAs in the tap loop, 4 no window DMA, 5 no offset_conv MFMAs, 6 no third-fragment MFMAs, 7 no corner reads
 #ifndef EMAVFI_P3_ABL
 #define EMAVFI_P3_ABL 0
 #endif
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
             const int kg = s >> 1, m = s & 1;
             const int pm = (s + 7) & 1;              // row of the previous step (step 7 of the previous tap for s = 0)
             const int pkg = ((s + 7) & 7) >> 1;      // its k-group: weights still in wq[pkg & 1]
-            if (s + 1 < 8) gather(s + 1, vb[(s + 1) & 1]);
+            if (s + 1 < 8 && !(EMAVFI_P3_ABL & 128)) gather(s + 1, vb[(s + 1) & 1]);
             f16x8 w3n;
             if (m == 0) w3n = __builtin_bit_cast(f16x8, lds_read16(lds_r + w3a + (unsigned)(kg * 128)));
             __builtin_amdgcn_sched_barrier(0);
@@ -475,25 +476,29 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
             const unsigned (&d)[4][4] = vb[s & 1];
             const unsigned wa = w01[m], wb = w23[m];
             // ---- MFMA 0 of the previous step | blend ops 0..4
-            mma_kg(acc[pm][0], wq[pkg & 1][0], xf_prev);
+            if (!(EMAVFI_P3_ABL & 8)) mma_kg(acc[pm][0], wq[pkg & 1][0], xf_prev);
 #pragma unroll
             for (int q = 0; q < 4; ++q) a[q] = __builtin_bit_cast(f16x2_t, d[0][q]) * bcast_half<0>(wa);
-            a[0] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d[1][0]), bcast_half<1>(wa), a[0]);
+            if (!(EMAVFI_P3_ABL & 4)) a[0] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d[1][0]), bcast_half<1>(wa), a[0]);
             PACK3_PIN(a);
             // ---- MFMA 1 | blend ops 5..9
-            mma_kg(acc[pm][1], wq[pkg & 1][1], xf_prev);
+            if (!(EMAVFI_P3_ABL & 8)) mma_kg(acc[pm][1], wq[pkg & 1][1], xf_prev);
+            if (!(EMAVFI_P3_ABL & 4)) {
 #pragma unroll
-            for (int q = 1; q < 4; ++q) a[q] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d[1][q]), bcast_half<1>(wa), a[q]);
+                for (int q = 1; q < 4; ++q) a[q] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d[1][q]), bcast_half<1>(wa), a[q]);
 #pragma unroll
-            for (int q = 0; q < 2; ++q) a[q] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d[2][q]), bcast_half<0>(wb), a[q]);
+                for (int q = 0; q < 2; ++q) a[q] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d[2][q]), bcast_half<0>(wb), a[q]);
+            }
             PACK3_PIN(a);
             // ---- MFMA 2 | blend ops 10..15, then the weight fragments of the next k-group (behind the MFMAs that read wq[(kg+1)&1])
             if (!(EMAVFI_P3_ABL & 64)) mma_k32(acc3[pm], w3_prev, xf_prev);   // (ablation bit 6: no third-fragment MFMA in the tap loop - results wrong in channels 64..66 only)
+            if (!(EMAVFI_P3_ABL & 4)) {
 #pragma unroll
-            for (int q = 2; q < 4; ++q) a[q] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d[2][q]), bcast_half<0>(wb), a[q]);
+                for (int q = 2; q < 4; ++q) a[q] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d[2][q]), bcast_half<0>(wb), a[q]);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) a[q] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d[3][q]), bcast_half<1>(wb), a[q]);
-            if (m == 0) {
+                for (int q = 0; q < 4; ++q) a[q] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d[3][q]), bcast_half<1>(wb), a[q]);
+            }
+            if (m == 0 && !(EMAVFI_P3_ABL & 1)) {
                 if (kg + 1 < 4) {
 #pragma unroll
                     for (int n = 0; n < 2; ++n) wq[(kg + 1) & 1][n] = *reinterpret_cast<const f16x8 *>(wtap + ((kg + 1) * 2 + n) * 1024 + lane16);
@@ -501,8 +506,8 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
 #pragma unroll
                     for (int n = 0; n < 2; ++n) wq[0][n] = *reinterpret_cast<const f16x8 *>(wtap + C::DCN_TAP + n * 1024 + lane16);
                 }
-                w3_cur = w3n;
             }
+            if (m == 0) w3_cur = w3n;
             PACK3_PIN(a);
             xf_prev = f16x8{a[0][0], a[0][1], a[1][0], a[1][1], a[2][0], a[2][1], a[3][0], a[3][1]};
             w3_prev = w3_cur;
