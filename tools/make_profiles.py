@@ -26,7 +26,7 @@ def one(pattern):
     hits = glob.glob(os.path.join(src, pattern))
     if not hits:
         raise SystemExit(f"missing {pattern} under {src}")
-    return hits[0]
+    return max(hits, key=os.path.getmtime)   # (gpurun MERGES a call's files into gpurun_out/: an earlier profile of the same OUT stays beside the new one)
 
 
 shutil.copy(one("stats/*/*_kernel_stats.csv"), os.path.join(prof, f"{tag}_bench_kernel_stats.csv"))

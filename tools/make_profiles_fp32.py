@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, tag = sys.argv[1], sys.argv[2]
 prof = os.path.join(ROOT, "profiles")
 for size, name in (("720", "traffic_fp32_8x720x1280.json"), ("256", "traffic_fp32_16x256x256.json")):
-    one = lambda pat: glob.glob(os.path.join(src, pat))[0]   # noqa: E731
+    one = lambda pat: max(glob.glob(os.path.join(src, pat)), key=os.path.getmtime)   # noqa: E731  (the newest: gpurun merges into gpurun_out/)
     shutil.copy(one(f"stats_{size}/*/*_kernel_stats.csv"), os.path.join(prof, f"{tag}_fp32_{size}_kernel_stats.csv"))
     cmd = [sys.executable, os.path.join(ROOT, "tools", "pmc_to_traffic.py"), one(f"pmc_fetch_{size}/*/*_counter_collection.csv"),
            one(f"pmc_write_{size}/*/*_counter_collection.csv"), prof + os.sep, f"{tag}_fp32_{size}", f"--install-as={name}"]
