@@ -12,8 +12,10 @@
 //     round trips per step and one more step of lag in a kernel whose step is a chain of LDS round trips.  Round 5, after the stamps
 //     of profiles/r05_ring_stamps.txt - 40 % matrix-pipe occupancy at 1.98 GHz, i.e. NOT clock-bound like the rest of the family -
 //     removed the hand-off: the registers were there.)
-//   * stage B (32 -> 3, two steps behind): wave w computes the 16 columns [16 w, 16 w + 16) of the strip's 62, nine MFMAs with the
-//     weights in 36 registers; tanh, (t + 1) / 2, three planar fp32 stores;
+//   * stage B (32 -> 3, one row behind stage A): wave w owns the 16 columns [16 w, 16 w + 16) of the strip's 62.  The head's VERTICAL taps
+//     sit on the rows of the MFMA's A operand (row 4 c + dy = W[c][dy][dx][:]), so THREE MFMAs - one per horizontal tap, 12 weight
+//     registers - add the newest row of the ring to the three output rows it belongs to, and a rotating accumulator hands a finished
+//     row to the epilogue every step (see the kernel); tanh, (t + 1) / 2, ONE planar fp32 store for the three planes;
 //   * both LDS images are UNPADDED and XOR-swizzled for the 16x16x32 operand pattern: the input ring (128-byte pixels, unit u of
 //     pixel c at u ^ swz16(c) - the DMA's lanes fetch the permuted piece) and the row ring (64-byte pixels, unit u at
 //     u ^ (((c >> 2) & 1) << 1)); both conflict-free on paper (tools/lds_swizzle_search.py);
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvPara
                 dma_row(y + C::D, sl, y + C::D <= a1 + 1);
             }
             RING_STAMP(ts2);
-            // the head row two steps behind (its three row-ring rows y - 3 .. y - 1 were written before this step's barrier), then row y
+            // the head consumes row-ring row y - 1 (written before this step's barrier) and finishes head row y - 2; then stage A's row y
             head_row(y - 2, y - 2 >= ys);
             RING_STAMP(ts3);
             RING_STAMP(ts4);
