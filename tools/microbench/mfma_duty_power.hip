@@ -47,6 +47,38 @@ template <int SLEEP, int WAVES, int DATA> __global__ __launch_bounds__(WAVES * 6
     if (threadIdx.x == 0 && blockIdx.x == 0) ticks[0] = t1 - t0;
 }
 
+
+// How many independent accumulation chains does ONE wave need to keep the pipe full?  (the ring kernels afford two)
+template <int CHAINS> __global__ __launch_bounds__(256) void chains(float *sink, int iters)
+{
+    const int lane = threadIdx.x & 63;
+    bf16x8 a, b;
+    for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(0.001f * (float)((lane + e) & 15)); b[e] = (__bf16)(0.002f * (float)((lane * 3 + e) & 15)); }
+    f32x16 acc[CHAINS] = {};
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+        for (int c = 0; c < CHAINS; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[c], 0, 0, 0);
+    float s = 0;
+    for (int c = 0; c < CHAINS; ++c) s += acc[c][0];
+    if (s == 123.456f) sink[0] = s;
+}
+template <int CHAINS> static int run_chains(float *sink)
+{
+    const int wgs = 256, iters = 600000 / CHAINS;
+    chains<CHAINS><<<wgs, 256>>>(sink, 100);
+    CHECK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    CHECK(hipEventRecord(e0));
+    for (int k = 0; k < 8; ++k) chains<CHAINS><<<wgs, 256>>>(sink, iters);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipDeviceSynchronize());
+    float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double tf = 8.0 * wgs * 4 * (double)iters * CHAINS * 32768.0 / (ms * 1e-3) / 1e12;
+    printf("one wave per SIMD, %d accumulation chain(s), constant data: %8.1f TFLOP/s = %5.1f %% of 2.5 PFLOP/s\n", CHAINS, tf, tf / 25.0);
+    return 0;
+}
+
 static std::string smi()
 {
     std::string out;
@@ -94,6 +126,7 @@ int main()
 {
     float *sink; unsigned long long *ticks;
     CHECK(hipMalloc(&sink, 64)); CHECK(hipMalloc(&ticks, 64));
+    if (run_chains<1>(sink) || run_chains<2>(sink) || run_chains<3>(sink) || run_chains<4>(sink)) return 1;
     if (run<0, 4, 0>(sink, ticks)) return 1;
     if (run<2, 4, 0>(sink, ticks)) return 1;
     if (run<4, 4, 0>(sink, ticks)) return 1;
