@@ -499,6 +499,11 @@ def add_sustained_clock(obj, sclk_mhz, peak_mhz=2400.0):
     if isinstance(obj, dict):
         if obj.get("bound") == "mfma" and isinstance(obj.get("frac"), float):
             obj["frac_at_sustained_clock"] = round(obj["frac"] * peak_mhz / sclk_mhz, 4)
+            # against what this board's matrix pipe was MEASURED to deliver at its 1 400 W cap with convolution-like operands (a bare
+            # v_mfma_f32_32x32x16_bf16 loop: 1 855 TFLOP/s at 1.90 GHz; with constant operands the same loop reaches 94-97 % of the
+            # 2.5 PFLOP/s peak: the MFMA's energy is in its data - tools/microbench/mfma_duty_power.hip, profiles/r05_mfma_duty_power.txt)
+            if obj.get("unit") == "TFLOP/s" and obj.get("peak") == PEAK["bf16"] and isinstance(obj.get("achieved"), float):
+                obj["frac_of_measured_bf16_matrix_ceiling_1855_tflops"] = round(obj["achieved"] / 1855.0, 4)
         if "frac_of_mfma_peak" in obj:
             obj["frac_of_mfma_peak_at_sustained_clock"] = round(obj["frac_of_mfma_peak"] * peak_mhz / sclk_mhz, 4)
         for v in obj.values():
