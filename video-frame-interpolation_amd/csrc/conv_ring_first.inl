@@ -141,52 +141,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringfirst_kernel(const FirstPa
             frame_load(t + 3, fnew);
             store_row(t - 3, t - 3 >= ys);
             RING_STAMP(ts2);
+            // Round 5 (the duty-cycle law of DESIGN.md section 4.2): the step used to run stage A (operand reads -> five dependent MFMAs ->
+            // epilogue) and then stage B, each a serial chain of its own.  Now B contracts first, A's five MFMAs queue behind B's last ones
+            // (its first operands are read under them), B's epilogue runs while A's chain is in the pipe, A's epilogue last.  Same
+            // arithmetic in the same order per stage: still bit-identical to the two launches.
 #if defined(EMAVFI_RF_ABL) && (EMAVFI_RF_ABL & 2)   // timing-only: no stage A
-            if (t <= ye && t == -12345) {
+            const bool doA = t <= ye && t == -12345;
 #else
-            if (t <= ye) {
+            const bool doA = t <= ye;
 #endif
-                // ---- stage A: row t of feat_ext_conv1 (conv_first_kernel's arithmetic)
-                f32x16 acc;
-                {
-                    const f32x4 *lb = reinterpret_cast<const f32x4 *>(smem + C::BIAS_OFF + (frag * 32 + 4 * h) * 4);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 v = lb[2 * g];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[4 * g + e] = v[e];
-                    }
-                }
-                vec x[5], wa[5];
-#pragma unroll
-                for (int kg = 0; kg < 5; ++kg) {
-                    x[kg] = *reinterpret_cast<const vec *>(smem + C::FR_OFF + ((t - a0 + ady[kg]) & 3) * C::FROW + (cb * 32 + r + adx[kg]) * 16);
-                    wa[kg] = *reinterpret_cast<const vec *>(smem + C::WA_OFF + (kg * 2 + frag) * 1024 + lane * 16);
-                }
-#pragma unroll
-                for (int kg = 0; kg < 5; ++kg) mma_kg(acc, wa[kg], x[kg]);
-                const bool inside = (unsigned)t < (unsigned)H && (unsigned)xg < (unsigned)W;
-                const unsigned keep = inside ? ~0u : 0u;
-                lchar_t *mid = (lchar_t *)smem + C::MID_OFF + ((t - a0) & 3) * C::MID + (cb * 32 + r) * C::PSTR + frag * 64;
-#pragma unroll
-                for (int g = 0; g < 4; g += 2) {
-                    unsigned a[2], c[2];
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const float v0 = fmaxf(acc[4 * g + 2 * q], 0.0f), v1 = fmaxf(acc[4 * g + 2 * q + 1], 0.0f);
-                        const float u0 = fmaxf(acc[4 * (g + 1) + 2 * q], 0.0f), u1 = fmaxf(acc[4 * (g + 1) + 2 * q + 1], 0.0f);
-                        const pair_t pa = {(T)v0, (T)v1}, pb = {(T)u0, (T)u1};
-                        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, pa) & keep, __builtin_bit_cast(unsigned, pb) & keep, false, false);
-                        a[q] = sw[0]; c[q] = sw[1];
-                    }
-                    *reinterpret_cast<__attribute__((address_space(3))) u4_t *>(mid + 16 * (g + h)) = u4_t{a[0], a[1], c[0], c[1]};
-                }
-            }
-            RING_STAMP(ts3);
             const int yb = t - 2;
-            if (yb >= ys) {
+            const bool doB = yb >= ys;
+            f32x16 acc[2];
+            if (doB) {
                 // ---- stage B: row yb of conv_block_0 from stage-A rows yb - 1 .. yb + 1 (conv3x3_ring_kernel's main loop)
-                f32x16 acc[2];
                 {
                     const f32x4 *lb = reinterpret_cast<const f32x4 *>(smem + C::BIAS_OFF + 256 + (frag * 32 + 4 * h) * 4);
 #pragma unroll
@@ -217,6 +185,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringfirst_kernel(const FirstPa
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+            }
+            RING_STAMP(ts3);
+            f32x16 acca;
+            if (doA) {
+                // ---- stage A: row t of feat_ext_conv1 (conv_first_kernel's arithmetic), its contraction
+                {
+                    const f32x4 *lb = reinterpret_cast<const f32x4 *>(smem + C::BIAS_OFF + (frag * 32 + 4 * h) * 4);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 v = lb[2 * g];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acca[4 * g + e] = v[e];
+                    }
+                }
+                vec x[5], wa[5];
+#pragma unroll
+                for (int kg = 0; kg < 5; ++kg) {
+                    x[kg] = *reinterpret_cast<const vec *>(smem + C::FR_OFF + ((t - a0 + ady[kg]) & 3) * C::FROW + (cb * 32 + r + adx[kg]) * 16);
+                    wa[kg] = *reinterpret_cast<const vec *>(smem + C::WA_OFF + (kg * 2 + frag) * 1024 + lane * 16);
+                }
+#pragma unroll
+                for (int kg = 0; kg < 5; ++kg) mma_kg(acca, wa[kg], x[kg]);
+            }
+            if (doB) {   // stage B's epilogue (VALU + two LDS writes) while stage A's chain is in the matrix pipe
                 lchar_t *stg = (lchar_t *)smem + C::STG_OFF + (yb & 1) * C::STG + (cb * 32 + r) * C::PSTR + frag * 64;
 #pragma unroll
                 for (int g = 0; g < 4; g += 2) {
@@ -231,6 +223,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringfirst_kernel(const FirstPa
                         a[q] = sw[0]; c[q] = sw[1];
                     }
                     *reinterpret_cast<__attribute__((address_space(3))) u4_t *>(stg + 16 * (g + h)) = u4_t{a[0], a[1], c[0], c[1]};
+                }
+            }
+            if (doA) {   // stage A's epilogue: ReLU, rounded to T, ZERO outside the image, into the row ring
+                const bool inside = (unsigned)t < (unsigned)H && (unsigned)xg < (unsigned)W;
+                const unsigned keep = inside ? ~0u : 0u;
+                lchar_t *mid = (lchar_t *)smem + C::MID_OFF + ((t - a0) & 3) * C::MID + (cb * 32 + r) * C::PSTR + frag * 64;
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    unsigned a[2], c[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const float v0 = fmaxf(acca[4 * g + 2 * q], 0.0f), v1 = fmaxf(acca[4 * g + 2 * q + 1], 0.0f);
+                        const float u0 = fmaxf(acca[4 * (g + 1) + 2 * q], 0.0f), u1 = fmaxf(acca[4 * (g + 1) + 2 * q + 1], 0.0f);
+                        const pair_t pa = {(T)v0, (T)v1}, pb = {(T)u0, (T)u1};
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, pa) & keep, __builtin_bit_cast(unsigned, pb) & keep, false, false);
+                        a[q] = sw[0]; c[q] = sw[1];
+                    }
+                    *reinterpret_cast<__attribute__((address_space(3))) u4_t *>(mid + 16 * (g + h)) = u4_t{a[0], a[1], c[0], c[1]};
                 }
             }
             RING_STAMP(ts4);
