@@ -190,7 +190,7 @@ def test_ring_kernels_issue_a_fixed_number_of_vmem_instructions_per_step(tmp_pat
     """csrc/conv_ring.inl retires its LDS-DMA ring with a COUNTED `s_waitcnt vmcnt(N)`: N is only right while every wave issues
     exactly 3 DMA + 2 store instructions per row step and nothing else that counts.  hipcc is free to
     break that silently (a branch over an all-inactive store, a spill, a hoisted load), so the shipped code objects are checked:
-    between the counted wait and the drain behind the row loop there are three global_load_lds, three buffer stores (the fused head
+    in the row loop (the innermost loop around the counted wait) there are three global_load_lds, three buffer stores (the fused head
     kernel and the fused reconstruction tail: one) and no other vector-memory instruction, and N is stores + (3 + stores) (D - 2) (D = 3; the
     fused head kernel: D = 2)."""
     import re
@@ -204,10 +204,14 @@ def test_ring_kernels_issue_a_fixed_number_of_vmem_instructions_per_step(tmp_pat
                     and "s_barrier" in " ".join(lines[i:i + 4])]
             assert len(tops) == 1, (name, "one counted wait (the row loop's) expected", len(tops))
             n = int(re.search(r"vmcnt\((\d+)\)", lines[tops[0]]).group(1))
-            # the loop body runs from the counted wait to the drain behind the loop, or to the end of the function where hipcc
-            # laid the exit block out in front of the loop
-            drain = next((i for i in range(tops[0] + 1, len(lines)) if re.search(r"s_waitcnt vmcnt\(0\)\s*$", lines[i].split("//")[0].rstrip())), len(lines))
-            region = "\n".join(lines[tops[0]:drain])
+            # the row loop = the innermost loop (backward branch) around the counted wait.  (Until round 5 this test read the text from
+            # the wait to the drain behind the loop; hipcc rotates the loop when the step ENDS with a store - the fused head kernel's
+            # head_out - and lays that store out in front of the wait.)
+            ins, loops = _loops_of(body)
+            wait_addr = next(a for a, t in ins if t.startswith(lines[tops[0]].split("//")[0].strip()) and
+                             any(t2 == "s_barrier" for _, t2 in ins[[x[0] for x in ins].index(a) + 1:[x[0] for x in ins].index(a) + 4]))
+            row = min((l for l in loops if l[0] <= wait_addr <= l[1]), key=lambda l: l[1] - l[0])
+            region = "\n".join(t for a, t in ins if row[0] <= a <= row[1])
             dma = len(re.findall(r"global_load_lds_dwordx4", region))
             stores = len(re.findall(r"buffer_store_dword", region))
             other = len(re.findall(r"\b(?:global_load_dword|global_store|buffer_load|flat_load|flat_store|scratch_)", region))

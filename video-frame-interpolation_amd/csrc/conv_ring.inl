@@ -268,7 +268,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
         // finished by it.  hacc: register dy = the pending sums of head row rho + 1 - dy (rows below ys are never stored: whatever the
         // registers and the ring hold when an item starts only reaches those)
         f32x4 hacc = {0.0f, 0.0f, 0.0f, 0.0f};
-        auto head_row = [&](int yb, bool real) {
+        // (two halves: in the row loop the six MFMAs queue behind the main contraction's and the main epilogue runs in their shadow)
+        auto head_mma = [&](int yb) {
             if constexpr (HEAD) {
                 const lchar_t *mr = (const lchar_t *)smem + C::STG_OFF + ((yb + 1 - a0) & 1) * C::STG;
                 vec hxv[6];
@@ -277,6 +278,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
                 hacc = f32x4{0.0f, hacc[0], hacc[1], 0.0f};
 #pragma unroll
                 for (int q = 0; q < 6; ++q) mma_k32(hacc, hwr[q], hxv[q]);
+            }
+        };
+        auto head_out = [&](int yb, bool real) {
+            if constexpr (HEAD) {
                 float o = hacc[2] + hb;
                 if (p.round16) o = (float)(half_t)o;
                 float *orow = p.out_planar + (size_t)b * p.nplanes * p.Hout * p.Wout + (size_t)(real ? yb : ys) * p.Wout;
@@ -307,12 +312,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
                 int sl = s0 + C::D + 1; sl = sl >= C::RING ? sl - C::RING : sl;
                 dma_row(y + C::D, sl, y + C::D <= a1 + 1);
             }
-            if constexpr (HEAD) {
-                RING_STAMP(ts1b);
-                head_row(y - 2, y - 2 >= ys && !(EMAVFI_RING_ABL & 2));
-                RING_STAMP_ADD(4, ts1b, ring_stamp());
-            } else
-                store_row(y - 1, y > a0 && !(EMAVFI_RING_ABL & 2));
+            if constexpr (!HEAD) store_row(y - 1, y > a0 && !(EMAVFI_RING_ABL & 2));   // (HEAD: the head stage follows the main contraction - head_mma / head_out below)
             RING_STAMP(ts2);
             f32x16 acc[2];
             {
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
             }
             {
                 // operands EMAVFI_RING_AHEAD k-groups ahead of their MFMAs: one wave's read -> MFMA chain must not expose the LDS latency
-                constexpr int AH = TAIL ? EMAVFI_RING_AHEAD - 1 : EMAVFI_RING_AHEAD;   // (TAIL: 12 more weight registers)
+                constexpr int AH = (TAIL || HEAD) ? EMAVFI_RING_AHEAD - 1 : EMAVFI_RING_AHEAD;   // (TAIL: 12 more weight registers; HEAD: 24 + the head stage behind the loop)
                 const char *xb[3];
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
@@ -373,6 +373,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
                 }
             }
             RING_STAMP(ts3);
+            if constexpr (HEAD) head_mma(y - 2);   // the 64 -> 64 row of the step before enters the head: six MFMAs behind the 36
             // ---- optional ReLU; this wave's 32 channels of its 32 pixels into the row's staging buffer (HEAD: the ring of 64 -> 64
             // rows, zero outside the image: they are the head convolution's padding)
             {
@@ -397,6 +398,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
                     *reinterpret_cast<__attribute__((address_space(3))) u4_t *>(stg + 16 * ((frag * 4 + g + h) ^ usw)) = u4_t{a[0], a[1], c[0], c[1]};
                 }
             }
+            if constexpr (HEAD) head_out(y - 2, y - 2 >= ys && !(EMAVFI_RING_ABL & 2));
             s0 = s0 + 1 >= C::RING ? 0 : s0 + 1;
             RING_STAMP(ts4);
             RING_STAMP_ADD(0, ts0, ts1); RING_STAMP_ADD(1, ts1, ts2); RING_STAMP_ADD(2, ts2, ts3); RING_STAMP_ADD(3, ts3, ts4);
@@ -405,7 +407,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the next item primes the same slots)
         __syncthreads();
         if constexpr (HEAD) {
-            head_row(a1 - 1, true);   // (a1 = ye: the segment's last head row, from the 64 -> 64 rows ye - 2 .. ye)
+            head_mma(a1 - 1);         // (a1 = ye: the segment's last head row, from the 64 -> 64 rows ye - 2 .. ye)
+            head_out(a1 - 1, true);
             __syncthreads();          // the next item's first rows overwrite the ring of 64 -> 64 rows
         } else
             store_row(a1, true);
