@@ -135,10 +135,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvPara
         const size_t plane = (size_t)p.Hout * p.Wout;
         // stage A: row y of the 64 -> 32 layer for this wave's 16 columns, all 32 channels: 18 operand reads, 36 MFMAs, then bias, ReLU,
         // rounding and the row-ring write (zero outside the image: the rows are the head convolution's padding)
-        auto stage_a = [&](int y, int s0) {
-            f32x4 acc[2];
+        // (round 5, end: FOUR accumulation chains - even and odd steps of either channel block - instead of two: a lone wave's two chains of
+        // 16-cycle MFMAs left the pipe idle more than half of the contraction; and the step's order is contraction A, the head's three
+        // MFMAs queued behind it, A's epilogue, the head's epilogue)
+        f32x4 acc[2][2];
+        auto stage_a_mma = [&](int s0) {
 #pragma unroll
-            for (int blk = 0; blk < 2; ++blk) acc[blk] = f32x4{ba[blk][0], ba[blk][1], ba[blk][2], ba[blk][3]};
+            for (int blk = 0; blk < 2; ++blk) { acc[blk][0] = f32x4{ba[blk][0], ba[blk][1], ba[blk][2], ba[blk][3]}; acc[blk][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
             // LDS byte offsets, not pointers: a row-base array indexed by a run-time dy loses its address space and the reads become
             // flat_load (vmcnt AND lgkmcnt: the counted wait would be wrong - tests/test_cabi_cpu.py checks the code object)
             int xs[3];
@@ -160,11 +163,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvPara
             for (int q = 0; q < 18; ++q) {
                 if (q + AH < 18) xq[(q + AH) % (AH + 1)] = xread(q + AH);
                 if (!(EMAVFI_RT_ABL & 4) || q == 0) {
-                    mma_k32(acc[0], wr[q][0], xq[q % (AH + 1)]);
-                    mma_k32(acc[1], wr[q][1], xq[q % (AH + 1)]);
+                    mma_k32(acc[0][q & 1], wr[q][0], xq[q % (AH + 1)]);
+                    mma_k32(acc[1][q & 1], wr[q][1], xq[q % (AH + 1)]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        };
+        auto stage_a_out = [&](int y) {
             const int c = wave * 16 + j;
             const bool inside = (unsigned)y < (unsigned)p.Hout && (unsigned)(ox0 + c) < (unsigned)p.Wout;
             const unsigned keepm = inside ? ~0u : 0u;
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvPara
             for (int blk = 0; blk < 2; ++blk) {
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = p.epi == EPI_RELU ? fmaxf(acc[blk][e], 0.0f) : acc[blk][e];
+                for (int e = 0; e < 4; ++e) { const float sum = acc[blk][0][e] + acc[blk][1][e]; v[e] = p.epi == EPI_RELU ? fmaxf(sum, 0.0f) : sum; }
                 typedef __attribute__((ext_vector_type(2))) T pair_t;
                 const pair_t lo = {(T)v[0], (T)v[1]}, hi = {(T)v[2], (T)v[3]};
                 // channels 16 blk + 4 kb .. + 3 = bytes 32 blk + 8 kb of the 64-byte pixel: unit 2 blk + (kb >> 1), half kb & 1
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvPara
         // stage B: the row ring's row rho (written in the step before) enters the head; head row rho - 1 = yb is finished by it.
         // NSTORE = 1 store (lane (j, kb): plane kb)
         f32x4 hacc = {0.0f, 0.0f, 0.0f, 0.0f};   // per item: register dy = the pending sums of output row (newest row consumed) + 1 - dy
-        auto head_row = [&](int yb, bool real) {
+        auto head_mma = [&](int yb) {
             const int mr = C::MID_OFF + ((yb + 1 - a0) & 3) * C::MID;
             vec hxv[3];
 #pragma unroll
@@ -191,6 +196,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvPara
             hacc = f32x4{0.0f, hacc[0], hacc[1], 0.0f};
 #pragma unroll
             for (int dx = 0; dx < ((EMAVFI_RT_ABL & 2) ? 1 : 3); ++dx) mma_k32(hacc, hw[dx], hxv[dx]);
+        };
+        auto head_out = [&](int yb, bool real) {
             float o = hacc[2] + hb;
             float *orow = p.out_planar + (size_t)b * p.nplanes * plane + (size_t)(real ? yb : ys) * p.Wout;
             if constexpr (TANH) {   // ema_vfi.py:106,146 (round16: every op rounds as an fp16 tensor op does under autocast)
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvPara
 #pragma unroll 1
         for (int k = 0; k <= C::D; ++k) {
             dma_row(a0 - 1 + k, k, a0 - 1 + k <= a1 + 1);
-            // (the store of the steady-state pattern, dropped: a buffer of zero records.  NOT head_row: its accumulator carries state)
+            // (the store of the steady-state pattern, dropped: a buffer of zero records.  NOT head_mma: its accumulator carries state)
             const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(p.out_planar, 0, 0, 0x00020000);
             __builtin_amdgcn_raw_buffer_store_b32(0u, rs0, soff, 0, 0);
         }
@@ -230,11 +237,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvPara
                 dma_row(y + C::D, sl, y + C::D <= a1 + 1);
             }
             RING_STAMP(ts2);
-            // the head consumes row-ring row y - 1 (written before this step's barrier) and finishes head row y - 2; then stage A's row y
-            head_row(y - 2, y - 2 >= ys);
+            // stage A's row y; behind its contraction the head consumes row-ring row y - 1 (written before this step's barrier) and finishes
+            // head row y - 2
+            stage_a_mma(s0);
             RING_STAMP(ts3);
+            head_mma(y - 2);
+            stage_a_out(y);
             RING_STAMP(ts4);
-            stage_a(y, s0);
+            head_out(y - 2, y - 2 >= ys);
             s0 = s0 + 1 >= C::RING ? 0 : s0 + 1;
             RING_STAMP(ts5);
             RING_STAMP_ADD(0, ts0, ts1); RING_STAMP_ADD(1, ts1, ts2); RING_STAMP_ADD(2, ts2, ts3); RING_STAMP_ADD(3, ts3, ts4); RING_STAMP_ADD(4, ts4, ts5);
@@ -242,7 +252,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ringtail_kernel(const ConvPara
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        head_row(a1 - 1, true);   // (a1 = ye: the segment's last head row, from the rows ye - 2 .. ye)
+        head_mma(a1 - 1);         // (a1 = ye: the segment's last head row, from the rows ye - 2 .. ye)
+        head_out(a1 - 1, true);
         __syncthreads();          // the next item's first rows overwrite the rings
     }
     RING_STAMP_WRITE(p, 14, 4);
