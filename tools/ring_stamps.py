@@ -14,9 +14,9 @@ sys.path.insert(0, os.path.join(ROOT, "video-frame-interpolation_amd"))
 SEGS = {
     "ring": ["W  counted wait + barrier", "I  DMA issue + stores of row y-1", "M  bias + 36 MFMAs (operands 4 ahead)", "E  epilogue (ReLU, round, staging writes)", "-"],
     "tail": ["W  counted wait + barrier", "I  DMA issue + stores of row y-1", "M  bias + 3 tail + 36 MFMAs", "E  epilogue", "-"],
-    "head": ["W  counted wait + barrier", "I+H  DMA issue + head_row", "M  bias + 36 MFMAs", "E  epilogue -> row ring", "H  head_row alone (6 reads, 6 MFMAs 16x16x32 with the vertical taps on their rows, 1 store)"],
-    "ringtail": ["W  counted wait + barrier", "I  DMA issue", "B  head_row (3 reads, 3 MFMAs with the vertical taps on their rows, exp / rcp, 1 store)", "-", "A  stage_a (36 MFMAs 16x16x32, 18 reads, bias / ReLU / round, row-ring write)"],
-    "ringfirst": ["W  barrier", "I  frame loads + stores of row t-3", "A  stage A (5 MFMAs + epilogue -> row ring)", "B  stage B (36 MFMAs + epilogue -> staging)", "P  frame_put"],
+    "head": ["W  counted wait + barrier", "I  DMA issue", "M  bias + 36 MFMAs", "H+E  head's 6 reads + 6 MFMAs behind the contraction, main epilogue -> row ring in their shadow, head epilogue + store", "-"],
+    "ringtail": ["W  counted wait + barrier", "I  DMA issue", "A  stage A's contraction (36 MFMAs 16x16x32 on four chains, 18 reads)", "H+E  head's 3 reads + 3 MFMAs behind it, stage A's epilogue -> row ring", "O  head epilogue (exp / rcp) + store"],
+    "ringfirst": ["W  barrier", "I  frame loads + stores of row t-3", "B  stage B's contraction (36 MFMAs)", "A+E  stage A's 5 MFMAs behind it, B's epilogue in their shadow, A's epilogue -> row ring", "P  frame_put"],
 }
 KIND = {"ring": 10, "tail": 11, "head": 12, "ringtail": 14, "ringfirst": 15}
 
