@@ -329,26 +329,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[1][i] = 0.0f;
             const char *xl = ring + (cb * 32 + r) * C::PSTR + h * 16;
-            if (TAIL) {
-                const char *tl = ring + (cb * 32 + r) * C::PSTR + 128;
-                int toff[6];
+            // TAIL: the three im2col MFMAs (round 5, end) no longer open the step behind their own exposed reads - the reads go out inside
+            // the main loop's last iterations, where the operand queue has free registers, and the MFMAs queue behind the 36
+            const char *tl = ring + (cb * 32 + r) * C::PSTR + 128;
+            int toff[TAIL ? 6 : 1];
+            if constexpr (TAIL) {
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
                     int sl = s0 + tdy[k]; sl = sl >= C::RING ? sl - C::RING : sl;
                     toff[k] = sl * C::ROWB + tdx[k] * C::PSTR;
                 }
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    u2_t lo = *reinterpret_cast<const u2_t *>(tl + toff[2 * j]);
-                    u2_t hi = *reinterpret_cast<const u2_t *>(tl + toff[2 * j + 1]);
-                    if (j == 2) {   // tap slots 9..11 do not exist: zero operand (their weights are zero, but 0 x Inf is not)
-                        const unsigned keep0 = h ? 0u : ~0u;
-                        lo[0] &= keep0; lo[1] &= keep0; hi[0] = 0u; hi[1] = 0u;
-                    }
-                    const u4_t xv = {lo[0], lo[1], hi[0], hi[1]};
-                    mma_kg(acc[j & 1], wt[j], __builtin_bit_cast(vec, xv));
-                }
             }
+            vec tq[TAIL ? 3 : 1];
             {
                 // operands EMAVFI_RING_AHEAD k-groups ahead of their MFMAs: one wave's read -> MFMA chain must not expose the LDS latency
                 constexpr int AH = (TAIL || HEAD) ? EMAVFI_RING_AHEAD - 1 : EMAVFI_RING_AHEAD;   // (TAIL: 12 more weight registers; HEAD: 24 + the head stage behind the loop)
@@ -368,8 +360,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(const ConvParams p
                         const int n = s + AH;
                         xq[n % (AH + 1)] = *reinterpret_cast<const vec *>(xb[n / 12] + ((n / 4) % 3) * C::PSTR + (n & 3) * 32);
                     }
+                    if constexpr (TAIL) {
+                        if (s >= 33) {   // one im2col operand per iteration 33, 34, 35 (two 8-byte reads each)
+                            const int j = s - 33;
+                            u2_t lo = *reinterpret_cast<const u2_t *>(tl + toff[2 * j]);
+                            u2_t hi = *reinterpret_cast<const u2_t *>(tl + toff[2 * j + 1]);
+                            if (j == 2) {   // tap slots 9..11 do not exist: zero operand (their weights are zero, but 0 x Inf is not)
+                                const unsigned keep0 = h ? 0u : ~0u;
+                                lo[0] &= keep0; lo[1] &= keep0; hi[0] = 0u; hi[1] = 0u;
+                            }
+                            tq[j] = __builtin_bit_cast(vec, u4_t{lo[0], lo[1], hi[0], hi[1]});
+                        }
+                    }
                     mma_kg(acc[s & 1], wf[s >> 2][s & 3], xq[s % (AH + 1)]);
                     __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks every read to just above its MFMA)
+                }
+                if constexpr (TAIL) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) mma_kg(acc[j & 1], wt[j], tq[j]);
                 }
             }
             RING_STAMP(ts3);
