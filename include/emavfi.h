@@ -62,7 +62,7 @@
 extern "C" {
 #endif
 
-#define EMAVFI_VERSION 402 /* 0.4.2: emavfi_forward_staged, emavfi_mdcn_profiled (round 5; the packed layout is 0.4.1's, but a blob says which library packed it: re-pack); 0.4.1: context_encoding.1 / .2 re-packed for conv_wreg.inl; 0.4.0: the packed blob starts with a 256-byte self-describing header, emavfi_forward takes packed_bytes (round 4): re-pack */
+#define EMAVFI_VERSION 403 /* 0.4.3: emavfi_forward_census, emavfi_mdcn_census (round 6; the workspace grows by 8 KiB, the packed layout is unchanged); 0.4.2: emavfi_forward_staged, emavfi_mdcn_profiled (round 5; the packed layout is 0.4.1's, but a blob says which library packed it: re-pack); 0.4.1: context_encoding.1 / .2 re-packed for conv_wreg.inl; 0.4.0: the packed blob starts with a 256-byte self-describing header, emavfi_forward takes packed_bytes (round 4): re-pack */
 
 #define EMAVFI_F32 0
 #define EMAVFI_BF16 1
@@ -234,6 +234,20 @@ int emavfi_mdcn(const float *x, const float *offset_weight, const float *offset_
 int emavfi_mdcn_profiled(const float *x, const float *offset_weight, const float *offset_bias, const float *dcn_weight, const float *dcn_bias,
                          float *y, int B, int C, int H, int W, int dtype, int flags, void *workspace, size_t workspace_bytes,
                          void *const *events, int n_events, void *stream);
+
+/* Census of the one-launch ModulatedDeformConvPack kernel (measurement hook; the reference bounds its offsets nowhere, ema_vfi.py:55-60,
+ * and the kernel stages a window that holds offsets up to +-2 px beyond the tap: samples that leave it take a fix-up pass).  The kernel
+ * counts, while it runs: the (wave, tap) groups - 4 rows x 16 pixels x one tap - that took the fix-up, the samples outside the window and
+ * the largest |offset| it computed.  emavfi_forward_census reads the counters the LAST emavfi_forward* call on `workspace` left there
+ * (same model, B, H, W, dtype; enqueue it on the same stream), emavfi_mdcn_census those of the last emavfi_mdcn* call:
+ *   out[block][4] (unsigned 64-bit, DEVICE memory, num_blocks rows - one row for mdcn) =
+ *     {fix-up wave-taps, all wave-taps (0: this block did not run the one-launch kernel, nothing was counted), samples outside the
+ *      window (of B*H*W*9), max |offset| in px as fp32 bits}.
+ * One tiny launch; nothing is synchronised. */
+int emavfi_forward_census(int in_channels, int mid_channels, int num_blocks, int B, int H, int W, int dtype,
+                          const void *workspace, size_t workspace_bytes, unsigned long long *out, void *stream);
+int emavfi_mdcn_census(int B, int C, int H, int W, int dtype, int flags, const void *workspace, size_t workspace_bytes,
+                       unsigned long long *out, void *stream);
 
 /* context_encoding(feat) -> ctx, ema_vfi.py:79-86 (called at :120): conv stride 2 + ReLU, conv stride 2 + ReLU, conv + ReLU,
  * AdaptiveAvgPool2d(1), Flatten, Linear.  feat [B,mid,H,W]; params = 8 device pointers in the Sequential's registration order:

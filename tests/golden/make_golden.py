@@ -226,15 +226,16 @@ def large_odd():
     np.savez_compressed(os.path.join(OUT, "large_odd.npz"), **arrays)
 
 
-def large_offsets():
+def large_offsets(recipe=(3.0, 3.0), fname="large_offsets.npz", tag="off", seed=6):
     """mid_channels 64 with LARGE deformable offsets (round 5): synthetic_state_dict(offset_std = 3, offset_bias = 3) makes the three
     packs' offsets span about +-8 px (the benchmark's recipe: +-2), so that most (wave, tap) groups of the HIP pack kernels leave their
-    staged window (R = 2) and take the fix-up loop - which round 5 rewrote.  B = 1, 120 x 200 (7.5 x 12.5 tiles of 16 x 16), natural
-    input; samples of every stage of the reference's forward, and the offsets' quantiles for the record."""
+    staged window (R = 2) and take the fix-up pass.  B = 1, 120 x 200 (7.5 x 12.5 tiles of 16 x 16), natural
+    input; samples of every stage of the reference's forward, and the offsets' quantiles for the record.
+    Round 6 ("offsets16": recipe (6, 6), large_offsets16.npz): offsets spanning about +-16 px - nearly every (wave, tap) group is outside,
+    several arena rounds per wave in the rebuilt fix-up (deform_pack3.inl)."""
     arrays = {}
-    recipe = (3.0, 3.0)
     sd = synth.synthetic_state_dict(seed=0, offset_std=recipe[0], offset_bias=recipe[1])
-    tag, B, H, W, kind, seed = "off", 1, 120, 200, "natural", 6
+    B, H, W, kind = 1, 120, 200, "natural"
     f1, f2 = synth.synthetic_frames(seed, B, H, W, kind)
     t0 = time.time()
     taps = run_reference(sd, f1, f2, 64)
@@ -251,7 +252,7 @@ def large_offsets():
         arrays[f"{tag}.pos.{k}"] = pos
         arrays[f"{tag}.val.{k}"] = v[torch.from_numpy(pos)].numpy()
         arrays[f"{tag}.stats.{k}"] = stage_stats(taps[k])
-    np.savez_compressed(os.path.join(OUT, "large_offsets.npz"), **arrays)
+    np.savez_compressed(os.path.join(OUT, fname), **arrays)
 
 
 class DeformConv2dAutocastStandIn(DeformConv2dStandIn):
@@ -346,6 +347,8 @@ if __name__ == "__main__":
         large_odd()
     if "offsets" in which:
         large_offsets()
+    if "offsets16" in which:
+        large_offsets((6.0, 6.0), "large_offsets16.npz", "off16", 7)
     if "amp" in which:
         amp("amp_mid8_23x37", 8, 2, 23, 37, "stress", 12)
         amp("amp_mid64_40x56", 64, 1, 40, 56, "natural", 13)

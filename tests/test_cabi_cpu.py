@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/emavfi.h but not exported"
     assert sorted(lib.SYMBOLS) == declared, "emavfi/lib.py prototypes out of sync with the header"
-    assert L.emavfi_version() == 402
+    assert L.emavfi_version() == 403
 
 
 def test_host_queries_and_error_codes():

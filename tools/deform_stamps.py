@@ -30,9 +30,11 @@ with torch.no_grad():
     m(f1, f2)   # each pack overwrites the rows: what is read back is the LAST pack of this forward
 assert fn(buf.ctypes.data, ROWS, 0) == 0
 sel = buf[buf[:, 6] == 1]
-n_out = ((sel[:, 4] >> np.uint64(32)) & np.uint64(0xff)).astype(np.float64)      # (tap, row) steps with a lane outside the window, of 18
-n_lanes = (sel[:, 4] >> np.uint64(40)).astype(np.float64)                          # lanes outside, of 18 * 64
+n_out = ((sel[:, 4] >> np.uint64(32)) & np.uint64(0xff)).astype(np.float64)      # taps of the wave with a lane outside the window, of 9
+n_lanes = (sel[:, 4] >> np.uint64(40)).astype(np.float64)                          # samples outside, of 9 * 64
+fixup = (sel[:, 2] >> np.uint64(32)).astype(np.float64)                            # cycles in the fix-up pass (round 6)
 sel[:, 4] &= np.uint64(0xffffffff)
+sel[:, 2] &= np.uint64(0xffffffff)
 v = sel.astype(np.float64)
 names = ["prologue (window DMA + barrier)", "offset_conv", "geometry + tail of all 9 taps (up front)",
          "gather + blend + MFMA steps (9 taps)", "epilogue stores (drained)", "total"]
@@ -40,8 +42,10 @@ print(f"{dtype}: {len(v)} waves sampled (median cycles per wave and tile)")
 tot = np.median(v[:, 5])
 for i, n in enumerate(names):
     print(f"  {n:42s} {np.median(v[:, i]):10.0f}  {100.0 * np.median(v[:, i]) / tot:5.1f} %   (p10 {np.percentile(v[:, i], 10):.0f}, p90 {np.percentile(v[:, i], 90):.0f})")
-print(f"  fallback: {n_out.mean():.2f} of 18 (tap, row) groups per wave have a lane outside the window ({100 * n_out.mean() / 18:.1f} %), "
-      f"{n_lanes.mean():.2f} of 1152 lane samples ({100 * n_lanes.mean() / 1152:.2f} %)")
+print(f"  fix-up: {n_out.mean():.3f} of 9 taps per wave have a lane outside the window ({100 * n_out.mean() / 9:.2f} %), "
+      f"{n_lanes.mean():.2f} of 576 samples ({100 * n_lanes.mean() / 576:.3f} %); {fixup.mean():.0f} cycles per wave on average, "
+      f"{fixup[n_out > 0].mean() if (n_out > 0).any() else 0:.0f} per wave that has any, "
+      f"{fixup.sum() / max(1.0, n_out.sum()):.0f} per flagged (wave, tap)")
 d = buf[buf[:, 6] == 1][:, 7]
 parts = [((d >> np.uint64(16 * i)) & np.uint64(0xffff)).astype(np.float64) * 4 for i in range(4)]
 print("  prologue detail (median cycles): tile mapping + small loads + DMA issue %.0f, DMA landed after %.0f, convert %.0f, barrier wait %.0f"

@@ -269,7 +269,10 @@ struct DeformParams {
     void *out16;          // fp32 LDS-window kernel (deform_f32w.inl) only, EMAVFI_AMP16: ALSO write the result's fp16 rounding, channels-last with
     int out16_ps;         // pixel stride out16_ps (elements) - what the fp16 offset_conv / reconstruction.0 read (was a separate conversion pass)
     unsigned long long *stamps;  // diagnostic build (-DEMAVFI_DEFORM_STAMPS=1) only, else null
+    unsigned *census;            // deform_pack3.inl: null, or 64 slots x 4 u32 (zeroed by the host before the launch) that receive
+                                 // {(wave, tap) groups in the fix-up, samples outside the window, max |offset| as float bits, 0}
 };
+#define DEFORM_CENSUS_SLOTS 64
 #define DEFORM_STAMP_STRIDE 14
 #define DEFORM_STAMP_ROWS 16384
 

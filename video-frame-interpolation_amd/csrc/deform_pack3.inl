@@ -45,7 +45,15 @@ struct Pack3 {
     static constexpr int SEG_PX = 7, SEG_BYTES = SEG_PX * PSB;                            // one DMA instruction = 7 pixels x 9 pieces
     static constexpr int LAST_PX = TC - 3 * SEG_PX;                                       // wave 3: the last 2 pixels of a row
     static constexpr int W3_OFF = WIN_BYTES, W3_TAP = 4 * 4 * 2 * 16, W3_BYTES = 9 * W3_TAP;  // third-fragment A operands
-    static constexpr int LDS_BYTES = W3_OFF + W3_BYTES;                                   // 80 784 B: two workgroups per CU
+    // fix-up arena (round 6): once all four waves have left the tap loop the window is dead, and every wave owns a quarter of it as an
+    // arena of 32 entries = {4 corners x 9 pieces | one pad slot} (an odd number of 16-byte slots: conflict-free like the window's pixels);
+    // entry 31 is all zeros (what lanes without a sample in the round read against zero weights)
+    static constexpr int ENT_SLOTS = 4 * SP + 1, ENT_BYTES = ENT_SLOTS * 16, NENT = 31, ZERO_ENT = NENT * ENT_BYTES;   // 592 B entries
+    static constexpr int ARENA_BYTES = (WIN_BYTES / 4) & ~15;                             // 19 040 B per wave
+    static constexpr int SYNC_OFF = W3_OFF + W3_BYTES;                                    // u32: waves that have left the tap loop
+    static constexpr int TAB_OFF = SYNC_OFF + 16, TAB_BYTES = 4 * 32 * 4;                 // per wave 32 corner descriptors
+    static constexpr int LDS_BYTES = TAB_OFF + TAB_BYTES;                                 // 81 312 B: two workgroups per CU
+    static_assert((NENT + 1) * ENT_BYTES <= ARENA_BYTES && (ENT_SLOTS & 1) == 1, "arena");
     // packed weights (bytes): DCN = [tap][kg 4][nf 2][lane][16] | W3 table | tail [j 3][nf 3][lane][16]
     static constexpr int DCN_TAP = 4 * 2 * 1024, DCN_W3 = 9 * DCN_TAP, DCN_TAIL = DCN_W3 + W3_BYTES, DCN_BYTES = DCN_TAIL + 9 * 1024;
     // offset_conv = [tap][kg 4][lane][16] | tail [j 3][lane][16]
@@ -227,7 +235,9 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
     const unsigned w3lane = (unsigned)(C::W3_OFF + (a3row * 2 + a3half) * 16);
     const int t3lane16 = (a3half * 32 + a3row) * 16;   // the same operand out of a 32x32x16 fragment of the blob (its row 3 is a zero row)
     DEFORM_STAMP(ts_converted);
-    __syncthreads();  // hipcc drains the DMA (vmcnt(0)) ahead of the barrier
+    if (tid == 0) *reinterpret_cast<__attribute__((address_space(3))) unsigned *>((lds_char_t *)smem + C::SYNC_OFF) = 0u;   // (fix-up hand-shake below)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the window DMA has landed (hipcc emits this wait today; not relied upon - ADVICE r5)
+    __syncthreads();
     DEFORM_STAMP(ts_window);
 
     f32x16 omr[FUSE_OFF ? 2 : 1];
@@ -334,6 +344,7 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
     typedef unsigned u32x16_t __attribute__((ext_vector_type(9)));
     u32x16_t gm0 = {}, gm1 = {}, gm2 = {};
     unsigned lane_fb = 0, fb_taps = 0;   // per-lane / wave-uniform masks over taps
+    float omax = 0.0f;                   // census (DeformParams::census): largest |offset| this lane computed
     unsigned tl[12][2];                  // blended tail (channels 64..66 of this half-lane's own pixel) per tap slot; 9..11 zero
 #pragma unroll
     for (int t = 9; t < 12; ++t) tl[t][0] = tl[t][1] = 0u;
@@ -356,6 +367,7 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
         } else {
             o = load_om(om_my, tap, my_in);
         }
+        omax = fmaxf(omax, fmaxf(fabsf(o.dy), fabsf(o.dx)));   // (one v_max3_f32 with |.| modifiers; NaN offsets are ignored)
         const float py = fminf(fmaxf((fy_base + (float)ti) + o.dy, -2.0f), fy_max);
         const float px = fminf(fmaxf((fx_base + (float)tj) + o.dx, -2.0f), fx_max);
         const float fy = floorf(py), fx = floorf(px);
@@ -421,18 +433,18 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
     tail_mma(std::integral_constant<int, 0>{}); tail_mma(std::integral_constant<int, 1>{}); tail_mma(std::integral_constant<int, 2>{});
     DEFORM_STAMP(ts_geom_all);
 
-    // ---- 9 taps x 4 k-groups x 2 rows: two fragments from global weight fragments, the third from the LDS table
+    // ---- 9 taps x 4 k-groups x 2 rows: two fragments from global weight fragments, the third from the LDS table.
+    // The tap body is a generic lambda because it runs from TWO operand sources: the staged window (corners one pixel / one row apart)
+    // and, for the samples that left the window, the fix-up arena (round 6: four consecutive 144-byte corner records per entry).
     f16x8 xf_prev = {}, w3_prev = {}, w3_cur = {};   // software pipeline: the MFMAs of a step run inside the NEXT step's blend
 #pragma unroll
     for (int n = 0; n < 2; ++n) wq[1][n] = f16x8{};  // read (against the zero xf_prev) by the first tap's first step
-#pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
-        DEFORM_STAMP(ts_tap);
+    // one tap: operands (g0, g1, g2) = {LDS byte offset of the top-left corner | (w00, w01) | (w10, w11)} of this half-lane's OWN pixel;
+    // wnext = the NEXT tap's first weight fragments (null: none).  The last step's MFMAs stay pending in (xf_prev, w3_prev, wq[1]).
+    auto tap_body = [&](auto arena_tag, const int tap, const char *wnext, const unsigned g0, const unsigned g1, const unsigned g2) {
+        constexpr bool ARENA = decltype(arena_tag)::value;
+        constexpr int OFFC[4] = {0, C::PSB, ARENA ? 2 * C::PSB : C::ROWB, ARENA ? 3 * C::PSB : C::ROWB + C::PSB};
         const char *wtap = wbase_g + (size_t)tap * C::DCN_TAP;   // wave-uniform
-        unsigned g0 = gm0[tap], g1 = gm1[tap], g2 = gm2[tap];   // wave-uniform index: indexed register moves
-        if (__builtin_expect((fb_taps >> tap) & 1u, 0)) {   // wave-uniform, rare: lanes parked for the fix-up loop hold (py, px, mask)
-            if ((lane_fb >> tap) & 1u) { g0 = 0u; g1 = 0u; g2 = 0u; }
-        }
         unsigned base[2], w01[2], w23[2];
         {
             auto both = [&](unsigned x, unsigned (&out)[2]) {
@@ -443,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
             // swap(a, b) = {(a.lo, b.lo), (a.hi, b.hi)}: the h = 1 receivers take b = base + 16 (their piece of the pixel)
             const auto sw = __builtin_amdgcn_permlane32_swap(g0, g0 + 16u, false, false);
             base[0] = sw[0]; base[1] = sw[1];
-            if (EMAVFI_P3_ABL & 2) { base[0] = xbase[0] + (unsigned)(tap * 16); base[1] = xbase[1] + (unsigned)(tap * 16); }
+            if (!ARENA && (EMAVFI_P3_ABL & 2)) { base[0] = xbase[0] + (unsigned)(tap * 16); base[1] = xbase[1] + (unsigned)(tap * 16); }
         }
         const unsigned w3a = w3lane + (unsigned)(tap * C::W3_TAP);
         // ---- the eight (k-group, row) steps, scheduled by hand.  Left to hipcc the block came out as runs of 4-6 back-to-back
@@ -457,7 +469,7 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
             const int kg = s >> 1, m = s & 1;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const u32x4_t v = lds_read16(lds_r + base[m] + (unsigned)(kg * 32 + OFF[c]));
+                const u32x4_t v = lds_read16(lds_r + base[m] + (unsigned)(kg * 32 + OFFC[c]));
                 d[c][0] = v[0]; d[c][1] = v[1]; d[c][2] = v[2]; d[c][3] = v[3];
             }
         };
@@ -502,9 +514,9 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
                 if (kg + 1 < 4) {
 #pragma unroll
                     for (int n = 0; n < 2; ++n) wq[(kg + 1) & 1][n] = *reinterpret_cast<const f16x8 *>(wtap + ((kg + 1) * 2 + n) * 1024 + lane16);
-                } else if (tap < 8) {
+                } else if (wnext) {
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) wq[0][n] = *reinterpret_cast<const f16x8 *>(wtap + C::DCN_TAP + n * 1024 + lane16);
+                    for (int n = 0; n < 2; ++n) wq[0][n] = *reinterpret_cast<const f16x8 *>(wnext + n * 1024 + lane16);
                 }
             }
             if (m == 0) w3_cur = w3n;
@@ -512,30 +524,57 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
             xf_prev = f16x8{a[0][0], a[0][1], a[1][0], a[1][1], a[2][0], a[2][1], a[3][0], a[3][1]};
             w3_prev = w3_cur;
         }
+    };
+    // the pending last step (k-group 3, row 1) of a tap sequence
+    auto flush_taps = [&]() {
+        mma_kg(acc[1][0], wq[1][0], xf_prev);
+        mma_kg(acc[1][1], wq[1][1], xf_prev);
+        mma_k32(acc3[1], w3_prev, xf_prev);
+    };
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+        DEFORM_STAMP(ts_tap);
+        unsigned g0 = gm0[tap], g1 = gm1[tap], g2 = gm2[tap];   // wave-uniform index: indexed register moves
+        if (__builtin_expect((fb_taps >> tap) & 1u, 0)) {   // wave-uniform, rare: lanes parked for the fix-up hold (py, px, mask)
+            if ((lane_fb >> tap) & 1u) { g0 = 0u; g1 = 0u; g2 = 0u; }
+        }
+        tap_body(std::false_type{}, tap, tap < 8 ? wbase_g + (size_t)(tap + 1) * C::DCN_TAP : nullptr, g0, g1, g2);
 #if EMAVFI_DEFORM_STAMPS
         DEFORM_STAMP(ts_end);
         sum_steps += ts_end - ts_tap;
 #endif
     }
-    // the last step (k-group 3, row 1) of the last tap
-    mma_kg(acc[1][0], wq[1][0], xf_prev);
-    mma_kg(acc[1][1], wq[1][1], xf_prev);
-    mma_k32(acc3[1], w3_prev, xf_prev);
+    flush_taps();
+    DEFORM_STAMP(ts_taps_done);
 
-    // ---- fix-up: the marked taps' samples that left the window, gathered from global memory with clamped corners and
-    // validity-masked weights (the value deform_kernel computes); every other lane takes part with zero weights
+    // ---- fix-up (round 6): the samples that left the window.  Round 5 gathered them from global memory in a second copy of the tap
+    // body - a full wave contraction per flagged tap with its corner loads in front of the blend, 2-4 tap times each.
+    // Now: every wave signals that it has left the tap loop; a wave with parked samples waits until all four have (the window is dead
+    // then), takes ITS quarter of the window as an arena, fetches the parked samples' four corner records (4 x 144 B) into it with
+    // LDS-DMA - up to 31 samples of ANY of its taps per round, one exposed round trip per round instead of one per tap -, and runs the
+    // very tap body of the main loop on the arena (zero weights and the zero entry for every lane without a sample in the round).
+    // Corners are clamped into the image and the weights of out-of-image corners are zero: the value deform_kernel computes.
+    typedef __attribute__((address_space(3))) unsigned lds_u32_t;
+    lds_u32_t *sync_word = reinterpret_cast<lds_u32_t *>((lds_char_t *)smem + C::SYNC_OFF);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's last window reads have returned
+    if (lane == 0) __hip_atomic_fetch_add(sync_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    unsigned n_parked = 0;
     if (__builtin_expect(fb_taps != 0, 0)) {
 #if EMAVFI_DEFORM_STAMPS
         cnt_out += __popc(fb_taps);
 #endif
-#pragma unroll 1
-        for (unsigned left = fb_taps; left != 0; left &= left - 1) {
-            const int tap = __builtin_ctz(left);
-            const char *wtap = wbase_g + (size_t)tap * C::DCN_TAP;
+        // every wave of the workgroup reaches the increment above unconditionally: the wait ends
+        while (*reinterpret_cast<volatile lds_u32_t *>(sync_word) < (unsigned)C::WAVES) __builtin_amdgcn_s_sleep(4);
+        const unsigned lds0 = (unsigned)(size_t)(lds_char_t *)smem;
+        const unsigned arena = (unsigned)__builtin_amdgcn_readfirstlane(wave * C::ARENA_BYTES);   // (an SGPR: the DMA's M0 operand)
+        lds_u32_t *table = reinterpret_cast<lds_u32_t *>((lds_char_t *)smem + C::TAB_OFF + wave * 128);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        // (py, px, mask) of a parked lane -> clamped corner descriptor (top-left pixel | x1 - x0 << 24 | y1 - y0 << 25) and the
+        // validity-masked corner weights; lanes without `sel` get zero weights
+        auto fix_geom = [&](int tap, bool sel, unsigned &desc, unsigned &w01h, unsigned &w23h) {
             const unsigned g0 = gm0[tap], g1 = gm1[tap], g2 = gm2[tap];
-            const bool need_fb = ((lane_fb >> tap) & 1u) != 0;
-            const float py = need_fb ? __uint_as_float(g0) : 0.0f, px = need_fb ? __uint_as_float(g1) : 0.0f;
-            const float mk = need_fb ? __uint_as_float(g2) : 0.0f;
+            const float py = sel ? __uint_as_float(g0) : 0.0f, px = sel ? __uint_as_float(g1) : 0.0f;
+            const float mk = sel ? __uint_as_float(g2) : 0.0f;
             const float fy = floorf(py), fx = floorf(px);
             const int hl = (int)fy, wl = (int)fx, hh = hl + 1, wh = wl + 1;
             const float lh = py - fy, lw = px - fx, uh = 1.0f - lh, uw = 1.0f - lw;
@@ -545,132 +584,145 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
             const bool vwl = (unsigned)wl < (unsigned)W, vwh = (unsigned)wh < (unsigned)W;
             const float w4[4] = {vhl && vwl ? mk * (uh * uw) : 0.0f, vhl && vwh ? mk * (uh * lw) : 0.0f,
                                  vhh && vwl ? mk * (lh * uw) : 0.0f, vhh && vwh ? mk * (lh * lw) : 0.0f};
-            // top-left pixel index | (x1 - x0) << 24 | (y1 - y0) << 25 (clamped corners) | flag << 26
-            const unsigned gpk = (__umul24((unsigned)hlc, (unsigned)W) + (unsigned)wlc) | ((unsigned)(whc - wlc) << 24) |
-                                 ((unsigned)(hhc - hlc) << 25) | (need_fb ? 1u << 26 : 0u);
-            const unsigned w01h = __builtin_bit_cast(unsigned, f16x2_t{(half_t)w4[0], (half_t)w4[1]});
-            const unsigned w23h = __builtin_bit_cast(unsigned, f16x2_t{(half_t)w4[2], (half_t)w4[3]});
-            unsigned w01[2], w23[2], gp[2];
+            desc = (__umul24((unsigned)hlc, (unsigned)W) + (unsigned)wlc) | ((unsigned)(whc - wlc) << 24) | ((unsigned)(hhc - hlc) << 25);
+            w01h = __builtin_bit_cast(unsigned, f16x2_t{(half_t)w4[0], (half_t)w4[1]});
+            w23h = __builtin_bit_cast(unsigned, f16x2_t{(half_t)w4[2], (half_t)w4[3]});
+        };
+        // one LDS-DMA instruction = 64 consecutive 16-byte slots of the arena; lane L of instruction i fills slot q = 64 i + L =
+        // entry q / 37, corner (q % 37) / 9, piece (q % 37) % 9 (slot 36 of an entry: pad)
+        auto dma = [&](const char *src, unsigned dst) {
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(__builtin_amdgcn_readfirstlane(dst)) : "memory", "m0");
+        };
+        if (lane < C::ENT_SLOTS) dma(zeros, lds0 + arena + (unsigned)C::ZERO_ENT);   // the zero entry, once
+#pragma unroll 1
+        for (unsigned left = fb_taps; left != 0; left &= left - 1)
+            n_parked += (unsigned)__popcll(__ballot(((lane_fb >> __builtin_ctz(left)) & 1u) != 0));
+        const bool convert = std::is_same<TS, bf16_t>::value && !p.in_f16;
+        const char *wtl_fx = wbase_g + C::DCN_TAIL;
+#pragma unroll 1
+        for (unsigned rbase = 0; rbase < n_parked; rbase += (unsigned)C::NENT) {
+            const unsigned n_ent = min((unsigned)C::NENT, n_parked - rbase);
+            // -- A: the round's corner descriptors
+            unsigned round_taps = 0, prefix = 0;
+#pragma unroll 1
+            for (unsigned left = fb_taps; left != 0; left &= left - 1) {
+                const int tap = __builtin_ctz(left);
+                const bool parked = ((lane_fb >> tap) & 1u) != 0;
+                const unsigned long long bal = __ballot(parked);
+                const unsigned cnt = (unsigned)__popcll(bal);
+                if (prefix < rbase + n_ent && prefix + cnt > rbase) {
+                    round_taps |= 1u << tap;
+                    const unsigned slot = prefix + (unsigned)__popcll(bal & below) - rbase;
+                    unsigned desc, wa_, wb_;
+                    fix_geom(tap, parked, desc, wa_, wb_);
+                    if (parked && slot < n_ent) table[slot] = desc;
+                }
+                prefix += cnt;
+            }
+            // -- B: fetch the entries (the table reads return before the first DMA leaves; the DMA is inline asm, so hipcc places no
+            // waits for it: C below does)
+            const unsigned lim = n_ent * (unsigned)C::ENT_SLOTS, ninst = (lim + 63u) >> 6;
             {
-                auto both = [&](unsigned x, unsigned (&out)[2]) {
-                    const auto sw = __builtin_amdgcn_permlane32_swap(x, x, false, false);
-                    out[0] = sw[0]; out[1] = sw[1];
-                };
-                both(w01h, w01); both(w23h, w23); both(gpk, gp);
-            }
-            auto corners_of = [&](unsigned g, unsigned (&pc)[4]) {
-                const unsigned pix = g & 0xffffffu, ddx = (g >> 24) & 1u, ddy = (g >> 25) & 1u;
-                pc[0] = pix; pc[1] = pix + ddx; pc[2] = pix + (ddy ? (unsigned)W : 0u); pc[3] = pc[2] + ddx;
-            };
-            const unsigned w3a = w3lane + (unsigned)(tap * C::W3_TAP);
-            // Round 5 (bench.py also_pack_vs_offset_spread: 25 k cycles per (wave, tap) in this loop, against 2.1 k for a tap of the
-            // main loop): the loop used to issue a (k-group, row)'s four corner loads inside a divergent `if`, right in front of their
-            // blend - eight exposed global round trips per tap.  Now EVERY lane loads (a parked lane its clamped corners, every other
-            // lane pixel 0 of the plane: a valid address, one line, its value replaced by zero below, so a NaN there cannot leak through a
-            // zero weight), branch-free, the byte offsets of both rows' corners are computed once per tap, and k-group kg + 1's eight
-            // loads are issued BEFORE k-group kg is blended and contracted: one exposed round trip per tap, the other three under the
-            // arithmetic (their lines were fetched by k-group 0: a pixel's four k-groups share its 144-byte record).
-            unsigned co[2][4];
-            bool fl[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                unsigned pc[4];
-                corners_of(gp[m], pc);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) co[m][c] = __umul24(pc[c], ps_bytes) + (unsigned)(h * 16);
-                fl[m] = ((gp[m] >> 26) & 1u) != 0;
-            }
-            u32x4_t gb[2][2][4];   // [buffer][row][corner]
-            f16x8 wfb[2][2];       // [buffer][fragment]: a stage = 8 corner loads + its 2 weight fragments, so that "stage kg has landed" is
-                                   // a partial vmcnt (loads return in issue order: a fragment load issued BEHIND the next stage's gathers
-                                   // would make its wait drain them too)
-            auto issue = [&](int kg, u32x4_t (&dst)[2][4], f16x8 (&wdst)[2]) {
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) dst[m][c] = *reinterpret_cast<const u32x4_t *>(gplane + (size_t)(co[m][c] + (unsigned)(kg * 32)));   // (uniform base + 32-bit offset: no address pairs)
-#pragma unroll
-                for (int n = 0; n < 2; ++n) wdst[n] = *reinterpret_cast<const f16x8 *>(wtap + (kg * 2 + n) * 1024 + lane16);
-            };
-            // storage -> f16 without a branch (a uniform branch per piece cut the block into regions and pinned a full wait in each)
-            const unsigned keep_raw = (std::is_same<TS, bf16_t>::value && !p.in_f16) ? 0u : 0xffffffffu;
-            auto conv_piece = [&](u32x4_t v) {
-                if constexpr (std::is_same<TS, bf16_t>::value) {
-                    const u32x4_t cv = to_f16_piece<TS>(v);
-                    return u32x4_t{(v[0] & keep_raw) | (cv[0] & ~keep_raw), (v[1] & keep_raw) | (cv[1] & ~keep_raw),
-                                   (v[2] & keep_raw) | (cv[2] & ~keep_raw), (v[3] & keep_raw) | (cv[3] & ~keep_raw)};
-                } else {
-                    return v;
+                unsigned e = lane >= C::ENT_SLOTS ? 1u : 0u, rem = (unsigned)lane - e * (unsigned)C::ENT_SLOTS;
+#pragma unroll 1
+                for (unsigned i = 0; i < ninst; ++i) {
+                    const unsigned d = table[min(e, 31u)];
+                    const unsigned cr = (rem * 57u) >> 9, pc = rem - cr * 9u;               // corner 0..3 (4: the pad slot), piece 0..8
+                    const unsigned cpx = (d & 0xffffffu) + ((cr & 1u) ? ((d >> 24) & 1u) : 0u) + (((cr & 2u) && ((d >> 25) & 1u)) ? (unsigned)W : 0u);
+                    const char *src = pc == 8u && tplane ? tplane + (size_t)__umul24(cpx, tail_bytes) : gplane + (size_t)(__umul24(cpx, ps_bytes) + pc * 16u);
+                    if (cr == 4u) src = zeros;
+                    if (i * 64u + (unsigned)lane < lim) dma(src, lds0 + arena + i * 1024u);
+                    rem += 64u - (unsigned)C::ENT_SLOTS; e += 1u;
+                    if (rem >= (unsigned)C::ENT_SLOTS) { rem -= (unsigned)C::ENT_SLOTS; e += 1u; }
                 }
-            };
-            u32x2_t traw[4];
-            issue(0, gb[0], wfb[0]);
+            }
+            // the round's first weight fragments travel under the DMA
+            {
+                const char *w0 = wbase_g + (size_t)__builtin_ctz(round_taps) * C::DCN_TAP;
 #pragma unroll
-            for (int kg = 0; kg < 4; ++kg) {
-                if (kg + 1 < 4) issue(kg + 1, gb[(kg + 1) & 1], wfb[(kg + 1) & 1]);
-                if (kg == 2) {   // the parked lanes' tail channels (one 8-byte piece per corner): in flight under the last two k-groups
-                    unsigned pc[4];
-                    corners_of(gpk, pc);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        traw[c] = tplane ? *reinterpret_cast<const u32x2_t *>(tplane + (size_t)__umul24(pc[c], tail_bytes))
-                                         : *reinterpret_cast<const u32x2_t *>(gplane + (size_t)(__umul24(pc[c], ps_bytes) + 128u));
+                for (int n = 0; n < 2; ++n) { wq[0][n] = *reinterpret_cast<const f16x8 *>(w0 + n * 1024 + lane16); wq[1][n] = f16x8{}; }
+                xf_prev = f16x8{}; w3_prev = f16x8{};
+            }
+            // -- C: landed (in-order return: the fragments above too); bf16 storage: every lane converts the slots it fetched
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (convert) {
+#pragma unroll 1
+                for (unsigned i = 0; i < ninst; ++i) {
+                    if (i * 64u + (unsigned)lane < lim) {
+                        lds_char_t *q = (lds_char_t *)smem + arena + i * 1024u + lane16;
+                        const u32x4_t v = to_f16_piece<TS>(lds_read16(q));
+                        *reinterpret_cast<__attribute__((address_space(3))) u32x4_t *>(q) = v;
+                    }
                 }
-                const f16x8 w3f = __builtin_bit_cast(f16x8, lds_read16(lds_r + w3a + (unsigned)(kg * 128)));
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    unsigned d[4][4];
+            }
+            // -- D: the round's taps on the arena
+            prefix = 0;
+#pragma unroll 1
+            for (unsigned left = fb_taps; left != 0; left &= left - 1) {
+                const int tap = __builtin_ctz(left);
+                const bool parked = ((lane_fb >> tap) & 1u) != 0;
+                const unsigned long long bal = __ballot(parked);
+                const unsigned cnt = (unsigned)__popcll(bal);
+                const unsigned slot = prefix + (unsigned)__popcll(bal & below) - rbase;
+                prefix += cnt;
+                if (!((round_taps >> tap) & 1u)) continue;
+                const bool mine = parked && slot < n_ent;
+                unsigned desc, w01h, w23h;
+                fix_geom(tap, mine, desc, w01h, w23h);
+                const unsigned ent = arena + (mine ? slot * (unsigned)C::ENT_BYTES : (unsigned)C::ZERO_ENT);
+                const unsigned later = round_taps & ~((2u << tap) - 1u);
+                tap_body(std::true_type{}, tap, later ? wbase_g + (size_t)__builtin_ctz(later) * C::DCN_TAP : nullptr, ent, w01h, w23h);
+                // the tail channels (64..66) of the same samples: one im2col k-group with this tap's slot alone
+                {
+                    u32x4_t vt[4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const u32x4_t v = conv_piece(gb[kg & 1][m][c]);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) d[c][q] = fl[m] ? v[q] : 0u;
+                        const u32x2_t t2 = lds_read8(lds_r + ent + (unsigned)(128 + c * C::PSB));
+                        vt[c] = u32x4_t{t2[0], t2[1], 0u, 0u};
                     }
-                    unsigned xd[4];
-                    blend_corners_cm<4>(d, w01[m], w23[m], xd);
-                    const f16x8 xf = __builtin_bit_cast(f16x8, u32x4_t{xd[0], xd[1], xd[2], xd[3]});
-                    mma_kg(acc[m][0], wfb[kg & 1][0], xf);
-                    mma_kg(acc[m][1], wfb[kg & 1][1], xf);
-                    mma_k32(acc3[m], w3f, xf);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // tail channels of the parked lanes' own pixels: one im2col k-group with this tap's slot alone
-            {
-                unsigned vt[4][4];
+                    const u32x4_t td = __builtin_bit_cast(u32x4_t, blend_corners<2>(vt, w01h, w23h));
+                    // K = 16 j + 8 h' + 4 u + channel with tap = 4 j + 2 h' + u: only lanes of half h' carry it, in dwords (2u, 2u + 1)
+                    const int j = tap >> 2, hsel = (tap >> 1) & 1, u = tap & 1;
+                    unsigned tm[2][2];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const u32x4_t cv = conv_piece(u32x4_t{traw[c][0], traw[c][1], 0u, 0u});
-                    vt[c][0] = need_fb ? cv[0] : 0u; vt[c][1] = need_fb ? cv[1] : 0u;
-                    vt[c][2] = vt[c][3] = 0u;
-                }
-                unsigned td[4];
-                blend_corners_cm<2>(vt, w01h, w23h, td);
-                // K = 16 j + 8 h' + 4 u + channel with tap = 4 j + 2 h' + u: only lanes of half h' carry it, in dwords (2u, 2u + 1)
-                const int j = tap >> 2, hsel = (tap >> 1) & 1, u = tap & 1;
-                unsigned tm[2][2];
+                    for (int dd = 0; dd < 2; ++dd) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(td[dd], td[dd], false, false);   // {row 0's, row 1's} in both halves
+                        tm[0][dd] = h == hsel ? sw[0] : 0u;
+                        tm[1][dd] = h == hsel ? sw[1] : 0u;
+                    }
+                    f16x8 wt[3];
 #pragma unroll
-                for (int d = 0; d < 2; ++d) {
-                    const auto sw = __builtin_amdgcn_permlane32_swap(td[d], td[d], false, false);   // {row 0's, row 1's} in both halves
-                    tm[0][d] = h == hsel ? sw[0] : 0u;
-                    tm[1][d] = h == hsel ? sw[1] : 0u;
-                }
-                f16x8 wt[3];
+                    for (int n = 0; n < 3; ++n) wt[n] = *reinterpret_cast<const f16x8 *>(wtl_fx + (j * 3 + n) * 1024 + (n < 2 ? lane16 : t3lane16));
 #pragma unroll
-                for (int n = 0; n < 3; ++n) wt[n] = *reinterpret_cast<const f16x8 *>(wtl + (j * 3 + n) * 1024 + (n < 2 ? lane16 : t3lane16));
+                    for (int m = 0; m < 2; ++m) {
+                        const u32x4_t bq = u ? u32x4_t{0u, 0u, tm[m][0], tm[m][1]} : u32x4_t{tm[m][0], tm[m][1], 0u, 0u};
+                        const f16x8 xf = __builtin_bit_cast(f16x8, bq);
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const u32x4_t bq = u ? u32x4_t{0u, 0u, tm[m][0], tm[m][1]} : u32x4_t{tm[m][0], tm[m][1], 0u, 0u};
-                    const f16x8 xf = __builtin_bit_cast(f16x8, bq);
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) mma_kg(acc[m][n], wt[n], xf);
-                    mma_k32(acc3[m], wt[2], xf);
+                        for (int n = 0; n < 2; ++n) mma_kg(acc[m][n], wt[n], xf);
+                        mma_k32(acc3[m], wt[2], xf);
+                    }
                 }
             }
+            flush_taps();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the round's arena reads have returned before the next round's DMA overwrites them
         }
     }
     DEFORM_STAMP(ts_loop);
+    // ---- census of this launch (emavfi_forward_census / emavfi_mdcn_census): (wave, tap) groups that took the fix-up, samples outside the
+    // window, largest |offset| - 64 slots of {u32 x 4} per launch so that the atomics of 118 k waves spread; no-return atomics
+    if (p.census) {
+        float om = my_in ? omax : 0.0f;
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) om = fmaxf(om, __shfl_xor(om, sh));
+        if (lane == 0) {
+            unsigned *cs = p.census + (blockIdx.x & 63u) * 4u;
+            if (fb_taps) {
+                (void)__hip_atomic_fetch_add(cs, (unsigned)__popc(fb_taps), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                (void)__hip_atomic_fetch_add(cs + 1, n_parked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            (void)__hip_atomic_fetch_max(cs + 2, __float_as_uint(om), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 
     // ---- epilogue (no activation: ema_vfi.py:136-138 chains the blocks directly)
 #pragma unroll
@@ -706,8 +758,9 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
         const unsigned row = (blockIdx.x / DEFORM_STAMP_STRIDE) * C::WAVES + wave;
         if (row < DEFORM_STAMP_ROWS) {
             unsigned long long *o = p.stamps + (size_t)row * 8;
-            o[0] = ts_window - ts_begin; o[1] = ts_offconv - ts_window; o[2] = ts_geom_all - ts_offconv; o[3] = sum_steps;
-            o[4] = (ts_done - ts_loop) | (cnt_out << 32); o[5] = ts_done - ts_begin; o[6] = 1;
+            // (o[2] bits 32..63: the fix-up pass - hand-shake wait, arena rounds, its taps; o[4]: flagged taps << 32, parked samples << 40)
+            o[0] = ts_window - ts_begin; o[1] = ts_offconv - ts_window; o[2] = (ts_geom_all - ts_offconv) | ((ts_loop - ts_taps_done) << 32); o[3] = sum_steps;
+            o[4] = (ts_done - ts_loop) | (cnt_out << 32) | ((unsigned long long)n_parked << 40); o[5] = ts_done - ts_begin; o[6] = 1;
             auto q16 = [](unsigned long long v) { v >>= 2; return v > 0xffffull ? 0xffffull : v; };
             o[7] = q16(ts_issued - ts_begin) | (q16(ts_landed - ts_issued) << 16) | (q16(ts_converted - ts_landed) << 32) | (q16(ts_window - ts_converted) << 48);
         }

@@ -404,10 +404,12 @@ unsigned long long *debug_stamp_buffer()
 
 int run_deform(const Plan &P, const Layer &L, const void *packed, const void *x, int x_ps, float *om, void *out,
                int out_ps, int cstore, int B, int H, int W, hipStream_t s, const void *zeros = nullptr, const Layer *off = nullptr,
-               const void *x_tail = nullptr, int tail_ps = 0, int force_dtype = -1, int in_f16 = 0, int out_f16 = 0, void *out16 = nullptr, int out16_ps = 0)
+               const void *x_tail = nullptr, int tail_ps = 0, int force_dtype = -1, int in_f16 = 0, int out_f16 = 0, void *out16 = nullptr, int out16_ps = 0,
+               unsigned *census = nullptr)
 {
     const int kd = force_dtype >= 0 ? force_dtype : P.dtype;
     DeformParams d{};
+    d.census = census;
     d.x = x; d.om = om; d.out = out;
     d.x_tail = x_tail; d.tail_ps = tail_ps;
     if (off) {  // fused ModulatedDeformConvPack: the kernel computes om itself (off = the copy in the kernel's on-chip type)
@@ -455,12 +457,16 @@ struct Workspace {
     void *take(size_t bytes) { void *p = base ? base + used : nullptr; used = rup256(used + bytes); return p; }
 };
 
+constexpr size_t kCensusBlock = (size_t)DEFORM_CENSUS_SLOTS * 4 * sizeof(unsigned);   // one launch's census
+constexpr size_t kCensusBytes = (size_t)kMaxBlocks * kCensusBlock;
+
 struct FwdBuffers {
     void *in16, *fA, *fB, *fu0, *fu1, *c1, *c2, *c3;
     float *fuF0, *fuF1;  // amp: fp32 copies of the fusion tensor (input / output of the fp32 DCN)
     float *part, *ctx, *table, *flow, *om;
     float *tpart;        // context_encoding.2 fused with the pool (conv_wreg.inl): per-tile channel sums [B][ntiles][p4]
     int ntiles, nparts2; // ... and the partial sums avg_pool_partial reduces them to
+    unsigned *census;    // deform_pack3.inl's per-launch census: [kMaxBlocks][DEFORM_CENSUS_SLOTS][4] u32, zeroed at the head of every forward
     int nparts, H2, W2, H4, W4, p2, p4, p_half;
 };
 
@@ -493,6 +499,7 @@ void carve_forward(const Plan &P, Workspace &ws, FwdBuffers &f, int B, int H, in
         f.fuF0 = (float *)ws.take(px * P.fpad * sizeof(float));
         f.fuF1 = (float *)ws.take(px * P.fpad * sizeof(float));
     }
+    f.census = (unsigned *)ws.take(kCensusBytes);   // (last: every other offset is what it was before round 6)
 }
 
 // ---- launch recorder: names every kernel launch of a forward, its algorithmic work, and can
@@ -575,7 +582,7 @@ bool pack_f16_link(const Plan &P, int i)
 // 16-bit / fp32 models: x -> y (channels-last, pixel stride P.fps).  x_tail: the compact 8-channel buffer the first pack takes channels
 // 64.. from (or null); in_f16 / out_f16: the bf16 model's f16 hand-off (DeformParams)
 int attention_block(const Plan &P, int i, const void *packed, const void *x, void *y, float *om, const void *x_tail, int in_f16, int out_f16,
-                    int B, int H, int W, hipStream_t s, Recorder &rec)
+                    int B, int H, int W, hipStream_t s, Recorder &rec, unsigned *census = nullptr)
 {
     const double px = (double)B * H * W, e = P.esize, cf = P.mid + 3;
     double fl, by;
@@ -585,7 +592,7 @@ int attention_block(const Plan &P, int i, const void *packed, const void *x, voi
         // the input is read once and the offsets / masks never leave the registers
         EMAVFI_STEP(rec, deform_name(P, P.dcn[i]) + " offset_conv+dcn_v2", fl + 2.0 * 9.0 * cf * cf * px, px * (2.0 * cf * e) + 9.0 * cf * (cf + 27.0) * e,
                     run_deform(P, P.dcn[i], packed, x, P.fps, om, y, P.fps, P.fps, B, H, W, s, nullptr, P.has_offh ? &P.offh[i] : &P.off[i], x_tail, 8,
-                               -1, in_f16, out_f16));
+                               -1, in_f16, out_f16, nullptr, 0, census));
     } else {
         if (x_tail || in_f16 || out_f16) return fail(EMAVFI_E_UNSUPPORTED, "attention block: split tail / f16 hand-off need the one-launch pack kernel");
         EMAVFI_STEP(rec, conv_name(P, P.off[i]) + " offset_conv", fl, by, run_conv(P, P.off[i], packed, x, P.fps, H, W, om, 32, 0, 32, EPI_OM, B, s));
@@ -724,6 +731,8 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
     }
     hipStream_t s = (hipStream_t)stream;
     const unsigned sw = emavfi_switches();
+    // the one-launch packs count what left their window (emavfi_forward_census reads it back): 8 KiB, zeroed per forward
+    if (!rec.dry && hipMemsetAsync(f.census, 0, kCensusBytes, s) != hipSuccess) return fail(EMAVFI_E_LAUNCH, "forward: census memset failed");
     // the header of the blob is compared ON THE DEVICE with what this call expects (the forward's last launch, blob_guard_kernel): a
     // blob of another version / model / dtype / layout-switch setting yields an all-NaN frame instead of plausible garbage.
     // emavfi_packed_check() is the (synchronising) entry that returns a code for it.
@@ -868,7 +877,8 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
         // --- multi-attention fusion: num_blocks x ModulatedDeformConvPack, no activation (ema_vfi.py:136-138)
         for (int i = 0; i < P.nb; ++i) {
             if (const int rc = attention_block(P, i, packed, x, y, f.om, i == 0 && split_tail ? f.in16 : nullptr,
-                                               (i == 0 ? feat16 : pack_f16_link(P, i - 1)) ? 1 : 0, pack_f16_link(P, i) ? 1 : 0, B, H, W, s, rec);
+                                               (i == 0 ? feat16 : pack_f16_link(P, i - 1)) ? 1 : 0, pack_f16_link(P, i) ? 1 : 0, B, H, W, s, rec,
+                                               rec.dry ? nullptr : f.census + (size_t)i * DEFORM_CENSUS_SLOTS * 4);
                 rc != EMAVFI_OK)
                 return rc;
             if (!rec.dry && taps && taps[5 + i])
@@ -1273,7 +1283,7 @@ static int mdcn_plan(Plan &P, int C, int dtype, int flags, bool &split, int &in_
     return EMAVFI_OK;
 }
 
-struct MdcnBuffers { void *blob, *xcl, *tail, *ycl; float *om, *xF, *yF; };
+struct MdcnBuffers { void *blob, *xcl, *tail, *ycl; float *om, *xF, *yF; unsigned *census; };
 static void mdcn_carve(const Plan &P, Workspace &ws, MdcnBuffers &m, int B, int H, int W, bool split)
 {
     const size_t px = (size_t)B * H * W;
@@ -1287,6 +1297,7 @@ static void mdcn_carve(const Plan &P, Workspace &ws, MdcnBuffers &m, int B, int 
         m.xF = (float *)ws.take(px * P.fpad * sizeof(float));
         m.yF = (float *)ws.take(px * P.fpad * sizeof(float));
     }
+    m.census = (unsigned *)ws.take(kCensusBlock);
 }
 
 size_t emavfi_mdcn_workspace_bytes(int B, int C, int H, int W, int dtype, int flags)
@@ -1322,7 +1333,8 @@ static int mdcn_impl(const float *x, const float *offset_weight, const float *of
     std::vector<const void *> params((size_t)emavfi_param_count(1), nullptr);
     params[P.off[0].param] = offset_weight; params[P.off[0].param + 1] = offset_bias;
     params[P.dcn[0].param] = dcn_weight; params[P.dcn[0].param + 1] = dcn_bias;
-    if (hipMemsetAsync(m.blob, 0, P.total, s) != hipSuccess) return fail(EMAVFI_E_LAUNCH, "mdcn: blob memset failed");
+    if (hipMemsetAsync(m.blob, 0, P.total, s) != hipSuccess || hipMemsetAsync(m.census, 0, kCensusBlock, s) != hipSuccess)
+        return fail(EMAVFI_E_LAUNCH, "mdcn: blob / census memset failed");
     EMAVFI_TRY(pack_layer(P.off[0], params.data(), m.blob, kd, s, P.amp), "mdcn pack offset_conv");
     if (P.has_offh) EMAVFI_TRY(pack_layer(P.offh[0], params.data(), m.blob, kd, s), "mdcn pack offset_conv (f16 fragments)");
     EMAVFI_TRY(pack_layer(P.dcn[0], params.data(), m.blob, kd, s), "mdcn pack dcn_v2");
@@ -1341,7 +1353,7 @@ static int mdcn_impl(const float *x, const float *offset_weight, const float *of
     } else {
         EMAVFI_TRY(launch_nchw_to_cl(x, m.xcl, B, C, H, W, P.fps, xdt, s), "mdcn layout in");
     }
-    if (const int rc = attention_block(P, 0, m.blob, m.xcl, m.ycl, m.om, m.tail, in_f16, out_f16, B, H, W, s, rec); rc != EMAVFI_OK) return rc;
+    if (const int rc = attention_block(P, 0, m.blob, m.xcl, m.ycl, m.om, m.tail, in_f16, out_f16, B, H, W, s, rec, m.census); rc != EMAVFI_OK) return rc;
     EMAVFI_TRY(launch_cl_to_nchw(m.ycl, y, B, C, H, W, P.fps, 0, ydt, s), "mdcn layout out");
     return EMAVFI_OK;
 }
@@ -1361,6 +1373,46 @@ int emavfi_mdcn_profiled(const float *x, const float *offset_weight, const float
     Recorder rec;
     rec.events = events; rec.n_events = n_events;
     return mdcn_impl(x, offset_weight, offset_bias, dcn_weight, dcn_bias, y, B, C, H, W, dtype, flags, workspace, workspace_bytes, stream, rec);
+}
+
+// ---- census of the one-launch packs (round 6): what deform_pack3_kernel itself counted while it ran - the (wave, tap)
+// groups that took the fix-up, the samples outside the staged window, the largest |offset| - reduced over the launch's 64 atomic slots
+// into out[block][4] (u64, DEVICE memory): {fix-up wave-taps, all wave-taps, samples outside, max |offset| as fp32 bits}.  All wave-taps
+// is 0 for a block that did not run the one-launch kernel (fp32 / autocast modes, other widths): nothing was counted.
+static unsigned long long pack3_wave_taps(int B, int H, int W) { return (unsigned long long)B * ((H + 15) / 16) * ((W + 15) / 16) * 4ull * 9ull; }
+
+int emavfi_forward_census(int in_channels, int mid_channels, int num_blocks, int B, int H, int W, int dtype, const void *workspace,
+                          size_t workspace_bytes, unsigned long long *out, void *stream)
+{
+    Plan P;
+    if (!build_plan(P, in_channels, mid_channels, num_blocks, dtype)) return fail(EMAVFI_E_UNSUPPORTED, "%s", P.why);
+    if (B < 1 || H < 1 || W < 1) return fail(EMAVFI_E_ARG, "forward_census: B, H, W must be >= 1");
+    if (!workspace || !out) return fail(EMAVFI_E_ARG, "forward_census: null pointer");
+    Workspace ws{(char *)const_cast<void *>(workspace), workspace_bytes, 0};
+    FwdBuffers f;
+    carve_forward(P, ws, f, B, H, W);
+    if (ws.used > workspace_bytes) return fail(EMAVFI_E_WORKSPACE, "forward_census: this forward's workspace has %zu bytes, got %zu", ws.used, workspace_bytes);
+    unsigned long long totals[kMaxBlocks] = {};
+    for (int i = 0; i < P.nb; ++i) totals[i] = pack_fuses(P, i) && P.dcn[i].pack3 == 1 ? pack3_wave_taps(B, H, W) : 0ull;
+    EMAVFI_TRY(launch_census_reduce(f.census, out, P.nb, totals, (hipStream_t)stream), "forward_census");
+    return EMAVFI_OK;
+}
+
+int emavfi_mdcn_census(int B, int C, int H, int W, int dtype, int flags, const void *workspace, size_t workspace_bytes, unsigned long long *out, void *stream)
+{
+    Plan P;
+    bool split; int in_f16, out_f16;
+    if (const int rc = mdcn_plan(P, C, dtype, flags, split, in_f16, out_f16); rc != EMAVFI_OK) return rc;
+    if (B < 1 || H < 1 || W < 1) return fail(EMAVFI_E_ARG, "mdcn_census: B, H, W must be >= 1");
+    if (!workspace || !out) return fail(EMAVFI_E_ARG, "mdcn_census: null pointer");
+    Workspace ws{(char *)const_cast<void *>(workspace), workspace_bytes, 0};
+    MdcnBuffers m;
+    mdcn_carve(P, ws, m, B, H, W, split);
+    if (ws.used > workspace_bytes) return fail(EMAVFI_E_WORKSPACE, "mdcn_census: this stage's workspace has %zu bytes, got %zu", ws.used, workspace_bytes);
+    unsigned long long totals[kMaxBlocks] = {};
+    totals[0] = pack_fuses(P, 0) && P.dcn[0].pack3 == 1 ? pack3_wave_taps(B, H, W) : 0ull;
+    EMAVFI_TRY(launch_census_reduce(m.census, out, 1, totals, (hipStream_t)stream), "mdcn_census");
+    return EMAVFI_OK;
 }
 
 // ---- context_encoding and reconstruction as stage-level entries (SURVEY 8b's proposed emavfi_context / emavfi_reconstruct): the model is

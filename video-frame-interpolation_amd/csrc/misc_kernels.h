@@ -71,3 +71,6 @@ int launch_preprocess_u8(const unsigned char *src, float *dst, int B, int H, int
                          hipStream_t s);
 int launch_postprocess_u8(const float *src, unsigned char *dst, int B, int H, int W, int C, const double *mean, const double *stdv,
                           int denorm, hipStream_t s);
+// deform_pack3.inl's census: sums the 64 atomic slots of each of `nblocks` launches ([block][64][4] u32) into out[block][4] u64 =
+// {fix-up wave-taps, totals[block], samples outside the window, max |offset| as fp32 bits}
+int launch_census_reduce(const unsigned *census, unsigned long long *out, int nblocks, const unsigned long long *totals, hipStream_t s);

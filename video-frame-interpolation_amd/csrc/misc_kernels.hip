@@ -1110,3 +1110,31 @@ int launch_postprocess_u8(const float *src, unsigned char *dst, int B, int H, in
     postprocess_u8_kernel<<<grid, 256, 0, s>>>(src, dst, B, H, W, C, st, denorm);
     return (int)hipGetLastError();
 }
+
+// ---- census of the one-launch packs (deform_pack3.inl, DeformParams::census): one wave per block adds the 64 slots
+struct CensusTotals { unsigned long long t[8]; };
+__global__ void census_reduce_kernel(const unsigned *__restrict__ census, unsigned long long *__restrict__ out, CensusTotals totals)
+{
+    const int blk = blockIdx.x, lane = threadIdx.x;   // 64 threads
+    const unsigned *c = census + ((size_t)blk * 64 + lane) * 4;
+    unsigned long long fix = c[0], par = c[1];
+    unsigned mx = c[2];
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) {
+        fix += __shfl_xor(fix, sh);
+        par += __shfl_xor(par, sh);
+        const unsigned o = __shfl_xor(mx, sh);
+        mx = o > mx ? o : mx;
+    }
+    if (lane == 0) {
+        out[blk * 4 + 0] = fix; out[blk * 4 + 1] = totals.t[blk]; out[blk * 4 + 2] = par; out[blk * 4 + 3] = mx;
+    }
+}
+int launch_census_reduce(const unsigned *census, unsigned long long *out, int nblocks, const unsigned long long *totals, hipStream_t s)
+{
+    if (nblocks < 1 || nblocks > 8) return (int)hipErrorInvalidValue;
+    CensusTotals t{};
+    for (int i = 0; i < nblocks; ++i) t.t[i] = totals[i];
+    census_reduce_kernel<<<nblocks, 64, 0, s>>>(census, out, t);
+    return (int)hipGetLastError();
+}

@@ -49,6 +49,8 @@ _PROTOTYPES = {
     "emavfi_mdcn_workspace_bytes": (c_size_t, [c_int] * 6),
     "emavfi_mdcn": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
     "emavfi_mdcn_profiled": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p, c_size_t, POINTER(c_void_p), c_int, c_void_p]),
+    "emavfi_forward_census": (c_int, [c_int] * 7 + [c_void_p, c_size_t, c_void_p, c_void_p]),
+    "emavfi_mdcn_census": (c_int, [c_int] * 6 + [c_void_p, c_size_t, c_void_p, c_void_p]),
     "emavfi_context_workspace_bytes": (c_size_t, [c_int] * 5),
     "emavfi_context": (c_int, [c_void_p, POINTER(c_void_p), c_void_p] + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "emavfi_reconstruct_workspace_bytes": (c_size_t, [c_int] * 5),
@@ -360,6 +362,36 @@ def mdcn(x, offset_weight, offset_bias, dcn_weight, dcn_bias, dtype="fp32", flag
             check(L.emavfi_mdcn(x.data_ptr(), ow.data_ptr(), ob.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None, y.data_ptr(),
                                 B, C, H, W, dt, flags, ws.data_ptr(), ws.numel(), _stream()), "emavfi_mdcn")
     return y
+
+
+def _census_rows(raw, samples):
+    """[blocks][4] u64 (device) -> list of dicts (one blocking copy)"""
+    import struct
+    rows = []
+    for fix, total, parked, mx in raw.cpu().tolist():
+        if total == 0:
+            rows.append(None)   # this block did not run the one-launch kernel
+            continue
+        rows.append({"fixup_wave_taps": fix, "wave_taps": total, "fixup_share": fix / total, "samples_outside_window": parked,
+                     "samples_outside_share": parked / samples, "abs_offset_px_max": struct.unpack("<f", struct.pack("<I", mx & 0xffffffff))[0]})
+    return rows
+
+
+def mdcn_census(B, C, H, W, dtype="bf16", flags=0, device=None):
+    """What the one-launch pack kernel counted during the LAST lib.mdcn(...) call of this shape on the current stream
+    (include/emavfi.h, emavfi_mdcn_census): [{fixup_wave_taps, wave_taps, fixup_share, samples_outside_window, ...}] or [None]."""
+    import torch
+    L = load()
+    dt = dtype_code(dtype)
+    dev = torch.device(device if device is not None else "cuda")
+    n = L.emavfi_mdcn_workspace_bytes(B, C, H, W, dt, flags)
+    if n == 0:
+        raise RuntimeError(f"emavfi_mdcn_census: {last_error()}")
+    ws = workspace(n, dev)
+    out = torch.zeros(1, 4, dtype=torch.int64, device=ws.device)
+    with torch.cuda.device(ws.device):
+        check(L.emavfi_mdcn_census(B, C, H, W, dt, flags, ws.data_ptr(), ws.numel(), out.data_ptr(), _stream()), "emavfi_mdcn_census")
+    return _census_rows(out, B * H * W * 9)
 
 
 def _stage(entry, ws_entry, x, params, out_shape, mid, dtype, what):

@@ -351,6 +351,7 @@ class EMA_VFI(nn.Module):
                     _lib.check(L.emavfi_forward(C, self.mid_channels, self.num_blocks, packed.data_ptr(), packed.numel(), f1.data_ptr(),
                                                 f2.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, dt, taps_arg,
                                                 _lib._stream()), "emavfi_forward")
+            self._last_call = (dev, torch.cuda.current_stream(dev).cuda_stream, B, H, W, dt, nws)
         # under autocast the reference's reconstruction tail is fp16, so its frame is an fp16 tensor (the values computed
         # here are fp16-representable: the conversion is exact)
         out = out.half() if dt == _lib.AMP16 else out.to(frame1.dtype)
@@ -358,6 +359,25 @@ class EMA_VFI(nn.Module):
             taps["out"] = out
             return out, taps
         return out
+
+    def pack_census(self):
+        """What the one-launch ModulatedDeformConvPack kernels of the LAST one-sequence forward on the current stream counted while
+        they ran (include/emavfi.h, emavfi_forward_census): per attention block a dict {fixup_wave_taps, wave_taps, fixup_share,
+        samples_outside_window, samples_outside_share, abs_offset_px_max}, or None for a block that ran other kernels (fp32 / autocast
+        modes, other widths).  The reference bounds its offsets nowhere (ema_vfi.py:55-60); the kernel's staged window holds offsets up
+        to +-2 px beyond the tap and pays for every (4 x 16 pixels, tap) group with a sample outside it.  One blocking D2H copy."""
+        last = getattr(self, "_last_call", None)
+        if last is None:
+            raise RuntimeError("EMA_VFI.pack_census: no one-sequence forward has run yet")
+        dev, stream, B, H, W, dt, nws = last
+        if torch.cuda.current_stream(dev).cuda_stream != stream:
+            raise RuntimeError("EMA_VFI.pack_census: call it on the stream the forward ran on")
+        ws = _lib.workspace(nws, dev)
+        out = torch.zeros(self.num_blocks, 4, dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().emavfi_forward_census(self.in_channels, self.mid_channels, self.num_blocks, B, H, W, dt, ws.data_ptr(), ws.numel(),
+                                                         out.data_ptr(), _lib._stream()), "emavfi_forward_census")
+        return _lib._census_rows(out, B * H * W * 9)
 
     def _forward_pipelined(self, L, packed, f1, f2, out, dt, pieces, _events=None):
         """The batch as `pieces` contiguous slices alternating between the caller's stream and one side stream, piece k + 1 starting
@@ -377,34 +397,46 @@ class EMA_VFI(nn.Module):
             side = _lib.side_stream(dev, which=1)
         cuts = [B * k // pieces for k in range(pieces + 1)]
         key = (dev.index, cur.cuda_stream)
-        fork, join = hip.event(key + ("fork",)), hip.event(key + ("join",))
-        hip.record(fork, cur)          # the frames (and the packed blob) are ready on the caller's stream
-        hip.wait(side, fork)
         per = (_events[1] // pieces) if _events is not None else 0
+        if _events is not None:
+            # every piece runs the FULL launch list: an array sized for one sequence would leave most of each piece's launches
+            # unbracketed and the caller reading never-recorded events
+            nl = L.emavfi_forward_launches(C, self.mid_channels, self.num_blocks, 1, H, W, dt, None, 0, None, None, 0)
+            if per < 2 * nl:
+                raise ValueError(f"EMA_VFI: a pipelined forward of {pieces} pieces needs {pieces} x 2 x {nl} events, got {_events[1]}")
         front_prev = None
+        # hipEventCreateWithFlags binds an event to the CURRENT device: everything that creates, records or waits on one runs under
+        # the model's device (a model on cuda:1 while cuda:0 is current got hipErrorInvalidHandle here)
         with torch.cuda.device(dev):
-            for k in range(pieces):
-                b0, b1 = cuts[k], cuts[k + 1]
-                s = cur if k % 2 == 0 else side
-                if front_prev is not None:
-                    hip.wait(s, front_prev)
-                front = hip.event(key + ("stage", k))
-                with torch.cuda.stream(s):
-                    nws = L.emavfi_workspace_bytes(C, self.mid_channels, self.num_blocks, b1 - b0, H, W, dt)
-                    if nws == 0:
-                        raise RuntimeError(f"EMA_VFI: {_lib.last_error()}")
-                    ws = _lib.workspace(nws, dev)
-                    stage = (c_void_p * 3)(*[front if i == self.pipeline_stagger else None for i in range(3)])
-                    evp = None
-                    if _events is not None:
-                        evp = cast(c_void_p(_events[0].value + k * per * ctypes.sizeof(c_void_p)), POINTER(c_void_p))
-                    _lib.check(L.emavfi_forward_staged(C, self.mid_channels, self.num_blocks, packed.data_ptr(), packed.numel(),
-                                                       f1[b0:b1].data_ptr(), f2[b0:b1].data_ptr(), out[b0:b1].data_ptr(), ws.data_ptr(), ws.numel(),
-                                                       b1 - b0, H, W, dt, cast(stage, POINTER(c_void_p)), evp, per, c_void_p(s.cuda_stream)),
-                               "emavfi_forward_staged")
-                front_prev = front if self.pipeline_stagger >= 0 else None
-        hip.record(join, side)
-        hip.wait(cur, join)
+            fork, join = hip.event(key + ("fork",)), hip.event(key + ("join",))
+            hip.record(fork, cur)          # the frames (and the packed blob) are ready on the caller's stream
+            hip.wait(side, fork)
+            try:
+                for k in range(pieces):
+                    b0, b1 = cuts[k], cuts[k + 1]
+                    s = cur if k % 2 == 0 else side
+                    if front_prev is not None:
+                        hip.wait(s, front_prev)
+                    front = hip.event(key + ("stage", k))
+                    with torch.cuda.stream(s):
+                        nws = L.emavfi_workspace_bytes(C, self.mid_channels, self.num_blocks, b1 - b0, H, W, dt)
+                        if nws == 0:
+                            raise RuntimeError(f"EMA_VFI: {_lib.last_error()}")
+                        ws = _lib.workspace(nws, dev)
+                        stage = (c_void_p * 3)(*[front if i == self.pipeline_stagger else None for i in range(3)])
+                        evp = None
+                        if _events is not None:
+                            evp = cast(c_void_p(_events[0].value + k * per * ctypes.sizeof(c_void_p)), POINTER(c_void_p))
+                        _lib.check(L.emavfi_forward_staged(C, self.mid_channels, self.num_blocks, packed.data_ptr(), packed.numel(),
+                                                           f1[b0:b1].data_ptr(), f2[b0:b1].data_ptr(), out[b0:b1].data_ptr(), ws.data_ptr(), ws.numel(),
+                                                           b1 - b0, H, W, dt, cast(stage, POINTER(c_void_p)), evp, per, c_void_p(s.cuda_stream)),
+                                   "emavfi_forward_staged")
+                    front_prev = front if self.pipeline_stagger >= 0 else None
+            finally:
+                # also when a piece failed to enqueue: `out` and the frames are known to the caching allocator on the caller's stream
+                # only, so whatever the side stream already holds must be ordered in front of their reuse
+                hip.record(join, side)
+                hip.wait(cur, join)
         # the caching allocator knows `out` (and the frames) only on the caller's stream; the side stream's work on them is ordered
         # before everything the caller enqueues from here on by the join above
 
