@@ -331,6 +331,46 @@ def stream_legs(sd, dev, B, H, W):
     return out
 
 
+def stream_leg_one_rank(model, rank, world, B, H, W, pairs_per_rank=64, reps=2):
+    """N > 1: THIS rank's shard of one global stream through the streaming harness - uint8 host frames in pinned
+    buffers in, uint8 host frames out, PCIe included (reference inference.py:146-205 feeds ONE process; SURVEY 8(e) / section 7 name host
+    feeding as the 8-GPU risk).  The stream has world x pairs_per_rank pairs (BASELINE configs[3]: 64 pairs per 8 GPUs x 8; here 64 per
+    rank so that pipeline fill / drain does not dominate); FrameInterpolator.run(frames, rank, world) takes this rank's contiguous
+    segment (dist.shard_range).  All ranks stream at the same time (the caller puts a barrier in front).  Returns (pairs, frames out,
+    best-of-`reps` seconds)."""
+    import numpy as np
+    from emavfi import FrameInterpolator, synth
+    u8, _ = synth.synthetic_frames_u8(3, 1, H, W, "natural")
+    base = [np.roll(u8[0], 3 * i, axis=1) for i in range(65)]
+    frames = [base[i % 65] for i in range(world * pairs_per_rank + 1)]
+    fi = FrameInterpolator(model, interpolation_factor=1, batch_pairs=B, copy_out=False)
+    mine, _, _, _ = FrameInterpolator.segment(len(frames), 1, rank, world)
+    sum(1 for _ in fi.run(frames[:25]))                       # warm-up: buffers, the half-size first batch
+    best, n = None, 0
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = sum(1 for _ in fi.run(frames, rank, world))
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        best = el if best is None else min(best, el)
+    return len(mine), n, best
+
+
+def stream_leg_summary(rows, value):
+    """rows: [rank, pairs, frames out, seconds] per rank (gathered) -> the keys of the bench line"""
+    rows = sorted(rows)
+    per_rank = [round(r[1] / r[3], 2) for r in rows]
+    agg = sum(r[1] for r in rows) / max(r[3] for r in rows)
+    return {"stream_pcie_per_rank": per_rank, "stream_pcie_aggregate": round(agg, 2), "unit": "interpolated frames/s",
+            "pairs_per_rank": [int(r[1]) for r in rows], "frames_out_per_rank": [int(r[2]) for r in rows],
+            "seconds_per_rank": [round(r[3], 4) for r in rows],
+            "fraction_of_resident_value": None if not value else round(agg / value, 4),
+            "note": "every rank streams its contiguous segment of ONE global stream through FrameInterpolator at the same time: uint8 "
+                    "host frames in and out (pinned buffers, hipMemcpyAsync + device pre / post kernels on side streams); aggregate = all "
+                    "pairs / the slowest rank's time; PCIe- and host-feeding-inclusive, never part of `value`"}
+
+
 def fixup_census(raw, H, W):
     """Which deformable samples leave the pack kernel's staged window (deform_pack3.inl: 16 x 16-pixel tiles, a 23 x 23-pixel window
     = the tile + 1 tap + R = 2 px of offset reach + 1 bilinear neighbour), restated from the kernel's own test: the sample's
@@ -609,11 +649,20 @@ def rehearse(args, rank, world):
     mine = time.perf_counter() - t0
     elapsed = vdist.max_over_ranks(mine, None)
     seen = vdist.all_gather_floats([float(rank), mine / args.steps * 1e3], None)
+    # the per-rank stream leg's plumbing (segment sharding + gather + summary) with a stand-in for the harness: every rank "streams"
+    # ITS segment of a (world x 64 + 1)-frame stream - the host logic FrameInterpolator.segment is the real one
+    from emavfi import FrameInterpolator
+    pairs_mine, lo, hi, tail = FrameInterpolator.segment(world * 64 + 1, 1, rank, world)
+    vdist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.0005 * len(pairs_mine) * (1 + 0.1 * rank))
+    rows = vdist.all_gather_floats([float(rank), float(len(pairs_mine)), float(2 * len(pairs_mine) + (1 if tail else 0)), time.perf_counter() - t0], None)
     if rank == 0:
         print(json.dumps({"metric": "interpolated_frames_per_sec_720p_2x", "value": None, "unit": "frames/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
                           "higher_is_better": True, "scaling": "weak", "rehearsal": True, "backend": backend,
-                          "ranks_seen": sorted(int(r[0]) for r in seen), "ms_per_step_per_rank": [round(r[1], 3) for r in seen]}), flush=True)
+                          "ranks_seen": sorted(int(r[0]) for r in seen), "ms_per_step_per_rank": [round(r[1], 3) for r in seen],
+                          "also_stream_pcie_per_rank": stream_leg_summary(rows, None)}), flush=True)
     if world > 1:
         vdist.barrier()
         torch.distributed.destroy_process_group()
@@ -689,6 +738,20 @@ def main():
     if bad:
         raise SystemExit(f"bench.py: non-finite output frame on rank(s) {bad} (a foreign / corrupted packed blob yields an all-NaN frame)")
 
+    # N > 1: the PCIe-inclusive leg per rank (at N = 1 the extras below carry also_stream_pcie); gathered INSIDE a collective like the
+    # rank census, so that no rank-local failure leaves the others blocked
+    stream_rows = None
+    if world > 1 and not args.no_extras and args.dtype == "bf16":
+        fence()
+        try:
+            pairs, n_out, secs = stream_leg_one_rank(model, rank, world, B, H, W)
+        except Exception as e:   # noqa: BLE001 - reported through the gather, raised on every rank
+            print(f"bench.py: rank {rank}: stream leg failed: {e}", file=sys.stderr, flush=True)
+            pairs, n_out, secs = -1, -1, 1.0
+        stream_rows = vdist.all_gather_floats([float(rank), float(pairs), float(n_out), float(secs)], dev)
+        if any(r[1] < 0 for r in stream_rows):
+            raise SystemExit(f"bench.py: the stream leg failed on rank(s) {sorted(int(r[0]) for r in stream_rows if r[1] < 0)}")
+
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         frames = world * B * args.steps
@@ -735,6 +798,8 @@ def main():
             warp = warp_in_forward(table, agg, args.dtype, B * H * W)
             if warp:
                 res["roofline_warp_in_forward"] = warp
+        if stream_rows is not None:
+            res["also_stream_pcie_per_rank"] = stream_leg_summary(stream_rows, value)
         if world == 1 and not args.no_extras:
             def timed_alt(dtype, b, h, w, steps):
                 alt = EMA_VFI(compute_dtype=dtype).to(dev).eval()

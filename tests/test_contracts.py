@@ -117,6 +117,12 @@ def test_bench_two_ranks_the_way_the_driver_calls_it():
     assert r["n_gpus"] == 2 and r["ranks_seen"] == [0, 1] and len(r["ms_per_step_per_rank"]) == 2 and r["backend"] == "gloo"
     assert r["value"] > 0 and abs(r["value"] - 2 * 1 * 2 / (r["ms_per_step"] * 2e-3)) / r["value"] < 0.02   # whole-job frames / MAX time
     assert "roofline" in r and "cpu_baseline" not in r        # the CPU baseline is rank 0's at N = 1 only
+    # round 6: the PCIe-inclusive leg per rank - every rank streams ITS 64-pair segment of one 129-frame stream
+    sp = r["also_stream_pcie_per_rank"]
+    assert sp["pairs_per_rank"] == [64, 64] and sp["frames_out_per_rank"] == [128, 129] and len(sp["stream_pcie_per_rank"]) == 2
+    assert all(v > 0 for v in sp["stream_pcie_per_rank"]) and sp["stream_pcie_aggregate"] > 0
+    assert abs(sp["stream_pcie_aggregate"] - 128 / max(sp["seconds_per_rank"])) <= 0.02 * sp["stream_pcie_aggregate"]
+    assert abs(sp["fraction_of_resident_value"] - sp["stream_pcie_aggregate"] / r["value"]) < 1e-3
 
 
 @pytest.mark.gpu

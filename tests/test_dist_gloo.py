@@ -81,6 +81,11 @@ def test_bench_launches_its_own_ranks_the_way_the_driver_calls_it():
     assert res["n_gpus"] == 2 and res["ranks_seen"] == [0, 1] and len(res["ms_per_step_per_rank"]) == 2
     assert res["steps"] == 3 and res["warmup"] == 1 and res["rehearsal"] is True and res["value"] is None
     assert res["ms_per_step"] >= max(res["ms_per_step_per_rank"]) - 1e-3      # MAX over ranks, barrier included
+    # the per-rank PCIe leg's plumbing (round 6): segments of one global stream, gathered through the backend, aggregate = pairs / MAX time
+    sp = res["also_stream_pcie_per_rank"]
+    assert sp["pairs_per_rank"] == [64, 64] and sp["frames_out_per_rank"] == [128, 129] and len(sp["stream_pcie_per_rank"]) == 2
+    assert abs(sp["stream_pcie_aggregate"] - 128 / max(sp["seconds_per_rank"])) <= 0.02 * sp["stream_pcie_aggregate"]
+    assert sp["fraction_of_resident_value"] is None
     # the torchrun form of the contract still works, unchanged
     import socket
     with socket.socket() as s:

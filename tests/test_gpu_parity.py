@@ -337,7 +337,7 @@ def test_forward_large_offsets_vs_reference_run(dtype, fixture):
             m(f1.to(DEV), f2.to(DEV))
         rows = m.pack_census()
         print("  census:", [None if r is None else (round(r["fixup_share"], 3), round(r["samples_outside_share"], 4), round(r["abs_offset_px_max"], 1)) for r in rows])
-        assert all(r is not None and r["fixup_share"] > (0.5 if tag == "off16" else 0.2) for r in rows)
+        assert all(r is not None and r["fixup_share"] > (0.3 if tag == "off16" else 0.05) for r in rows)
 
 
 def test_forward_config2_batch16_256():

@@ -33,8 +33,8 @@ sel = buf[buf[:, 6] == 1]
 n_out = ((sel[:, 4] >> np.uint64(32)) & np.uint64(0xff)).astype(np.float64)      # taps of the wave with a lane outside the window, of 9
 n_lanes = (sel[:, 4] >> np.uint64(40)).astype(np.float64)                          # samples outside, of 9 * 64
 fixup = (sel[:, 2] >> np.uint64(32)).astype(np.float64)                            # cycles in the fix-up pass (round 6)
-sel[:, 4] &= np.uint64(0xffffffff)
-sel[:, 2] &= np.uint64(0xffffffff)
+for col in (0, 1, 2, 3, 4, 5):   # (bits 32..63 carry the fix-up's detail: tools/fixup_stamps.py)
+    sel[:, col] &= np.uint64(0xffffffff)
 v = sel.astype(np.float64)
 names = ["prologue (window DMA + barrier)", "offset_conv", "geometry + tail of all 9 taps (up front)",
          "gather + blend + MFMA steps (9 taps)", "epilogue stores (drained)", "total"]

@@ -48,12 +48,16 @@ struct Pack3 {
     // fix-up arena (round 6): once all four waves have left the tap loop the window is dead, and every wave owns a quarter of it as an
     // arena of 32 entries = {4 corners x 9 pieces | one pad slot} (an odd number of 16-byte slots: conflict-free like the window's pixels);
     // entry 31 is all zeros (what lanes without a sample in the round read against zero weights)
-    static constexpr int ENT_SLOTS = 4 * SP + 1, ENT_BYTES = ENT_SLOTS * 16, NENT = 31, ZERO_ENT = NENT * ENT_BYTES;   // 592 B entries
+    // Layout: piece-major - row (2 i + hb) = 32 slots x 16 B holds piece i % 9 of corner (2 hb + i / 9) of every slot, i = 0..17 - because an
+    // LDS-DMA instruction writes lane-linear: instruction i fetches row 2 i from lanes 0..31 and row 2 i + 1 from lanes 32..63, each lane
+    // ONE slot's corner pair (2 hb, 2 hb + 1) for the whole round: a DMA instruction costs one 64-bit add.  Slot 31 is all zeros.
+    static constexpr int NENT = 31, SLOTS = 32, AROW = SLOTS * 16, ADMA = 2 * SP;         // 512 B rows, 18 DMA instructions per round
     static constexpr int ARENA_BYTES = (WIN_BYTES / 4) & ~15;                             // 19 040 B per wave
+    static constexpr int A_KG = 2 * 2 * AROW, A_H = 2 * AROW, A_C1 = SP * 2 * AROW, A_C2 = AROW;   // k-group / piece / corner strides
     static constexpr int SYNC_OFF = W3_OFF + W3_BYTES;                                    // u32: waves that have left the tap loop
     static constexpr int TAB_OFF = SYNC_OFF + 16, TAB_BYTES = 4 * 32 * 4;                 // per wave 32 corner descriptors
     static constexpr int LDS_BYTES = TAB_OFF + TAB_BYTES;                                 // 81 312 B: two workgroups per CU
-    static_assert((NENT + 1) * ENT_BYTES <= ARENA_BYTES && (ENT_SLOTS & 1) == 1, "arena");
+    static_assert(4 * SP * AROW <= ARENA_BYTES && NENT < SLOTS, "arena");
     // packed weights (bytes): DCN = [tap][kg 4][nf 2][lane][16] | W3 table | tail [j 3][nf 3][lane][16]
     static constexpr int DCN_TAP = 4 * 2 * 1024, DCN_W3 = 9 * DCN_TAP, DCN_TAIL = DCN_W3 + W3_BYTES, DCN_BYTES = DCN_TAIL + 9 * 1024;
     // offset_conv = [tap][kg 4][lane][16] | tail [j 3][lane][16]
@@ -443,7 +447,8 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
     // wnext = the NEXT tap's first weight fragments (null: none).  The last step's MFMAs stay pending in (xf_prev, w3_prev, wq[1]).
     auto tap_body = [&](auto arena_tag, const int tap, const char *wnext, const unsigned g0, const unsigned g1, const unsigned g2) {
         constexpr bool ARENA = decltype(arena_tag)::value;
-        constexpr int OFFC[4] = {0, C::PSB, ARENA ? 2 * C::PSB : C::ROWB, ARENA ? 3 * C::PSB : C::ROWB + C::PSB};
+        constexpr int OFFC[4] = {0, ARENA ? C::A_C1 : C::PSB, ARENA ? C::A_C2 : C::ROWB, ARENA ? C::A_C1 + C::A_C2 : C::ROWB + C::PSB};
+        constexpr int KGS = ARENA ? C::A_KG : 32, HS = ARENA ? C::A_H : 16;   // byte strides of a k-group (two pieces) / of this half-lane's piece
         const char *wtap = wbase_g + (size_t)tap * C::DCN_TAP;   // wave-uniform
         unsigned base[2], w01[2], w23[2];
         {
@@ -453,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
             };
             both(g1, w01); both(g2, w23);
             // swap(a, b) = {(a.lo, b.lo), (a.hi, b.hi)}: the h = 1 receivers take b = base + 16 (their piece of the pixel)
-            const auto sw = __builtin_amdgcn_permlane32_swap(g0, g0 + 16u, false, false);
+            const auto sw = __builtin_amdgcn_permlane32_swap(g0, g0 + (unsigned)HS, false, false);
             base[0] = sw[0]; base[1] = sw[1];
             if (!ARENA && (EMAVFI_P3_ABL & 2)) { base[0] = xbase[0] + (unsigned)(tap * 16); base[1] = xbase[1] + (unsigned)(tap * 16); }
         }
@@ -469,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
             const int kg = s >> 1, m = s & 1;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const u32x4_t v = lds_read16(lds_r + base[m] + (unsigned)(kg * 32 + OFFC[c]));
+                const u32x4_t v = lds_read16(lds_r + base[m] + (unsigned)(kg * KGS + OFFC[c]));
                 d[c][0] = v[0]; d[c][1] = v[1]; d[c][2] = v[2]; d[c][3] = v[3];
             }
         };
@@ -559,12 +564,18 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's last window reads have returned
     if (lane == 0) __hip_atomic_fetch_add(sync_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     unsigned n_parked = 0;
+#if EMAVFI_DEFORM_STAMPS
+    unsigned long long fx_wait = 0, fx_issue = 0, fx_land = 0, fx_taps = 0;
+#endif
     if (__builtin_expect(fb_taps != 0, 0)) {
 #if EMAVFI_DEFORM_STAMPS
         cnt_out += __popc(fb_taps);
 #endif
         // every wave of the workgroup reaches the increment above unconditionally: the wait ends
-        while (*reinterpret_cast<volatile lds_u32_t *>(sync_word) < (unsigned)C::WAVES) __builtin_amdgcn_s_sleep(4);
+        while (*reinterpret_cast<volatile lds_u32_t *>(sync_word) < (unsigned)C::WAVES) __builtin_amdgcn_s_sleep(1);
+#if EMAVFI_DEFORM_STAMPS
+        { DEFORM_STAMP(t_); fx_wait = t_ - ts_taps_done; }
+#endif
         const unsigned lds0 = (unsigned)(size_t)(lds_char_t *)smem;
         const unsigned arena = (unsigned)__builtin_amdgcn_readfirstlane(wave * C::ARENA_BYTES);   // (an SGPR: the DMA's M0 operand)
         lds_u32_t *table = reinterpret_cast<lds_u32_t *>((lds_char_t *)smem + C::TAB_OFF + wave * 128);
@@ -588,21 +599,21 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
             w01h = __builtin_bit_cast(unsigned, f16x2_t{(half_t)w4[0], (half_t)w4[1]});
             w23h = __builtin_bit_cast(unsigned, f16x2_t{(half_t)w4[2], (half_t)w4[3]});
         };
-        // one LDS-DMA instruction = 64 consecutive 16-byte slots of the arena; lane L of instruction i fills slot q = 64 i + L =
-        // entry q / 37, corner (q % 37) / 9, piece (q % 37) % 9 (slot 36 of an entry: pad)
+        // one LDS-DMA instruction = 64 consecutive 16-byte slots = two rows of the arena (Pack3: piece-major layout)
         auto dma = [&](const char *src, unsigned dst) {
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(__builtin_amdgcn_readfirstlane(dst)) : "memory", "m0");
         };
-        if (lane < C::ENT_SLOTS) dma(zeros, lds0 + arena + (unsigned)C::ZERO_ENT);   // the zero entry, once
 #pragma unroll 1
         for (unsigned left = fb_taps; left != 0; left &= left - 1)
             n_parked += (unsigned)__popcll(__ballot(((lane_fb >> __builtin_ctz(left)) & 1u) != 0));
         const bool convert = std::is_same<TS, bf16_t>::value && !p.in_f16;
         const char *wtl_fx = wbase_g + C::DCN_TAIL;
+        const unsigned my_slot = (unsigned)lane & 31u, hb = (unsigned)lane >> 5;
 #pragma unroll 1
         for (unsigned rbase = 0; rbase < n_parked; rbase += (unsigned)C::NENT) {
             const unsigned n_ent = min((unsigned)C::NENT, n_parked - rbase);
-            // -- A: the round's corner descriptors
+            DEFORM_STAMP(tr0);
+            // -- A: the round's corner descriptors, slot by slot
             unsigned round_taps = 0, prefix = 0;
 #pragma unroll 1
             for (unsigned left = fb_taps; left != 0; left &= left - 1) {
@@ -619,22 +630,24 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
                 }
                 prefix += cnt;
             }
-            // -- B: fetch the entries (the table reads return before the first DMA leaves; the DMA is inline asm, so hipcc places no
-            // waits for it: C below does)
-            const unsigned lim = n_ent * (unsigned)C::ENT_SLOTS, ninst = (lim + 63u) >> 6;
+            // -- B: fetch.  Lane (slot, hb) owns corners 2 hb and 2 hb + 1 of its slot: instructions 0..8 their first, 9..17 their second,
+            // piece by piece (piece 8 = the tail channels, from the compact tail buffer when the pack has one).  Slots past the round's
+            // entries and slot 31 read the zero page.  The DMA is inline asm: hipcc places no waits for it, C below does.
             {
-                unsigned e = lane >= C::ENT_SLOTS ? 1u : 0u, rem = (unsigned)lane - e * (unsigned)C::ENT_SLOTS;
-#pragma unroll 1
-                for (unsigned i = 0; i < ninst; ++i) {
-                    const unsigned d = table[min(e, 31u)];
-                    const unsigned cr = (rem * 57u) >> 9, pc = rem - cr * 9u;               // corner 0..3 (4: the pad slot), piece 0..8
-                    const unsigned cpx = (d & 0xffffffu) + ((cr & 1u) ? ((d >> 24) & 1u) : 0u) + (((cr & 2u) && ((d >> 25) & 1u)) ? (unsigned)W : 0u);
-                    const char *src = pc == 8u && tplane ? tplane + (size_t)__umul24(cpx, tail_bytes) : gplane + (size_t)(__umul24(cpx, ps_bytes) + pc * 16u);
-                    if (cr == 4u) src = zeros;
-                    if (i * 64u + (unsigned)lane < lim) dma(src, lds0 + arena + i * 1024u);
-                    rem += 64u - (unsigned)C::ENT_SLOTS; e += 1u;
-                    if (rem >= (unsigned)C::ENT_SLOTS) { rem -= (unsigned)C::ENT_SLOTS; e += 1u; }
-                }
+                const unsigned d = table[my_slot];
+                const bool live = my_slot < n_ent;
+                const unsigned cpa = (d & 0xffffffu) + (hb && ((d >> 25) & 1u) ? (unsigned)W : 0u), cpb = cpa + ((d >> 24) & 1u);
+                const char *pa = live ? gplane + (size_t)__umul24(cpa, ps_bytes) : zeros, *pb = live ? gplane + (size_t)__umul24(cpb, ps_bytes) : zeros;
+                const char *ta = !live ? zeros : (tplane ? tplane + (size_t)__umul24(cpa, tail_bytes) : pa + 128);
+                const char *tb = !live ? zeros : (tplane ? tplane + (size_t)__umul24(cpb, tail_bytes) : pb + 128);
+                const unsigned step = live ? 16u : 0u;
+                const unsigned dst0 = lds0 + arena;
+#pragma unroll
+                for (int i = 0; i < C::SP - 1; ++i) { dma(pa, dst0 + (unsigned)(i * 1024)); pa += step; }
+                dma(ta, dst0 + (unsigned)((C::SP - 1) * 1024));
+#pragma unroll
+                for (int i = 0; i < C::SP - 1; ++i) { dma(pb, dst0 + (unsigned)((C::SP + i) * 1024)); pb += step; }
+                dma(tb, dst0 + (unsigned)((2 * C::SP - 1) * 1024));
             }
             // the round's first weight fragments travel under the DMA
             {
@@ -644,18 +657,19 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
                 xf_prev = f16x8{}; w3_prev = f16x8{};
             }
             // -- C: landed (in-order return: the fragments above too); bf16 storage: every lane converts the slots it fetched
+            DEFORM_STAMP(tr1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (convert) {
-#pragma unroll 1
-                for (unsigned i = 0; i < ninst; ++i) {
-                    if (i * 64u + (unsigned)lane < lim) {
-                        lds_char_t *q = (lds_char_t *)smem + arena + i * 1024u + lane16;
-                        const u32x4_t v = to_f16_piece<TS>(lds_read16(q));
-                        *reinterpret_cast<__attribute__((address_space(3))) u32x4_t *>(q) = v;
-                    }
+            DEFORM_STAMP(tr2);
+            if (convert && my_slot < n_ent) {   // (the other slots hold zeros)
+#pragma unroll
+                for (int i = 0; i < C::ADMA; ++i) {
+                    lds_char_t *q = (lds_char_t *)smem + arena + (unsigned)(i * 1024) + lane16;
+                    const u32x4_t v = to_f16_piece<TS>(lds_read16(q));
+                    *reinterpret_cast<__attribute__((address_space(3))) u32x4_t *>(q) = v;
                 }
             }
             // -- D: the round's taps on the arena
+            DEFORM_STAMP(tr3);
             prefix = 0;
 #pragma unroll 1
             for (unsigned left = fb_taps; left != 0; left &= left - 1) {
@@ -669,20 +683,25 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
                 const bool mine = parked && slot < n_ent;
                 unsigned desc, w01h, w23h;
                 fix_geom(tap, mine, desc, w01h, w23h);
-                const unsigned ent = arena + (mine ? slot * (unsigned)C::ENT_BYTES : (unsigned)C::ZERO_ENT);
+                const unsigned ent = arena + (mine ? slot : (unsigned)C::NENT) * 16u;
+                // the tail's weight fragments (one im2col k-group with this tap's slot alone) travel under the tap's steps
+                const int j = tap >> 2, hsel = (tap >> 1) & 1, u = tap & 1;
+                f16x8 wt[3];
+#pragma unroll
+                for (int n = 0; n < 3; ++n) wt[n] = *reinterpret_cast<const f16x8 *>(wtl_fx + (j * 3 + n) * 1024 + (n < 2 ? lane16 : t3lane16));
                 const unsigned later = round_taps & ~((2u << tap) - 1u);
                 tap_body(std::true_type{}, tap, later ? wbase_g + (size_t)__builtin_ctz(later) * C::DCN_TAP : nullptr, ent, w01h, w23h);
-                // the tail channels (64..66) of the same samples: one im2col k-group with this tap's slot alone
+                // the tail channels (64..66) of the same samples
                 {
+                    constexpr int OC[4] = {0, C::A_C1, C::A_C2, C::A_C1 + C::A_C2};
                     u32x4_t vt[4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const u32x2_t t2 = lds_read8(lds_r + ent + (unsigned)(128 + c * C::PSB));
+                        const u32x2_t t2 = lds_read8(lds_r + ent + (unsigned)((C::SP - 1) * C::A_H + OC[c]));
                         vt[c] = u32x4_t{t2[0], t2[1], 0u, 0u};
                     }
                     const u32x4_t td = __builtin_bit_cast(u32x4_t, blend_corners<2>(vt, w01h, w23h));
                     // K = 16 j + 8 h' + 4 u + channel with tap = 4 j + 2 h' + u: only lanes of half h' carry it, in dwords (2u, 2u + 1)
-                    const int j = tap >> 2, hsel = (tap >> 1) & 1, u = tap & 1;
                     unsigned tm[2][2];
 #pragma unroll
                     for (int dd = 0; dd < 2; ++dd) {
@@ -690,9 +709,6 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
                         tm[0][dd] = h == hsel ? sw[0] : 0u;
                         tm[1][dd] = h == hsel ? sw[1] : 0u;
                     }
-                    f16x8 wt[3];
-#pragma unroll
-                    for (int n = 0; n < 3; ++n) wt[n] = *reinterpret_cast<const f16x8 *>(wtl_fx + (j * 3 + n) * 1024 + (n < 2 ? lane16 : t3lane16));
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
                         const u32x4_t bq = u ? u32x4_t{0u, 0u, tm[m][0], tm[m][1]} : u32x4_t{tm[m][0], tm[m][1], 0u, 0u};
@@ -705,6 +721,9 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
             }
             flush_taps();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the round's arena reads have returned before the next round's DMA overwrites them
+#if EMAVFI_DEFORM_STAMPS
+            { DEFORM_STAMP(tr4); fx_issue += tr1 - tr0; fx_land += tr3 - tr1; fx_taps += tr4 - tr3; }
+#endif
         }
     }
     DEFORM_STAMP(ts_loop);
@@ -759,8 +778,10 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
         if (row < DEFORM_STAMP_ROWS) {
             unsigned long long *o = p.stamps + (size_t)row * 8;
             // (o[2] bits 32..63: the fix-up pass - hand-shake wait, arena rounds, its taps; o[4]: flagged taps << 32, parked samples << 40)
-            o[0] = ts_window - ts_begin; o[1] = ts_offconv - ts_window; o[2] = (ts_geom_all - ts_offconv) | ((ts_loop - ts_taps_done) << 32); o[3] = sum_steps;
-            o[4] = (ts_done - ts_loop) | (cnt_out << 32) | ((unsigned long long)n_parked << 40); o[5] = ts_done - ts_begin; o[6] = 1;
+            // (bits 32..63 of o[0] / o[1] / o[3] / o[5]: the fix-up's hand-shake wait / descriptor + DMA issue / DMA landing + conversion / taps)
+            o[0] = (ts_window - ts_begin) | (fx_wait << 32); o[1] = (ts_offconv - ts_window) | (fx_issue << 32);
+            o[2] = (ts_geom_all - ts_offconv) | ((ts_loop - ts_taps_done) << 32); o[3] = sum_steps | (fx_land << 32);
+            o[4] = (ts_done - ts_loop) | (cnt_out << 32) | ((unsigned long long)n_parked << 40); o[5] = (ts_done - ts_begin) | (fx_taps << 32); o[6] = 1;
             auto q16 = [](unsigned long long v) { v >>= 2; return v > 0xffffull ? 0xffffull : v; };
             o[7] = q16(ts_issued - ts_begin) | (q16(ts_landed - ts_issued) << 16) | (q16(ts_converted - ts_landed) << 32) | (q16(ts_window - ts_converted) << 48);
         }
