@@ -136,6 +136,14 @@ class Hip:
             self.lib.hipEventDestroy(e)
 
 
+_T0 = time.perf_counter()
+
+
+def progress(msg):
+    """One line on stderr per leg (never stdout: that carries the ONE JSON line): a long default run stays visibly alive."""
+    print(f"[bench {time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def cpu_model_name():
     try:
         for line in open("/proc/cpuinfo"):
@@ -165,12 +173,20 @@ def cpu_baseline(sd, height, width, reps, dev=None):
     The full frame then goes through the HIP path in all three arithmetic modes for the accuracy fields."""
     from emavfi import synth
     from oracle import emavfi_oracle as oracle
-    # every core this job is GRANTED (the GPU box exposes all host cores, the job's share is its affinity mask: 16 for one GPU)
+    # every core this job is GRANTED: the affinity mask, a cgroup CPU quota if one is set, and the pool's stated share for a one-GPU job
+    # (16: the GPU box exposes ALL host cores in the affinity mask - taking them all oversubscribes the share and the oracle crawls;
+    # EMAVFI_CPU_THREADS overrides the share)
     try:
         granted = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         granted = os.cpu_count() or 1
-    threads = max(1, min(granted, int(os.environ.get("EMAVFI_CPU_THREADS", str(granted)))))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            granted = min(granted, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    threads = max(1, min(granted, int(os.environ.get("EMAVFI_CPU_THREADS", "16"))))
     torch.set_num_threads(threads)
     cpu_sd = {k: v.float().cpu() for k, v in sd.items()}
     # the split VERDICT r5 asks for: the three deformable convolutions are a restatement in Python-level tensor ops (torchvision's C++
@@ -817,6 +833,7 @@ def main():
                 return {"value": round(b * steps / el, 2), "unit": "frames/s", "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,
                         "pairs_per_step": b, "height": h, "width": w, "dtype": dtype}
 
+            progress("timed region done; side legs: warp, board power, fp16, amp16, fp32, configs[1], stream, spread, CPU oracle")
             res["roofline_warp"] = warp_roofline(hip, B, H, W)
             res["board_under_load"] = board_under_load(model, f1, f2)
             # reported beside, never part of `value`
@@ -824,25 +841,32 @@ def main():
                 res["also_fp16_fast"] = timed_alt("fp16", B, H, W, args.steps)
             # what the reference's torch.cuda.amp.autocast() computes on a GPU (inference.py:159), op policy restated:
             # fp16 convolutions, fp32 grid_sample and fp32 deform_conv2d on an fp32 fusion tensor (EMAVFI_AMP16)
+            progress("amp16 leg")
             res["also_amp16_autocast_policy"] = timed_alt("amp16", B, H, W, max(3, args.steps // 2))
             if args.dtype != "fp32":  # the parity mode (exact fp32 MFMA; the only mode north_star's 1e-3 bound applies to): with ITS roofline
+                progress("fp32 leg")
                 res["also_fp32_exact"] = profiled_mode(hip, sd, dev, "fp32", B, H, W, max(3, args.steps // 4))
                 res["roofline_fp32"] = dict(res["also_fp32_exact"]["roofline"], workload=f"B={B} x {W}x{H}, exact fp32")
                 if "roofline_warp_in_forward" in res["also_fp32_exact"]:   # the mode north_star's 1e-3 clause is about
                     res["roofline_warp_in_forward_fp32"] = dict(res["also_fp32_exact"]["roofline_warp_in_forward"], workload=f"B={B} x {W}x{H}, exact fp32")
             # BASELINE.json configs[1]: batch 16 of 256x256 pairs, fp32 (with its roofline) and bf16
+            progress("configs[1] legs")
             c1 = profiled_mode(hip, sd, dev, "fp32", 16, 256, 256, args.steps)
             res["config1_256"] = {"fp32": c1, "bf16": timed_alt("bf16", 16, 256, 256, 4 * args.steps)}
             res["roofline_fp32_config1"] = dict(c1["roofline"], workload="BASELINE configs[1]: B=16 x 256x256, exact fp32")
             if args.dtype == "bf16" and (H, W) == (720, 1280):   # the harness legs (PCIe-inclusive; BASELINE configs[4] size)
+                progress("stream legs (PCIe-inclusive)")
                 res.update(stream_legs(sd, dev, B, H, W))
                 res["also_stream_pcie"]["fraction_of_resident_value"] = round(res["also_stream_pcie"]["value"] / value, 4)
+                progress("pack vs offset spread")
                 res["also_pack_vs_offset_spread"] = pack_vs_offset_spread(hip, sd, dev, B, H, W)
             sclk = (res.get("board_under_load") or {}).get("sclk_mhz")
             if sclk:
                 add_sustained_clock(res, float(sclk))
             if args.cpu_reps > 0:
+                progress("CPU oracle baseline (1 warm-up + timed forwards at three sizes)")
                 res["cpu_baseline"] = cpu_baseline(sd, H, W, args.cpu_reps, dev)
+                progress("done")
                 res["accuracy_vs_cpu_oracle"] = cpu_baseline.accuracy
         print(json.dumps(res), flush=True)
     if ev is not None:

@@ -346,6 +346,6 @@ static inline bool deform_pack3_shape(int ck, int nf, int cin_real, int cout_rea
 #endif
 static inline bool deform_f32w_shape(int ck, int nf, int cin_real, int cout_real)
 {
-    return EMAVFI_F32W && ck == 80 && nf == 3 && cin_real > 64 && cin_real <= 72 && cout_real > 64 && cout_real <= 80;
+    return EMAVFI_F32W && ck == 80 && nf == 3 && cin_real > 64 && cin_real <= 68 && cout_real > 64 && cout_real <= 80;   // (K = 36 + 32 issued)
 }
 bool deform16_can_fuse_offset_conv(int ck, int nf, int cin_real, int off_ck, int off_nf);

@@ -970,6 +970,9 @@ template <typename T> static int launch_conv_any(const ConvParams &p, hipStream_
     if constexpr (sizeof(T) == 2) {  // 16-bit types only: eight output fragments in one pass (EMAVFI_CONV_WREG=0: context_encoding.1)
         X(32, 8, 2)
     }
+    if constexpr (sizeof(T) == 4) {  // fp32 only (k-groups of 8 channels): 65..72 input channels as 9 k-groups instead of 10 (round 6: the
+        X(72, 1, 1) X(72, 2, 1)      // fp32 layers are matrix-pipe-bound at the clock the board holds; offset_conv 67 -> 27, reconstruction.0 67 -> 64)
+    }
 #undef X
     return -2;  // no instantiation
 }

@@ -5,7 +5,9 @@
 // deform_kernel<float, 80, 3> (deform.inl) gathers every corner from global memory (L1/L2) and contracts on
 // v_mfma_f32_32x32x2_f32 with N = 96 and K = 72 issued for 67 x 67 real: 12.8 ms per launch at B = 8 x 720p = 0.30 of the fp32
 // matrix peak, 40 % of the parity mode's step and 75 % of the autocast-policy mode's.  Here:
-//   * v_mfma_f32_16x16x4_f32: 5 output blocks of 16 (80 issued channels instead of 96), K in steps of 4 (72 = 2 x 36);
+//   * v_mfma_f32_16x16x4_f32: 5 output blocks of 16 (80 issued channels instead of 96), K in steps of 4: 36 + 32 = 68 issued for 67
+//     real (round 6: the second half's leftover step - channels 68..71, zero weights - is no longer issued: 85 instead of 90 MFMAs per
+//     (tap, block); the kernel is matrix-pipe-bound at the clock the board holds, section 3.3b of DESIGN.md);
 //   * the input window (tile + halo of 1 tap + R offset reach + 1 bilinear, zero outside the image) is staged in LDS by
 //     global->LDS DMA, one HALF of the channels at a time (36 fp32 channels = 144-byte pixels = 9 sixteen-byte slots, an odd
 //     slot stride: 76 KiB, two workgroups per CU); the nine taps run once per half;
@@ -135,7 +137,8 @@ __global__ __launch_bounds__(256, 2) void deform_f32w_kernel(const DeformParams 
                 }
             }
         }
-        __syncthreads();  // hipcc drains the DMA (vmcnt(0)) ahead of the barrier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the window DMA has landed (hipcc emits this wait today; not relied upon - ADVICE r5)
+        __syncthreads();
 
         // offsets / masks of a tap are fetched one tap ahead (an L2 round trip in front of every tap's geometry otherwise)
         float omv[4][3];
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void deform_f32w_kernel(const DeformParams 
             for (int c = 0; c < 5; ++c) {
                 a16[c][0] = *reinterpret_cast<const f32x4 *>(wt + c * C::CB_BYTES + lane16);
                 a16[c][1] = *reinterpret_cast<const f32x4 *>(wt + c * C::CB_BYTES + 1024 + lane16);
-                a4[c] = *reinterpret_cast<const float *>(wt + c * C::CB_BYTES + 2048 + lane4);
+                a4[c] = half ? 0.0f : *reinterpret_cast<const float *>(wt + c * C::CB_BYTES + 2048 + lane4);
             }
             Geo g[4];
 #pragma unroll
@@ -164,10 +167,12 @@ __global__ __launch_bounds__(256, 2) void deform_f32w_kernel(const DeformParams 
 #pragma unroll
                 for (int blk = 0; blk < 4; ++blk) { omv[blk][0] = om[blk][2 * tn]; omv[blk][1] = om[blk][2 * tn + 1]; omv[blk][2] = om[blk][18 + tn]; }
             }
-            // 12 units per tap: (block, group 0 | group 1 | leftover); corner reads one unit ahead of their blend + MFMAs
+            // units per tap: (block, group 0 | group 1 | leftover) - the leftover (channels 32..35 of the half) exists in the first half only
+            // (channels 68..71 are padding); corner reads one unit ahead of their blend + MFMAs
             f32x4 vq[2][4];
             auto issue = [&](int u, f32x4 (&v)[4]) {
                 const int blk = u / 3, part = u - 3 * blk;
+                if (part == 2 && half) return;
                 const unsigned a = g[blk].base + (part < 2 ? (unsigned)(part * 64 + kb * 16) : (unsigned)(128 + kb * 4));
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void deform_f32w_kernel(const DeformParams 
                     for (int t = 0; t < 4; ++t)
 #pragma unroll
                         for (int c = 0; c < 5; ++c) mma_f32_k4(acc[c][blk], a16[c][part][t], x[t]);
-                } else {
+                } else if (!half) {   // (wave-uniform)
                     float x = 0.f;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) x = fmaf(w[c], v[c][0], x);
@@ -241,6 +246,7 @@ __global__ __launch_bounds__(256, 2) void deform_f32w_kernel(const DeformParams 
                 const char *wt = wbase_g + (size_t)tap * C::TAP_BYTES + half * C::HALF_BYTES;
 #pragma unroll
                 for (int part = 0; part < 3; ++part) {
+                    if (part == 2 && half) continue;   // channels 68..71: padding
                     f32x4 x = {0.f, 0.f, 0.f, 0.f};
                     if (need) {
 #pragma unroll

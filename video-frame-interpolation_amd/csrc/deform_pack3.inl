@@ -571,11 +571,6 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
 #if EMAVFI_DEFORM_STAMPS
         cnt_out += __popc(fb_taps);
 #endif
-        // every wave of the workgroup reaches the increment above unconditionally: the wait ends
-        while (*reinterpret_cast<volatile lds_u32_t *>(sync_word) < (unsigned)C::WAVES) __builtin_amdgcn_s_sleep(1);
-#if EMAVFI_DEFORM_STAMPS
-        { DEFORM_STAMP(t_); fx_wait = t_ - ts_taps_done; }
-#endif
         const unsigned lds0 = (unsigned)(size_t)(lds_char_t *)smem;
         const unsigned arena = (unsigned)__builtin_amdgcn_readfirstlane(wave * C::ARENA_BYTES);   // (an SGPR: the DMA's M0 operand)
         lds_u32_t *table = reinterpret_cast<lds_u32_t *>((lds_char_t *)smem + C::TAB_OFF + wave * 128);
@@ -629,6 +624,17 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
                     if (parked && slot < n_ent) table[slot] = desc;
                 }
                 prefix += cnt;
+            }
+            // (the first round's descriptors were computed while the other waves finished their tap loops: the window is needed from here on)
+            if (rbase == 0) {
+#if EMAVFI_DEFORM_STAMPS
+                DEFORM_STAMP(tw0);
+#endif
+                // every wave of the workgroup reaches the increment above unconditionally: the wait ends
+                while (*reinterpret_cast<volatile lds_u32_t *>(sync_word) < (unsigned)C::WAVES) __builtin_amdgcn_s_sleep(1);
+#if EMAVFI_DEFORM_STAMPS
+                { DEFORM_STAMP(tw1); fx_wait = tw1 - tw0; }
+#endif
             }
             // -- B: fetch.  Lane (slot, hb) owns corners 2 hb and 2 hb + 1 of its slot: instructions 0..8 their first, 9..17 their second,
             // piece by piece (piece 8 = the tail channels, from the compact tail buffer when the pack has one).  Slots past the round's
@@ -779,7 +785,7 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
             unsigned long long *o = p.stamps + (size_t)row * 8;
             // (o[2] bits 32..63: the fix-up pass - hand-shake wait, arena rounds, its taps; o[4]: flagged taps << 32, parked samples << 40)
             // (bits 32..63 of o[0] / o[1] / o[3] / o[5]: the fix-up's hand-shake wait / descriptor + DMA issue / DMA landing + conversion / taps)
-            o[0] = (ts_window - ts_begin) | (fx_wait << 32); o[1] = (ts_offconv - ts_window) | (fx_issue << 32);
+            o[0] = (ts_window - ts_begin) | (fx_wait << 32); o[1] = (ts_offconv - ts_window) | ((fx_issue - fx_wait) << 32);
             o[2] = (ts_geom_all - ts_offconv) | ((ts_loop - ts_taps_done) << 32); o[3] = sum_steps | (fx_land << 32);
             o[4] = (ts_done - ts_loop) | (cnt_out << 32) | ((unsigned long long)n_parked << 40); o[5] = (ts_done - ts_begin) | (fx_taps << 32); o[6] = 1;
             auto q16 = [](unsigned long long v) { v >>= 2; return v > 0xffffull ? 0xffffull : v; };

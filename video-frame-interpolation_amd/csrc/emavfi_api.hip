@@ -59,6 +59,8 @@ const int kConvInst[][3] = {{16, 1, 1}, {16, 2, 1}, {32, 1, 1}, {48, 1, 1}, {64,
                             {64, 4, 1}, {80, 1, 1}, {80, 2, 1}, {16, 1, 2}, {32, 2, 2}, {32, 4, 2}};
 // 16-bit types only: all eight output fragments of a stride-2 layer in one pass (128 accumulator registers)
 const int kConvInst16[][3] = {{32, 8, 2}};
+// fp32 only: 65..72 input channels as nine k-groups of 8
+const int kConvInst32[][3] = {{72, 1, 1}, {72, 2, 1}};
 const int kDeformInst[][2] = {{16, 1}, {32, 1}, {48, 2}, {80, 3}};
 
 bool conv_inst_exists(int ck, int nf, int st, int esize)
@@ -67,6 +69,9 @@ bool conv_inst_exists(int ck, int nf, int st, int esize)
         if (i[0] == ck && i[1] == nf && i[2] == st) return true;
     if (esize == 2)
         for (auto &i : kConvInst16)
+            if (i[0] == ck && i[1] == nf && i[2] == st) return true;
+    if (esize == 4)
+        for (auto &i : kConvInst32)
             if (i[0] == ck && i[1] == nf && i[2] == st) return true;
     return false;
 }
@@ -150,6 +155,7 @@ bool conv_geometry(Layer &L, int esize, const LayoutEnv &env)
         return true;
     }
     if (L.stride == 2) L.ck = (L.cin_pad % 32 == 0) ? 32 : 16;
+    else if (esize == 4 && L.cin_take > 64 && L.cin_take <= 72) { L.ck = 72; L.cin_pad = 72; }   // fp32 k-groups are 8 channels: 9 instead of 10
     else if (L.cin_pad <= 80) L.ck = L.cin_pad;
     else if (L.cin_pad % 64 == 0) L.ck = 64;
     else return false;
