@@ -45,7 +45,13 @@
  *    torch.cuda.amp.autocast() gives the reference's convolutions on a GPU
  *    (inference.py:159); its fused deformable kernel blends the four corners
  *    in packed f16; values beyond +-65504 overflow to inf exactly as they
- *    would there.  A NaN / infinite flow (or one whose `2 * v` overflows)
+ *    would there.  NON-FINITE ACTIVATIONS inside the one-launch pack (reachable only through such an
+ *    f16 overflow): the reference confines an Inf / NaN sample to the output pixels that sample it; this
+ *    kernel may also turn channels 64..66 of the pixel 16 columns to the left / right in the same 2 x 16
+ *    fragment row into NaN (its third output fragment contracts two pixels per MFMA column and separates
+ *    them by zero weights: 0 x Inf), and a lane whose sample is parked for the fix-up pass reads window
+ *    offset 0 / the arena's zero slot against zero weights.  Finite inputs are unaffected; a frame that
+ *    contains any non-finite value is garbage in the reference as well.  A NaN / infinite flow (or one whose `2 * v` overflows)
  *    warps to NaN in every channel, a finite flow far outside to 0 - what
  *    the reference's CPU grid_sample returns (ema_vfi.py:169).  Flow, warp coordinates,
  *    deformable offsets / masks / sampling positions, the pooled context
@@ -238,7 +244,7 @@ int emavfi_mdcn_profiled(const float *x, const float *offset_weight, const float
 /* Census of the one-launch ModulatedDeformConvPack kernel (measurement hook; the reference bounds its offsets nowhere, ema_vfi.py:55-60,
  * and the kernel stages a window that holds offsets up to +-2 px beyond the tap: samples that leave it take a fix-up pass).  The kernel
  * counts, while it runs: the (wave, tap) groups - 4 rows x 16 pixels x one tap - that took the fix-up, the samples outside the window and
- * the largest |offset| it computed.  emavfi_forward_census reads the counters the LAST emavfi_forward* call on `workspace` left there
+ * the largest |offset| of the waves that had one (only those pay for the census: 0 = every sample was inside the window).  emavfi_forward_census reads the counters the LAST emavfi_forward* call on `workspace` left there
  * (same model, B, H, W, dtype; enqueue it on the same stream), emavfi_mdcn_census those of the last emavfi_mdcn* call:
  *   out[block][4] (unsigned 64-bit, DEVICE memory, num_blocks rows - one row for mdcn) =
  *     {fix-up wave-taps, all wave-taps (0: this block did not run the one-launch kernel, nothing was counted), samples outside the

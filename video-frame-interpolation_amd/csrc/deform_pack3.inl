@@ -38,6 +38,14 @@
 #ifndef EMAVFI_P3_ONE_WG
 #define EMAVFI_P3_ONE_WG 0
 #endif
+// A/B builds (round 6): what the census and the fix-up hand-shake cost a tile that has no sample outside its window.  NO_HANDSHAKE is
+// only legal together with -DEMAVFI_DEFORM_ABL_NO_FALLBACK=1 (no wave ever waits): timing only, wrong results beyond the window.
+#ifndef EMAVFI_P3_NO_CENSUS
+#define EMAVFI_P3_NO_CENSUS 0
+#endif
+#ifndef EMAVFI_P3_NO_HANDSHAKE
+#define EMAVFI_P3_NO_HANDSHAKE 0
+#endif
 struct Pack3 {
     static constexpr int R = 2, TROWS = 16, TCOLS = 16, WAVES = 4, THREADS = 256;
     static constexpr int TR = TROWS + 3 + 2 * R, TC = TCOLS + 3 + 2 * R;                 // 23 x 23 window pixels
@@ -233,6 +241,9 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
     // different K slices.  The A operand separates them again: row 4 ph + c holds W[64 + c][slice h] in K slice 2 h + ph and zeros in
     // the other pixel half's slices, so D[4 ph + c][j] is channel 64 + c of pixel 16 ph + j - lane L < 32 ends with channels
     // 64..67 of ITS OWN pixel in its four registers.  Same LDS table (rows 0..2 | zero row, two halves), another lane mapping.
+    // (Non-finite data: the other pixel's contribution is removed by ZERO weights, so an Inf / NaN blended value at pixel r +- 16 - reachable
+    // only through an f16 overflow - makes channels 64..66 of pixel r NaN too, where the 32x32x16 form and the reference confine it to the
+    // offending pixel.  Documented in include/emavfi.h; not masked: a frame with a non-finite activation is garbage either way - ADVICE r5.)
     const int a3i = lane & 15, a3kb = lane >> 4;
     const bool a3real = (a3i >> 2) < 2 && (a3i & 3) < 3 && (a3kb & 1) == (a3i >> 2);
     const int a3row = a3real ? (a3i & 3) : 3, a3half = a3kb >> 1;
@@ -371,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
         } else {
             o = load_om(om_my, tap, my_in);
         }
-        omax = fmaxf(omax, fmaxf(fabsf(o.dy), fabsf(o.dx)));   // (one v_max3_f32 with |.| modifiers; NaN offsets are ignored)
+        if (!EMAVFI_P3_NO_CENSUS) omax = fmaxf(omax, fmaxf(fabsf(o.dy), fabsf(o.dx)));   // (one v_max3_f32 with |.| modifiers; NaN offsets are ignored)
         const float py = fminf(fmaxf((fy_base + (float)ti) + o.dy, -2.0f), fy_max);
         const float px = fminf(fmaxf((fx_base + (float)tj) + o.dx, -2.0f), fx_max);
         const float fy = floorf(py), fx = floorf(px);
@@ -561,8 +572,10 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
     // Corners are clamped into the image and the weights of out-of-image corners are zero: the value deform_kernel computes.
     typedef __attribute__((address_space(3))) unsigned lds_u32_t;
     lds_u32_t *sync_word = reinterpret_cast<lds_u32_t *>((lds_char_t *)smem + C::SYNC_OFF);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's last window reads have returned
-    if (lane == 0) __hip_atomic_fetch_add(sync_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (!EMAVFI_P3_NO_HANDSHAKE) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's last window reads have returned
+        if (lane == 0) __hip_atomic_fetch_add(sync_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     unsigned n_parked = 0;
 #if EMAVFI_DEFORM_STAMPS
     unsigned long long fx_wait = 0, fx_issue = 0, fx_land = 0, fx_taps = 0;
@@ -734,17 +747,17 @@ __global__ __launch_bounds__(256, 2) void deform_pack3_kernel(const DeformParams
     }
     DEFORM_STAMP(ts_loop);
     // ---- census of this launch (emavfi_forward_census / emavfi_mdcn_census): (wave, tap) groups that took the fix-up, samples outside the
-    // window, largest |offset| - 64 slots of {u32 x 4} per launch so that the atomics of 118 k waves spread; no-return atomics
-    if (p.census) {
+    // window, and the largest |offset| of a wave that had one - ONLY such waves pay for it (a same-box A/B priced an unconditional
+    // wave reduction + atomic at 40-55 us per launch, 3-4 %: profiles/r06_experiments_that_lost.txt).  64 slots of {u32 x 4} per launch,
+    // no-return atomics.  A launch without a flagged wave reports max |offset| 0 = "every sample inside the +-2 px window".
+    if (!EMAVFI_P3_NO_CENSUS && __builtin_expect(fb_taps != 0, 0) && p.census) {
         float om = my_in ? omax : 0.0f;
 #pragma unroll
         for (int sh = 32; sh >= 1; sh >>= 1) om = fmaxf(om, __shfl_xor(om, sh));
         if (lane == 0) {
             unsigned *cs = p.census + (blockIdx.x & 63u) * 4u;
-            if (fb_taps) {
-                (void)__hip_atomic_fetch_add(cs, (unsigned)__popc(fb_taps), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                (void)__hip_atomic_fetch_add(cs + 1, n_parked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            (void)__hip_atomic_fetch_add(cs, (unsigned)__popc(fb_taps), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)__hip_atomic_fetch_add(cs + 1, n_parked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             (void)__hip_atomic_fetch_max(cs + 2, __float_as_uint(om), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
