@@ -446,29 +446,37 @@ def pack_vs_offset_spread(hip, sd, dev, B, H, W, spreads=(0, 1, 2, 3, 4, 8), rep
     px = float(B) * H * W
     flops = 2.0 * 9.0 * 67.0 * (67.0 + 27.0) * px
     ev = hip.events(2 * reps)
-    rows = []
+    # the forward hands its second pack IEEE f16 bit patterns and takes f16 back (the packs' hand-off: DESIGN.md 3.3 item 1); `rows` times
+    # the stage in THAT form; `rows_bf16_input` in the form rounds 4-5 timed (bf16 in, converted to f16 on chip: +40-60 us at +-0 and one
+    # conversion pass per fix-up round) for continuity with BENCH_r05.json
+    f16_flags = lib.MDCN_IN_F16 | lib.MDCN_OUT_F16
+    rows, rows_bf16 = [], []
     for s_px in spreads:
         ow_s, ob_s = ow.clone(), ob.clone()
         ow_s[offch] *= (0.5 * s_px / sigma0)
         ob_s[offch] *= 0.5 * s_px             # the recipe's offset bias is U(+-1)
-        lib.mdcn(x, ow_s, ob_s, dw, db, dtype="bf16")     # warm-up
-        for i in range(reps):
-            off = ctypes.cast(ctypes.addressof(ev) + 2 * i * ctypes.sizeof(ctypes.c_void_p), ctypes.c_void_p)
-            lib.mdcn(x, ow_s, ob_s, dw, db, dtype="bf16", _events=(off, 2))
-        torch.cuda.synchronize()
-        us = sorted(hip.elapsed_ms(ev[2 * i], ev[2 * i + 1]) for i in range(reps))[reps // 2] * 1e3
-        row = {"spread_px": s_px, "pack_us": round(us, 1), "frac": round(flops / (us * 1e-6) / 1e12 / PEAK["bf16"], 4)}
-        kc = lib.mdcn_census(B, 67, H, W, dtype="bf16", device=dev)[0]   # what the kernel itself counted in the last timed launch (all B samples)
-        row.update(fixup_census(lib.conv3x3(x[:1], ow_s, ob_s, dtype="fp32"), H, W))
-        if kc:
-            row["kernel_census"] = {"fixup_share": round(kc["fixup_share"], 5), "samples_outside_share": round(kc["samples_outside_share"], 6),
-                                    "abs_offset_px_max": round(kc["abs_offset_px_max"], 2)}
-        rows.append(row)
+        census = fixup_census(lib.conv3x3(x[:1], ow_s, ob_s, dtype="fp32"), H, W)
+        for flags, dest in ((f16_flags, rows), (0, rows_bf16)):
+            lib.mdcn(x, ow_s, ob_s, dw, db, dtype="bf16", flags=flags)     # warm-up
+            for i in range(reps):
+                off = ctypes.cast(ctypes.addressof(ev) + 2 * i * ctypes.sizeof(ctypes.c_void_p), ctypes.c_void_p)
+                lib.mdcn(x, ow_s, ob_s, dw, db, dtype="bf16", flags=flags, _events=(off, 2))
+            torch.cuda.synchronize()
+            us = sorted(hip.elapsed_ms(ev[2 * i], ev[2 * i + 1]) for i in range(reps))[reps // 2] * 1e3
+            row = {"spread_px": s_px, "pack_us": round(us, 1), "frac": round(flops / (us * 1e-6) / 1e12 / PEAK["bf16"], 4)}
+            if flags:
+                kc = lib.mdcn_census(B, 67, H, W, dtype="bf16", flags=flags, device=dev)[0]   # what the kernel counted in the last timed launch (all B samples)
+                row.update(census)
+                if kc:
+                    row["kernel_census"] = {"fixup_share": round(kc["fixup_share"], 5), "samples_outside_share": round(kc["samples_outside_share"], 6),
+                                            "abs_offset_px_max": round(kc["abs_offset_px_max"], 2)}
+            dest.append(row)
     hip.destroy(ev)
-    return {"kernel": "deform_pack3<bf16,fused> via emavfi_mdcn_profiled (attention_blocks.1 on its real input)", "pairs": B, "height": H, "width": W,
-            "window": "16x16 tile, R = 2 px of offset reach beyond the tap (23 x 23 pixels staged)", "rows": rows,
+    return {"kernel": "deform_pack3<bf16,fused> via emavfi_mdcn_profiled (attention_blocks.1 on its real input, f16 in / out as inside the forward)",
+            "pairs": B, "height": H, "width": W,
+            "window": "16x16 tile, R = 2 px of offset reach beyond the tap (23 x 23 pixels staged)", "rows": rows, "rows_bf16_input": rows_bf16,
             "note": "offsets = s/2 x unit-variance data term + U(+-s/2) bias; census (one sample, fp32 offset_conv) restates the kernel's in-window "
-                    "test; never part of `value`"}
+                    "test, kernel_census is what the kernel itself counted over all samples; never part of `value`"}
 
 
 def board_under_load(model, a1, a2, seconds=2.0):
