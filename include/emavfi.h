@@ -82,6 +82,14 @@ extern "C" {
  * sigmoid(mask) as fp16 values, tanh and (t+1)/2 in fp16.  The frame holds fp16-representable values.
  * EMAVFI_F16 stays the FAST half-precision mode (DCN contraction and blend in fp16 too). */
 #define EMAVFI_AMP16 3
+/* fp32-ACCURATE contractions on the 16-bit matrix pipe (round 6; gfx950 has no TF32 and its fp32 MFMA runs at 1/16 of the f16 rate):
+ * every nn.Conv2d / nn.Linear computes x_hi w_hi + x_hi w_lo + x_lo w_hi with x = x_hi + x_lo, w = w_hi + w_lo in IEEE f16 (22
+ * significant bits of each operand; the products are exact in fp32, accumulation in fp32, biases and activations in fp32), activations
+ * between the layers are stored as the two f16 halves of the fp32 value; flow, warp, sampling geometry, the pooled context and the three
+ * deform_conv2d are the EXACT fp32 ones of EMAVFI_F32.  Passes the fp32 mode's parity gates (<= 1e-3 on the frame, <= 5e-4 relative on
+ * every stage) on every reference-run fixture; a SEPARATELY NAMED mode: EMAVFI_F32 stays the exact-fp32 parity mode.  Needs |activation|
+ * < 65504; the low half underflows below 6e-5 (an absolute 6e-8 per product).  Stage entries: emavfi_conv3x3 only. */
+#define EMAVFI_F32X3 4
 
 #define EMAVFI_OK 0
 #define EMAVFI_E_ARG (-1)         /* bad shape / dtype / null pointer / misaligned pointer */

@@ -204,6 +204,12 @@ struct ConvParams {
                          // Pieces beyond read as zeros: the 72-channel fusion buffers feed CK = 80 layers this way.
     unsigned long long *stamps;  // diagnostic build (-DEMAVFI_DEFORM_STAMPS=1) only, else null: per-wave phase sums of the LDS-ring kernels
                                  // (tools/ring_stamps.py; EMAVFI_STAMP_RING selects the launch)
+    // EMAVFI_F32X3 (round 6): fp32-accurate contraction on the f16 matrix pipe.  Activations are stored as TWO f16 halves per pixel,
+    // [hi: Cpad channels | lo: Cpad channels] with v = hi + lo (hi = f16(v), lo = f16(v - hi): 22 significant bits), weights are packed as
+    // three chunk copies per 64-channel chunk - (w_hi, w_lo, w_hi) - and the tile kernel runs three virtual chunks per real one:
+    // x_hi w_hi, x_hi w_lo, x_lo w_hi (the products are exact in fp32; x_lo w_lo, 2^-22 relative, is dropped).  nchunk counts the VIRTUAL
+    // chunks; x3_lo_off / out_lo_off = element offset of the lo half inside an input / output pixel; in_ps / out_ps are whole-pixel strides.
+    int x3, x3_lo_off, out_lo_off;
 };
 
 // In-kernel stamps of the LDS-ring convolution kernels (diagnostic build only; cdna_hip_programming.md section 7): s_memtime at the
@@ -268,6 +274,7 @@ struct DeformParams {
     int in_f16, out_f16;  // bf16 storage only: x (and x_tail) / out hold IEEE f16 bit patterns (tensors handed between consecutive packs)
     void *out16;          // fp32 LDS-window kernel (deform_f32w.inl) only, EMAVFI_AMP16: ALSO write the result's fp16 rounding, channels-last with
     int out16_ps;         // pixel stride out16_ps (elements) - what the fp16 offset_conv / reconstruction.0 read (was a separate conversion pass)
+    int out16_lo_off;     // EMAVFI_F32X3: > 0 = also write the lo half f16(v - f16(v)) at this element offset of the out16 pixel
     unsigned long long *stamps;  // diagnostic build (-DEMAVFI_DEFORM_STAMPS=1) only, else null
     unsigned *census;            // deform_pack3.inl: null, or 64 slots x 4 u32 (zeroed by the host before the launch) that receive
                                  // {(wave, tap) groups in the fix-up, samples outside the window, max |offset| as float bits, 0}

@@ -157,6 +157,22 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[MF][NF], const
             continue;
         }
         T *ob = reinterpret_cast<T *>(p.out) + pix * p.out_ps + p.out_coff + pass * NF * 32;
+        if constexpr (sizeof(T) == 2) {
+            if (p.x3) {   // EMAVFI_F32X3: the fp32 result as two f16 halves, hi = f16(v), lo = f16(v - hi)
+                const bool relu = p.epi == EPI_RELU;
+#pragma unroll
+                for (int n = 0; n < NF; ++n) {
+                    const int limit = p.cstore - (pass * NF + n) * 32;
+                    if (limit <= 0) continue;
+                    store_frag(ob + n * 32, acc[m][n], h, limit, [relu](float v, int) { return relu ? fmaxf(v, 0.0f) : v; });
+                    store_frag(ob + p.out_lo_off + n * 32, acc[m][n], h, limit, [relu](float v, int) {
+                        const float r = relu ? fmaxf(v, 0.0f) : v;
+                        return r - (float)(T)r;
+                    });
+                }
+                continue;
+            }
+        }
 #pragma unroll
         for (int n = 0; n < NF; ++n) {
             const int limit = p.cstore - (pass * NF + n) * 32;
@@ -208,11 +224,13 @@ __global__ __launch_bounds__(256, (conv_wg_per_cu<T, CK, NF, S>())) void conv3x3
             __syncthreads();
         }
         // ---- DMA the input tile (+halo) for this channel chunk, and tap 0's weights ----
-        const char *gchunk = gin + (size_t)chunk * CK * sizeof(T);
+        // EMAVFI_F32X3: virtual chunk 3 c + t = real chunk c, term t: (x_hi, w_hi), (x_hi, w_lo), (x_lo, w_hi); term 1 reuses term 0's tile
+        const int rchunk = p.x3 ? chunk / 3 : chunk, term = p.x3 ? chunk - 3 * rchunk : 0;
+        const char *gchunk = gin + ((size_t)rchunk * CK + (term == 2 ? (size_t)p.x3_lo_off : 0)) * sizeof(T);
 #pragma unroll
         for (int i = 0; i < (C::NINST + 3) / 4; ++i) {
             const int j = i * 4 + wave;
-            if (j < C::NINST) {
+            if (j < C::NINST && term != 1) {
                 const int sl = j * 64 + lane;
                 const int pix = sl / C::SP, pc = sl - pix * C::SP;
                 const int ly = pix / IW, lx = pix - ly * IW;
@@ -305,7 +323,7 @@ __global__ __launch_bounds__(256, (conv_wg_per_cu<T, CK, NF, S>())) void conv3x3
     // of 32 bytes of 64 different pixels (conv_first.inl measured 25 % on this store pattern).  The tile and the weight ring are dead.
     constexpr int STG_PX = NF * 64 + 16, STG_WAVE = MF * 32 * STG_PX;
     if constexpr (sizeof(T) == 2 && EMAVFI_CONV_STAGED_STORE && 4 * STG_WAVE <= C::LDS_BYTES) {
-        if (p.epi == EPI_NONE || p.epi == EPI_RELU) {   // wave-uniform
+        if ((p.epi == EPI_NONE || p.epi == EPI_RELU) && !p.x3) {   // wave-uniform
             typedef __attribute__((ext_vector_type(2))) T pair_t;
             typedef __attribute__((ext_vector_type(4))) unsigned u4_t;
             typedef __attribute__((address_space(3))) char lchar_t;

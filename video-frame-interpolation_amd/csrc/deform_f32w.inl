@@ -293,7 +293,15 @@ __global__ __launch_bounds__(256, 2) void deform_f32w_kernel(const DeformParams 
             half_t *oh = reinterpret_cast<half_t *>(p.out16) + (((size_t)b * H + py_y[blk]) * W + px_x) * p.out16_ps;
 #pragma unroll
             for (int c = 0; c < 5; ++c)
-                if (16 * c + 4 * kb < p.cstore) store4(oh + 16 * c + 4 * kb, acc[c][blk][0], acc[c][blk][1], acc[c][blk][2], acc[c][blk][3]);
+                if (16 * c + 4 * kb < p.cstore) {
+                    store4(oh + 16 * c + 4 * kb, acc[c][blk][0], acc[c][blk][1], acc[c][blk][2], acc[c][blk][3]);
+                    if (p.out16_lo_off > 0) {   // EMAVFI_F32X3: the lo half, so that hi + lo carries 22 bits of the fp32 value
+                        float l[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) l[e] = acc[c][blk][e] - (float)(half_t)acc[c][blk][e];
+                        store4(oh + p.out16_lo_off + 16 * c + 4 * kb, l[0], l[1], l[2], l[3]);
+                    }
+                }
         }
     }
 }

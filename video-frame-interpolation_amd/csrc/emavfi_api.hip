@@ -89,6 +89,7 @@ struct Layer {
     int ring = 0;              // ConvParams::ring: 1 = stride 2, 64 -> 128 (regular packing for ck 64, nf 4); 2 = 64 -> 64 (regular packing for
                                // ck 64, nf 2); 3 = 65..67 -> 64 (that + the im2col tail of channels 64..66, 6 KiB)
     bool first6 = false;       // feat_ext_conv1 at mid_channels 64, 16-bit: a second copy of the weights in conv_first.inl's layout (10 KiB)
+    bool x3 = false;           // EMAVFI_F32X3: three virtual chunks per real one (w_hi, w_lo, w_hi), activations as [hi | lo] f16 halves
 };
 
 // Environment switches the PACKED LAYOUT depends on.  emavfi_pack_weights and emavfi_forward must agree on them, so the plan of
@@ -118,8 +119,12 @@ unsigned layout_tag_of(const LayoutEnv &e)
            (deform16_can_fuse_offset_conv(80, 3, 67, 80, 1) ? 0u : 32u) | (e.wreg_off ? 64u : 0u);   // (EMAVFI_NO_FUSED_OFFSET, latched in deform_bf16.hip)
 }
 
-bool conv_geometry(Layer &L, int esize, const LayoutEnv &env)
+bool conv_geometry(Layer &L, int esize, const LayoutEnv &env_in, bool x3 = false)
 {
+    // EMAVFI_F32X3 runs every layer on the generic tile kernel (weights through LDS): the weights-in-registers kernels cannot hold three
+    // weight sets; the virtual chunks are appended at the end of this function
+    const LayoutEnv env = x3 ? LayoutEnv{true, true, true, true} : env_in;
+    L.x3 = false;
     L.cin_pad = rup(L.cin_take, 16);
     // Stride-2 layers on the tile kernel: 32-channel chunks, two workgroups per CU (round 2 measured 64-channel chunks - every record read
     // once, but one workgroup per CU - SLOWER: 757 vs 513 us, 534 vs 513 us; that experiment and its instances were removed in round 4,
@@ -179,6 +184,12 @@ bool conv_geometry(Layer &L, int esize, const LayoutEnv &env)
     L.mfma16 = esize == 2 && L.stride == 1 && L.ck == 64 && (L.nf == 2 || L.nf == 1) && L.nchunk == 1 && L.npass == 1 && !env.m16_off;
     // 32 -> <= 4 channels (reconstruction.2): the planar-head kernel on 16x16x32 (conv_light.inl) reads the same regrouped packing
     if (esize == 2 && L.stride == 1 && L.ck == 32 && L.nf == 1 && L.nchunk == 1 && L.npass == 1 && L.cout <= 4 && !env.m16_off) L.mfma16 = true;
+    if (x3) {
+        if (esize != 2 || L.mfma16 || L.ring) return false;
+        L.x3 = true;
+        L.nchunk *= 3;      // virtual chunks 3 c + t
+        L.w_bytes *= 3;
+    }
     return true;
 }
 
@@ -215,6 +226,9 @@ struct Plan {
                                // motion_estimation.0) run the f16 ring kernels on bf16-rounded weights and hand bf16 on
     int in_ch, mid, nb, dtype, esize;  // dtype = the KERNEL storage type (EMAVFI_AMP16 runs the f16 kernels)
     bool amp;                          // EMAVFI_AMP16: autocast op policy (fp32 DCN on an fp32 fusion tensor, fp16 roundings)
+    bool x3;                           // EMAVFI_F32X3: fp32-accurate three-term f16 split in every convolution, exact fp32 DCN; the data flow of
+                                       // the autocast mode (an fp32 fusion tensor beside the 16-bit one) without any of its roundings
+    bool wide() const { return amp || x3; }   // the fusion tensor also exists in fp32 (what the fp32 DCN reads and writes)
     Layer dcn32[kMaxBlocks];           // amp: the deformable convolutions' fp32 master weights
     int fpad, p_mid;  // padded fusion / feature widths
     int fps;          // pixel stride (elements) of the fusion buffers: 72 when the 16-bit LDS-window pack serves them (the
@@ -239,12 +253,13 @@ Layer mk(int param, int cout, int cin_raw, int stride = 1, int cin_off = 0, int 
 bool build_plan(Plan &P, int in_ch, int mid, int nb, int dtype)
 {
     P.why = "";
-    if (dtype != EMAVFI_F32 && dtype != EMAVFI_BF16 && dtype != EMAVFI_F16 && dtype != EMAVFI_AMP16) {
-        P.why = "dtype must be EMAVFI_F32, EMAVFI_BF16, EMAVFI_F16 or EMAVFI_AMP16";
+    if (dtype != EMAVFI_F32 && dtype != EMAVFI_BF16 && dtype != EMAVFI_F16 && dtype != EMAVFI_AMP16 && dtype != EMAVFI_F32X3) {
+        P.why = "dtype must be EMAVFI_F32, EMAVFI_BF16, EMAVFI_F16, EMAVFI_AMP16 or EMAVFI_F32X3";
         return false;
     }
     P.amp = dtype == EMAVFI_AMP16;
-    if (P.amp) dtype = EMAVFI_F16;  // every convolution runs the f16 kernels; what differs is in forward_impl / pack
+    P.x3 = dtype == EMAVFI_F32X3;
+    if (P.wide()) dtype = EMAVFI_F16;  // every convolution runs the f16 kernels; what differs is in forward_impl / pack
     // the reference's fusion width is the literal mid_channels + 3 (ema_vfi.py:97): with any other in_channels its
     // forward raises a channel mismatch at the first attention block, so this build refuses instead of padding / dropping
     if (in_ch != 3) { P.why = "in_channels must be 3 (the reference's fusion width is mid_channels + 3, ema_vfi.py:97)"; return false; }
@@ -273,7 +288,7 @@ bool build_plan(Plan &P, int in_ch, int mid, int nb, int dtype)
 
     size_t o = kBlobHeaderBytes;   // the blob's header (misc_kernels.h, BlobHeader) comes first
     auto place = [&](Layer &L, bool deform) {
-        const bool ok = deform ? deform_geometry(L, P.esize) : conv_geometry(L, P.esize, process_layout_env());
+        const bool ok = deform ? deform_geometry(L, P.esize) : conv_geometry(L, P.esize, process_layout_env(), P.x3);
         if (!ok) return false;
         L.w_off = o; o = rup256(o + L.w_bytes);
         L.b_off = o; o = rup256(o + (size_t)L.coutpad * sizeof(float));
@@ -281,9 +296,9 @@ bool build_plan(Plan &P, int in_ch, int mid, int nb, int dtype)
     };
     // 16-bit, 6 -> 64: the fused cat + conv kernel (conv_first.inl) reads its own 10 KiB fragment copy behind the regular one
     // (the blob always carries both layouts: EMAVFI_CONV_FIRST=0, read per forward, runs pack_input + conv3x3<16,2,1> - A/B, parity test)
-    bool ok = conv_geometry(P.conv1, P.esize, process_layout_env());
+    bool ok = conv_geometry(P.conv1, P.esize, process_layout_env(), P.x3);
     if (ok) {
-        P.conv1.first6 = P.esize == 2 && P.conv1.cout == 64 && P.conv1.cin_take == 6;
+        P.conv1.first6 = P.esize == 2 && P.conv1.cout == 64 && P.conv1.cin_take == 6 && !P.x3;
         P.conv1.w_off = o; o = rup256(o + P.conv1.w_bytes + (P.conv1.first6 ? 10240 : 0));
         P.conv1.b_off = o; o = rup256(o + (size_t)P.conv1.coutpad * sizeof(float));
     }
@@ -296,8 +311,8 @@ bool build_plan(Plan &P, int in_ch, int mid, int nb, int dtype)
     // model its two weight sets are the bf16-rounded values stored as f16.  The stand-alone offset_conv (conv3x3, used
     // when the pack is not fused) still reads the bf16 copy.
     P.fps = P.fpad;
-    if (ok && !P.amp && dtype != EMAVFI_F32 && nb > 0 && deform_pack3_shape(P.dcn[0].ck, P.dcn[0].nf, P.dcn[0].cin_take, P.dcn[0].cout)) P.fps = 72;
-    if (ok && P.amp) {
+    if (ok && !P.wide() && dtype != EMAVFI_F32 && nb > 0 && deform_pack3_shape(P.dcn[0].ck, P.dcn[0].nf, P.dcn[0].cin_take, P.dcn[0].cout)) P.fps = 72;
+    if (ok && P.wide()) {
         for (int i = 0; i < nb && ok; ++i) {
             P.dcn32[i] = mk(P.dcn[i].param, f, f);
             ok = deform_geometry(P.dcn32[i], 4);
@@ -309,12 +324,12 @@ bool build_plan(Plan &P, int in_ch, int mid, int nb, int dtype)
     if (ok && dtype == EMAVFI_F32)
         for (int i = 0; i < nb; ++i)
             if (deform_f32w_shape(P.dcn[i].ck, P.dcn[i].nf, P.dcn[i].cin_take, P.dcn[i].cout)) P.dcn[i].pack3 = 3;
-    if (ok && P.amp)
+    if (ok && P.wide())
         for (int i = 0; i < nb; ++i)
             if (deform_f32w_shape(P.dcn32[i].ck, P.dcn32[i].nf, P.dcn32[i].cin_take, P.dcn32[i].cout)) P.dcn32[i].pack3 = 3;
     P.has_offh = false;
     P.feat16 = false;
-    const bool p3 = ok && !P.amp && dtype != EMAVFI_F32 && nb > 0 && deform_pack3_shape(P.dcn[0].ck, P.dcn[0].nf, P.dcn[0].cin_take, P.dcn[0].cout) &&
+    const bool p3 = ok && !P.wide() && dtype != EMAVFI_F32 && nb > 0 && deform_pack3_shape(P.dcn[0].ck, P.dcn[0].nf, P.dcn[0].cin_take, P.dcn[0].cout) &&
                     P.off[0].nchunk == 1 && P.off[0].npass == 1 && P.off[0].ck == 80 && P.off[0].nf == 1;
     if (p3) {
         // a second copy of offset_conv for the one-launch pack: f16 fragments (bf16 model: the bf16-rounded values), and in
@@ -368,6 +383,10 @@ int run_conv(const Plan &P, const Layer &L, const void *packed, const void *in, 
     // the missing pieces as zeros
     if (L.nchunk == 1 && in_ps < L.ck) c.in_pieces = in_ps * P.esize / 16;
     c.round16 = P.amp ? 1 : 0;
+    if (L.x3) {   // EMAVFI_F32X3: pixels are [hi | lo] halves of the widths the caller names
+        c.x3 = 1; c.x3_lo_off = in_ps; in_ps *= 2;
+        if (epi == EPI_NONE || epi == EPI_RELU) { c.out_lo_off = out_ps; out_ps *= 2; }   // (EPI_OM / planar outputs are fp32 as in every mode)
+    }
     c.zeros = zeros ? zeros : (const char *)packed + P.zero_off;
     c.in = in; c.out = out; c.out_planar = planar;
     c.w = (const char *)packed + L.w_off;
@@ -411,11 +430,12 @@ unsigned long long *debug_stamp_buffer()
 int run_deform(const Plan &P, const Layer &L, const void *packed, const void *x, int x_ps, float *om, void *out,
                int out_ps, int cstore, int B, int H, int W, hipStream_t s, const void *zeros = nullptr, const Layer *off = nullptr,
                const void *x_tail = nullptr, int tail_ps = 0, int force_dtype = -1, int in_f16 = 0, int out_f16 = 0, void *out16 = nullptr, int out16_ps = 0,
-               unsigned *census = nullptr)
+               unsigned *census = nullptr, int out16_lo_off = 0)
 {
     const int kd = force_dtype >= 0 ? force_dtype : P.dtype;
     DeformParams d{};
     d.census = census;
+    d.out16_lo_off = out16_lo_off;
     d.x = x; d.om = om; d.out = out;
     d.x_tail = x_tail; d.tail_ps = tail_ps;
     if (off) {  // fused ModulatedDeformConvPack: the kernel computes om itself (off = the copy in the kernel's on-chip type)
@@ -454,6 +474,7 @@ int pack_layer(const Layer &L, const void *const *params, void *packed, int dtyp
     d.ring = L.ring;
     d.first6 = L.first6 ? 1 : 0;
     d.pack3 = L.pack3;
+    d.x3 = L.x3 ? 1 : 0;
     return launch_pack_conv((const float *)params[L.param], (const float *)params[L.param + 1], (char *)packed + L.w_off,
                             (float *)((char *)packed + L.b_off), d, L.f16_of_bf16 ? (int)EMAVFI_F16 : dtype, s);
 }
@@ -478,7 +499,7 @@ struct FwdBuffers {
 
 void carve_forward(const Plan &P, Workspace &ws, FwdBuffers &f, int B, int H, int W)
 {
-    const size_t px = (size_t)B * H * W, e = P.esize;
+    const size_t px = (size_t)B * H * W, e = (size_t)P.esize * (P.x3 ? 2 : 1);   // (EMAVFI_F32X3: [hi | lo] halves per pixel)
     f.H2 = (H + 1) / 2; f.W2 = (W + 1) / 2; f.H4 = (f.H2 + 1) / 2; f.W4 = (f.W2 + 1) / 2;
     f.p2 = rup(2 * P.mid, 16); f.p4 = rup(4 * P.mid, 16); f.p_half = rup(P.mid / 2, 16);
     const int npix4 = f.H4 * f.W4;
@@ -491,7 +512,7 @@ void carve_forward(const Plan &P, Workspace &ws, FwdBuffers &f, int B, int H, in
     f.c1 = ws.take((size_t)B * f.H2 * f.W2 * f.p2 * e);
     f.c2 = ws.take((size_t)B * npix4 * f.p4 * e);
     f.c3 = ws.take((size_t)B * npix4 * f.p4 * e);
-    f.part = (float *)ws.take((size_t)B * f.nparts * f.p4 * sizeof(float));
+    f.part = (float *)ws.take((size_t)B * f.nparts * f.p4 * sizeof(float) * (P.x3 ? 2 : 1));
     f.ntiles = ((f.W4 + 31) / 32) * ((f.H4 + 3) / 4);   // conv_wreg_tiles()
     f.nparts2 = f.ntiles >= 32 ? (f.ntiles / 16 < 32 ? f.ntiles / 16 : 32) : 1;
     if (f.nparts2 > f.nparts) f.nparts2 = f.nparts;
@@ -501,7 +522,7 @@ void carve_forward(const Plan &P, Workspace &ws, FwdBuffers &f, int B, int H, in
     f.flow = (float *)ws.take(px * 2 * sizeof(float));
     f.om = (float *)ws.take(px * 32 * sizeof(float));
     f.fuF0 = f.fuF1 = nullptr;
-    if (P.amp) {
+    if (P.wide()) {
         f.fuF0 = (float *)ws.take(px * P.fpad * sizeof(float));
         f.fuF1 = (float *)ws.take(px * P.fpad * sizeof(float));
     }
@@ -621,11 +642,13 @@ int attention_block_amp(const Plan &P, int i, const void *packed, const void *x1
     EMAVFI_STEP(rec, conv_name(P, P.off[i]) + " offset_conv", fl, by, run_conv(P, P.off[i], packed, x16, P.fps, H, W, om, 32, 0, 32, EPI_OM, B, s));
     // (want16, not the pointer, decides: the enumeration-only pass has no buffers and must list the launches the real pass runs)
     const bool both = amp_dcn_writes_fp16(P, i) && want16;
-    EMAVFI_STEP(rec, both ? "deform<f32,ck=80,nf=3> dcn_v2 (fp32 under autocast; writes fp32 + its fp16 rounding)" : "deform<f32,ck=80,nf=3> dcn_v2 (fp32 under autocast)",
-                2.0 * 9.0 * cf * cf * px, px * (2.0 * cf * 4.0 + 27.0 * 4.0 + (both ? cf * 2.0 : 0.0)) + 9.0 * cf * cf * 4.0,
+    EMAVFI_STEP(rec, both ? (P.x3 ? "deform<f32,ck=80,nf=3> dcn_v2 (exact fp32; writes fp32 + its f16 hi / lo halves)" : "deform<f32,ck=80,nf=3> dcn_v2 (fp32 under autocast; writes fp32 + its fp16 rounding)")
+                          : "deform<f32,ck=80,nf=3> dcn_v2 (fp32 under autocast)",
+                2.0 * 9.0 * cf * cf * px, px * (2.0 * cf * 4.0 + 27.0 * 4.0 + (both ? cf * 2.0 * (P.x3 ? 2 : 1) : 0.0)) + 9.0 * cf * cf * 4.0,
                 run_deform(P, P.dcn32[i], packed, xF, P.fpad, om, yF, P.fpad, P.fpad, B, H, W, s, nullptr, nullptr, nullptr, 0, EMAVFI_F32, 0, 0,
-                           both ? y16 : nullptr, P.fps));
-    if (!both && want16) EMAVFI_STEP(rec, "fusion_round", 0, px * cf * 6.0, launch_convert_cl(yF, y16, npx, P.fpad, P.fps, 0, P.fpad, 0, s));
+                           both ? y16 : nullptr, P.fps * (P.x3 ? 2 : 1), nullptr, both && P.x3 ? P.fps : 0));
+    if (!both && want16)
+        EMAVFI_STEP(rec, "fusion_round", 0, px * cf * 6.0, launch_convert_cl(yF, y16, npx, P.fpad, P.fps * (P.x3 ? 2 : 1), 0, P.fpad, 0, s, P.x3 ? P.fps : 0));
     return EMAVFI_OK;
 }
 
@@ -656,13 +679,14 @@ int context_stage(const Plan &P, const void *packed, const void *feat_cl, const 
     } else {
         EMAVFI_STEP(rec, conv_name(P, P.c2) + " context_encoding.2", fl, by,
                     run_conv(P, P.c2, packed, f.c2, f.p4, f.H4, f.W4, f.c3, f.p4, 0, f.p4, EPI_RELU, B, s));
-        EMAVFI_STEP(rec, "avg_pool_partial", 0, (double)B * f.H4 * f.W4 * 4 * mid * e,
-                    launch_pool_partial(f.c3, f.part, B, f.H4 * f.W4, f.p4, f.p4, f.nparts, dtype, s));
+        const int hw = P.x3 ? 2 : 1;   // EMAVFI_F32X3: the hi and the lo halves are pooled as 2 x p4 channels and added in the fold
+        EMAVFI_STEP(rec, "avg_pool_partial", 0, (double)B * f.H4 * f.W4 * 4 * mid * e * hw,
+                    launch_pool_partial(f.c3, f.part, B, f.H4 * f.W4, hw * f.p4, hw * f.p4, f.nparts, dtype, s));
     }
     const int np = poolfuse ? f.nparts2 : f.nparts;
     EMAVFI_STEP(rec, "context_linear_fold", 0, (double)B * np * 4 * mid * 4,
-                launch_ctx_finish(f.part, packed ? (const float *)((const char *)packed + P.ctx_off) : nullptr, f.ctx, f.table, B, mid, f.p4,
-                                  np, f.H4 * f.W4, P.m0.coutpad, P.amp ? 1 : 0, s));
+                launch_ctx_finish(f.part, packed ? (const float *)((const char *)packed + P.ctx_off) : nullptr, f.ctx, f.table, B, mid,
+                                  P.x3 ? 2 * f.p4 : f.p4, np, f.H4 * f.W4, P.m0.coutpad, P.amp ? 1 : 0, s, P.x3 ? f.p4 : 0));
     return EMAVFI_OK;
 }
 
@@ -719,7 +743,7 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
     if ((size_t)B * H * W >= ((size_t)1 << 31)) return fail(EMAVFI_E_ARG, "forward: B*H*W must be < 2^31");
     // the kernels' byte offsets inside one sample are 32-bit: guard with the WIDEST element any kernel of the plan reads
     // (EMAVFI_AMP16 runs the fp32 deformable kernel on an fp32 fusion tensor: 4-byte elements beside P.esize = 2)
-    const size_t widest = P.amp ? sizeof(float) : (size_t)P.esize;
+    const size_t widest = P.wide() ? sizeof(float) : (size_t)P.esize;
     if ((size_t)H * W * P.fpad * widest >= ((size_t)1 << 32)) return fail(EMAVFI_E_ARG, "forward: one sample's activation plane must be < 4 GiB");
     if ((size_t)H * W >= ((size_t)1 << 24)) return fail(EMAVFI_E_ARG, "forward: H*W must be < 2^24 (24-bit pixel index arithmetic in the gather kernels)");
     Workspace ws{(char *)workspace, workspace_bytes, 0};
@@ -781,7 +805,8 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
                             dtype == EMAVFI_F16 ? launch_conv_first_f16(fp, s) : launch_conv_first_bf16(fp, s));
             }
         } else {
-            EMAVFI_STEP(rec, "pack_input", 0, px * (8.0 * C + 2.0 * C * e), launch_pack_input(frame1, frame2, f.in16, B, C, H, W, 16, dtype, s));
+            EMAVFI_STEP(rec, "pack_input", 0, px * (8.0 * C + 2.0 * C * e * (P.x3 ? 2 : 1)),
+                        P.x3 ? launch_pack_input_x3(frame1, frame2, f.in16, B, C, H, W, 16, s) : launch_pack_input(frame1, frame2, f.in16, B, C, H, W, 16, dtype, s));
             EMAVFI_STEP(rec, conv_name(P, P.conv1) + " feat_ext_conv1", fl, by,
                         run_conv(P, P.conv1, packed, f.in16, 16, H, W, f.fA, P.p_mid, 0, P.p_mid, EPI_RELU, B, s));
         }
@@ -810,7 +835,8 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
         }
         if (!last) { void *t = cur; cur = nxt; nxt = t; }
     }
-    if (!rec.dry && taps && taps[0]) EMAVFI_TRY(launch_cl_to_nchw(f.fu0, taps[0], B, mid, H, W, P.fps, 0, feat_dtype, s), "tap feat");
+    if (!rec.dry && taps && taps[0])
+        EMAVFI_TRY(P.x3 ? launch_cl_to_nchw_x3(f.fu0, taps[0], B, mid, H, W, P.fps, 0, s) : launch_cl_to_nchw(f.fu0, taps[0], B, mid, H, W, P.fps, 0, feat_dtype, s), "tap feat");
 
     // --- context encoding (ema_vfi.py:120): two stride-2 convs, one conv, global mean, linear
     if (const int rc = context_stage(P, packed, f.fu0, f, B, H, W, s, rec); rc != EMAVFI_OK) return rc;
@@ -846,16 +872,24 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
             return fail(EMAVFI_E_LAUNCH, "tap flow copy failed");
 
     void *x = f.fu0, *y = f.fu1;
-    if (P.amp) {
+    if (P.wide()) {
+        // --- EMAVFI_F32X3 takes the same data flow without any rounding: the fp32 fusion tensor is what the exact fp32 DCN reads and
+        // writes, its [hi | lo] f16 halves (22 bits) are what the split convolutions read.
         // --- EMAVFI_AMP16: the autocast op policy for ema_vfi.py:130-138.  grid_sample runs in fp32 on the fp16-valued
         // flow and cat(feat, warped) promotes to fp32, so the fusion tensor exists twice: fp32 (fuF: what the fp32
         // deform_conv2d reads and writes, never rounded between blocks) and its fp16 rounding (fu: what the fp16
         // offset_conv / reconstruction.0 read).
         float *xF = f.fuF0, *yF = f.fuF1;
         // (round 5: the warp writes the fp32 values AND their fp16 rounding - was the conversion pass fusion_round_warped)
-        EMAVFI_STEP(rec, "warp_fused<f32>", 24.0 * px, px * (8.0 + 8.0 * C + 2.0 * C),
-                    launch_warp_fused(frame2, f.flow, xF, B, C, H, W, P.fpad, mid, EMAVFI_F32, s, f.fu0, P.fps));
-        EMAVFI_STEP(rec, "fusion_widen_feat", 0, px * mid * 6.0, launch_convert_cl(f.fu0, xF, npx, P.fps, P.fpad, 0, mid, 1, s));
+        if (P.x3) {
+            EMAVFI_STEP(rec, "warp_fused<f32>", 24.0 * px, px * (8.0 + 8.0 * C), launch_warp_fused(frame2, f.flow, xF, B, C, H, W, P.fpad, mid, EMAVFI_F32, s));
+            EMAVFI_STEP(rec, "fusion_split_warped", 0, px * (P.fpad - mid) * 8.0, launch_convert_cl(xF, f.fu0, npx, P.fpad, 2 * P.fps, mid, P.fpad - mid, 0, s, P.fps));
+            EMAVFI_STEP(rec, "fusion_widen_feat", 0, px * mid * 8.0, launch_convert_cl(f.fu0, xF, npx, 2 * P.fps, P.fpad, 0, mid, 1, s, P.fps));
+        } else {
+            EMAVFI_STEP(rec, "warp_fused<f32>", 24.0 * px, px * (8.0 + 8.0 * C + 2.0 * C),
+                        launch_warp_fused(frame2, f.flow, xF, B, C, H, W, P.fpad, mid, EMAVFI_F32, s, f.fu0, P.fps));
+            EMAVFI_STEP(rec, "fusion_widen_feat", 0, px * mid * 6.0, launch_convert_cl(f.fu0, xF, npx, P.fps, P.fpad, 0, mid, 1, s));
+        }
         if (!rec.dry && taps && taps[3])
             EMAVFI_TRY(launch_cl_to_nchw(xF, taps[3], B, C, H, W, P.fpad, mid, EMAVFI_F32, s), "tap warped");
         EMAVFI_STAGE_EVENT(rec, 0);
@@ -957,7 +991,7 @@ int emavfi_pack_weights(int in_channels, int mid_channels, int num_blocks, const
     hipStream_t s = (hipStream_t)stream;
     const BlobHeader hdr = expected_header(P, dtype);
     dtype = P.dtype;            // kernel storage type (EMAVFI_AMP16 -> EMAVFI_F16)
-    const bool b16 = P.amp;     // autocast casts a convolution's bias to fp16 as well
+    const bool b16 = P.amp;     // autocast casts a convolution's bias to fp16 as well (EMAVFI_F32X3 keeps every bias in fp32)
     // (the gaps between the 256-byte aligned layers are part of the checksummed payload: zero, not whatever the buffer held)
     if (hipMemsetAsync(packed, 0, P.total, s) != hipSuccess) return fail(EMAVFI_E_LAUNCH, "pack: blob memset failed");
     EMAVFI_TRY(pack_layer(P.conv1, params, packed, dtype, s, b16), "pack conv1");
@@ -972,7 +1006,7 @@ int emavfi_pack_weights(int in_channels, int mid_channels, int num_blocks, const
         EMAVFI_TRY(pack_layer(P.off[i], params, packed, dtype, s, b16), "pack offset_conv");
         if (P.has_offh) EMAVFI_TRY(pack_layer(P.offh[i], params, packed, dtype, s), "pack offset_conv (f16 fragments)");
         EMAVFI_TRY(pack_layer(P.dcn[i], params, packed, dtype, s), "pack dcn_v2");
-        if (P.amp) EMAVFI_TRY(pack_layer(P.dcn32[i], params, packed, EMAVFI_F32, s), "pack dcn_v2 (fp32 master weights)");
+        if (P.wide()) EMAVFI_TRY(pack_layer(P.dcn32[i], params, packed, EMAVFI_F32, s), "pack dcn_v2 (fp32 master weights)");
     }
     EMAVFI_TRY(pack_layer(P.r0, params, packed, dtype, s, b16), "pack recon0");
     EMAVFI_TRY(pack_layer(P.r1, params, packed, dtype, s, b16), "pack recon1");
@@ -1143,26 +1177,27 @@ int emavfi_postprocess_u8(const float *frames_nchw, unsigned char *out_hwc, int 
 }
 
 // ---- stage-level entries (diagnostics / parity tests of single operators) ----
-static bool single_conv_layer(Layer &L, int Cin, int Cout, int stride, int esize)
+static bool single_conv_layer(Layer &L, int Cin, int Cout, int stride, int esize, bool x3 = false)
 {
     L = mk(0, Cout, Cin, stride);
-    return conv_geometry(L, esize, read_layout_env());   // stage-level entry: packs and runs inside one call
+    return conv_geometry(L, esize, read_layout_env(), x3);   // stage-level entry: packs and runs inside one call
 }
 
 size_t emavfi_conv3x3_workspace_bytes(int B, int Cin, int Cout, int H, int W, int stride, int dtype)
 {
     Layer L;
+    const bool x3 = dtype == EMAVFI_F32X3;
     const int e = dtype == EMAVFI_F32 ? 4 : 2;
-    if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || (stride != 1 && stride != 2) || !single_conv_layer(L, Cin, Cout, stride, e)) {
+    if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || (stride != 1 && stride != 2) || !single_conv_layer(L, Cin, Cout, stride, e, x3)) {
         fail(EMAVFI_E_UNSUPPORTED, "conv3x3: no kernel instantiation for Cin=%d Cout=%d stride=%d", Cin, Cout, stride);
         return 0;
     }
     const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
     Workspace ws{nullptr, 0, 0};
-    ws.take((size_t)B * H * W * L.cin_pad * e);
+    ws.take((size_t)B * H * W * L.cin_pad * e * (x3 ? 2 : 1));
     ws.take(L.w_bytes);
     ws.take((size_t)L.coutpad * sizeof(float));
-    ws.take((size_t)B * Ho * Wo * rup(Cout, 16) * e);
+    ws.take((size_t)B * Ho * Wo * rup(Cout, 16) * e * (x3 ? 2 : 1));
     ws.take(256);
     return ws.used;
 }
@@ -1170,24 +1205,28 @@ size_t emavfi_conv3x3_workspace_bytes(int B, int Cin, int Cout, int H, int W, in
 int emavfi_conv3x3(const float *x, const float *weight, const float *bias, float *y, int B, int Cin, int Cout, int H, int W,
                    int stride, int act, int dtype, void *workspace, size_t workspace_bytes, void *stream)
 {
-    if (dtype != EMAVFI_F32 && dtype != EMAVFI_BF16 && dtype != EMAVFI_F16) return fail(EMAVFI_E_ARG, "conv3x3: bad dtype %d", dtype);
+    if (dtype != EMAVFI_F32 && dtype != EMAVFI_BF16 && dtype != EMAVFI_F16 && dtype != EMAVFI_F32X3) return fail(EMAVFI_E_ARG, "conv3x3: bad dtype %d", dtype);
     if (!x || !weight || !y || !workspace) return fail(EMAVFI_E_ARG, "conv3x3: null pointer");
+    const bool x3 = dtype == EMAVFI_F32X3;   // the three-term f16 split: [hi | lo] halves in, fp32-accurate result out
+    if (x3) dtype = EMAVFI_F16;
     if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || (stride != 1 && stride != 2)) return fail(EMAVFI_E_ARG, "conv3x3: bad shape");
     if (act < EMAVFI_ACT_NONE || act > EMAVFI_ACT_TANH01) return fail(EMAVFI_E_ARG, "conv3x3: bad activation %d", act);
     if (act == EMAVFI_ACT_TANH01 && Cout > 4) return fail(EMAVFI_E_UNSUPPORTED, "conv3x3: TANH01 epilogue needs Cout <= 4");
     Plan P{};
     P.dtype = dtype; P.esize = dtype == EMAVFI_F32 ? 4 : 2;
     Layer L;
-    if (!single_conv_layer(L, Cin, Cout, stride, P.esize))
+    if (!single_conv_layer(L, Cin, Cout, stride, P.esize, x3))
         return fail(EMAVFI_E_UNSUPPORTED, "conv3x3: no kernel instantiation for Cin=%d Cout=%d stride=%d", Cin, Cout, stride);
+    P.x3 = x3;
+    const int hw = x3 ? 2 : 1;
     // the kernels' DMA source offsets inside one sample are 32-bit (conv3x3.inl, conv_dma_src)
     if ((size_t)H * W * L.cin_pad * P.esize >= ((size_t)1 << 32)) return fail(EMAVFI_E_ARG, "conv3x3: one sample's input plane must be < 4 GiB");
     const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride, ops = rup(Cout, 16);
     Workspace ws{(char *)workspace, workspace_bytes, 0};
-    void *xcl = ws.take((size_t)B * H * W * L.cin_pad * P.esize);
+    void *xcl = ws.take((size_t)B * H * W * L.cin_pad * P.esize * hw);
     void *wp = ws.take(L.w_bytes);
     float *bp = (float *)ws.take((size_t)L.coutpad * sizeof(float));
-    void *ycl = ws.take((size_t)B * Ho * Wo * ops * P.esize);
+    void *ycl = ws.take((size_t)B * Ho * Wo * ops * P.esize * hw);
     void *zpage = ws.take(256);
     if (ws.used > workspace_bytes) return fail(EMAVFI_E_WORKSPACE, "conv3x3: workspace needs %zu bytes, got %zu", ws.used, workspace_bytes);
     hipStream_t s = (hipStream_t)stream;
@@ -1196,14 +1235,15 @@ int emavfi_conv3x3(const float *x, const float *weight, const float *bias, float
     PackDesc d{L.cout, L.cin_raw, 0, L.cin_take, L.ck, L.nchunk, L.nf, L.npass, 0, 0};
     d.mfma16 = L.mfma16 ? 1 : 0;
     d.ring = L.ring;
+    d.x3 = x3 ? 1 : 0;
     if (hipMemsetAsync(zpage, 0, 256, s) != hipSuccess) return fail(EMAVFI_E_LAUNCH, "conv3x3: zero page memset failed");
     EMAVFI_TRY(launch_pack_conv(weight, bias, wp, bp, d, dtype, s), "conv3x3 pack");
-    EMAVFI_TRY(launch_nchw_to_cl(x, xcl, B, Cin, H, W, L.cin_pad, dtype, s), "conv3x3 layout in");
+    EMAVFI_TRY(x3 ? launch_nchw_to_cl_x3(x, xcl, B, Cin, H, W, L.cin_pad, s) : launch_nchw_to_cl(x, xcl, B, Cin, H, W, L.cin_pad, dtype, s), "conv3x3 layout in");
     if (act == EMAVFI_ACT_TANH01) {
         EMAVFI_TRY(run_conv(P, L, workspace, xcl, L.cin_pad, H, W, nullptr, 0, 0, 0, EPI_PLANAR_TANH01, B, s, nullptr, y, Cout, zpage), "conv3x3");
     } else {
         EMAVFI_TRY(run_conv(P, L, workspace, xcl, L.cin_pad, H, W, ycl, ops, 0, ops, act == EMAVFI_ACT_RELU ? EPI_RELU : EPI_NONE, B, s, nullptr, nullptr, 0, zpage), "conv3x3");
-        EMAVFI_TRY(launch_cl_to_nchw(ycl, y, B, Cout, Ho, Wo, ops, 0, dtype, s), "conv3x3 layout out");
+        EMAVFI_TRY(x3 ? launch_cl_to_nchw_x3(ycl, y, B, Cout, Ho, Wo, ops, 0, s) : launch_cl_to_nchw(ycl, y, B, Cout, Ho, Wo, ops, 0, dtype, s), "conv3x3 layout out");
     }
     return EMAVFI_OK;
 }
@@ -1276,6 +1316,7 @@ int emavfi_deform_conv2d(const float *x, const float *offset, const float *mask,
 // mid_channels + 3 channels (ema_vfi.py:97).
 static int mdcn_plan(Plan &P, int C, int dtype, int flags, bool &split, int &in_f16, int &out_f16)
 {
+    if (dtype == EMAVFI_F32X3) return fail(EMAVFI_E_UNSUPPORTED, "mdcn: EMAVFI_F32X3 has no stage entry of its own (its DCN is the exact fp32 one: use EMAVFI_F32)");
     if (C < 11 || !build_plan(P, 3, C - 3, 1, dtype))
         return fail(EMAVFI_E_UNSUPPORTED, "mdcn: C = %d is not mid_channels + 3 of a supported model (%s)", C, C < 11 ? "C < 11" : P.why);
     if (flags & ~(EMAVFI_MDCN_IN_F16 | EMAVFI_MDCN_OUT_F16 | EMAVFI_MDCN_SPLIT_TAIL)) return fail(EMAVFI_E_ARG, "mdcn: unknown flag bits 0x%x", flags);
@@ -1426,6 +1467,7 @@ int emavfi_mdcn_census(int B, int C, int H, int W, int dtype, int flags, const v
 // packs and runs them (context_stage / reconstruction_stage above), the tensors cross the boundary as NCHW fp32.
 static int stage_plan(Plan &P, int mid, int dtype, int B, int H, int W, const char *what)
 {
+    if (dtype == EMAVFI_F32X3) return fail(EMAVFI_E_UNSUPPORTED, "%s: EMAVFI_F32X3 has stage entries for conv3x3 only", what);
     if (!build_plan(P, 3, mid, 3, dtype)) return fail(EMAVFI_E_UNSUPPORTED, "%s: %s", what, P.why);
     if (B < 1 || H < 1 || W < 1) return fail(EMAVFI_E_ARG, "%s: B, H, W must be >= 1", what);
     if ((size_t)B * H * W >= ((size_t)1 << 31) || (size_t)H * W >= ((size_t)1 << 24) || (size_t)H * W * P.fpad * (P.amp ? sizeof(float) : (size_t)P.esize) >= ((size_t)1 << 32))

@@ -16,6 +16,7 @@ struct PackDesc {
     int ring;                              // Layer::ring; 3: the main fragments take input channels 0..63 (ck = 64) and conv_ring.inl's tail
                                            // [j 3][nf 2][lane (r, h)][8] follows: W[32 nf + r][64 + (e & 3)][tap slot 4 j + 2 h + (e >> 2)]
     int first6;                            // conv_first.inl layout (6 -> 64, 16-bit): [kg 5][nf 2][lane (r, h)][8]: W[32 nf + r][channel e][tap 2 kg + h]
+    int x3;                                // EMAVFI_F32X3: nchunk counts VIRTUAL chunks 3 c + t; t = 0, 2 carry f16(w), t = 1 carries f16(w - f16(w))
     int pack3;                             // deform_pack3.inl layouts (f16 elements, cin_take = 67): 1 = DCN 67 -> <= 67, 2 = offset_conv 67 -> 27;
                                            // 3 = deform_f32w.inl (fp32 elements, the fp32 DCN on an LDS window)
 };
@@ -52,7 +53,8 @@ int launch_pack_conv(const float *w, const float *bias, void *wp, float *bp, con
 int launch_pack_ctx(const float *lin_w, const float *lin_b, const float *w9, const float *b9, float *dst, int m, int round16,
                     hipStream_t s);
 // channels-last conversion of channels [c0, c0 + nc) of every pixel (nc % 4 == 0): fp16 -> fp32 (widen) or fp32 -> fp16
-int launch_convert_cl(const void *src, void *dst, size_t npx, int ps_src, int ps_dst, int c0, int nc, int widen, hipStream_t s);
+// lo_off > 0 (EMAVFI_F32X3): the 16-bit side holds [hi | lo] halves, lo at element offset lo_off: widen = hi + lo, narrow writes both
+int launch_convert_cl(const void *src, void *dst, size_t npx, int ps_src, int ps_dst, int c0, int nc, int widen, hipStream_t s, int lo_off = 0);
 int launch_pack_input(const float *f1, const float *f2, void *dst, int B, int C, int H, int W, int cpad, int dtype, hipStream_t s);
 int launch_nchw_to_cl(const float *src, void *dst, int B, int C, int H, int W, int ps, int dtype, hipStream_t s);
 // channels [c0, c0 + ctake) of an NCHW tensor with C channels -> channels 0.. of ps-channel pixels (the rest zero)
@@ -60,8 +62,13 @@ int launch_nchw_to_cl_sub(const float *src, void *dst, int B, int C, int c0, int
 int launch_cl_to_nchw(const void *src, float *dst, int B, int C, int H, int W, int ps, int coff, int dtype, hipStream_t s);
 int launch_om_from_nchw(const float *off, const float *msk, float *om, int B, int H, int W, hipStream_t s);
 int launch_pool_partial(const void *src, float *part, int B, int npix, int cp, int ps, int nparts, int dtype, hipStream_t s);
+// lo_off > 0 (EMAVFI_F32X3): a row of `part` holds the sums of the hi halves and, lo_off floats further, of the lo halves: added
 int launch_ctx_finish(const float *part, const float *ctxw, float *ctx_out, float *table, int B, int m, int cp, int nparts,
-                      int npix, int coutpad, int round16, hipStream_t s);
+                      int npix, int coutpad, int round16, hipStream_t s, int lo_off = 0);
+// EMAVFI_F32X3 layouts: NCHW fp32 <-> channels-last f16 halves [hi: ps_half | lo: ps_half]; pack_input the same for cat(frame1, frame2)
+int launch_nchw_to_cl_x3(const float *src, void *dst, int B, int C, int H, int W, int ps_half, hipStream_t s);
+int launch_cl_to_nchw_x3(const void *src, float *dst, int B, int C, int H, int W, int ps_half, int coff, hipStream_t s);
+int launch_pack_input_x3(const float *f1, const float *f2, void *dst, int B, int C, int H, int W, int cpad, hipStream_t s);
 int launch_warp_nchw(const float *frame2, const float *flow, float *out, int B, int C, int H, int W, hipStream_t s);
 // dst16 / ps16 (fp32 variant only, EMAVFI_AMP16): also write the fp16 rounding of the same values into channels [coff, ps16) of a second
 // channels-last tensor

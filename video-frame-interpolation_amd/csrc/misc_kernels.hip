@@ -64,9 +64,16 @@ __global__ void pack_conv_kernel(const float *__restrict__ w, const float *__res
             co = route_cout(pass * d.nf * 32 + blk * 16 + (lane & 15), d.perm);
             ci = chunk * d.ck + k32 * 32 + (lane >> 4) * 8 + e;
         }
+        int term = 0;
+        if (d.x3) {   // virtual chunk 3 c + t -> real chunk c
+            const int rc = chunk / 3;
+            term = chunk - 3 * rc;
+            ci = rc * d.ck + kg * CHKG + (lane >> 5) * EPV + e;
+        }
         float v = 0.0f;
-        if (co < d.cout && ci < d.cin_take && ci < d.ck * d.nchunk) v = w[((size_t)co * d.cin_raw + d.cin_off + ci) * 9 + tap];
+        if (co < d.cout && ci < d.cin_take && ci < d.ck * (d.x3 ? d.nchunk / 3 : d.nchunk)) v = w[((size_t)co * d.cin_raw + d.cin_off + ci) * 9 + tap];
         if (d.via_bf16) v = (float)(bf16_t)v;
+        if (term == 1) v = v - (float)(T)v;   // the lo part of the weight
         wp[idx] = (T)v;
     }
     if (d.ring == 3 && EPV == 8) {
@@ -296,6 +303,65 @@ __global__ void cl_to_nchw_kernel(const T *__restrict__ src, float *__restrict__
         for (int c = 0; c < C; ++c) dst[(b * C + c) * plane + pix] = (float)o[c];
     }
 }
+// EMAVFI_F32X3: fp32 <-> two f16 halves per pixel
+__global__ void nchw_to_cl_x3_kernel(const float *__restrict__ src, half_t *__restrict__ dst, int B, int C, int H, int W, int psh)
+{
+    const size_t plane = (size_t)H * W, total = (size_t)B * plane;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / plane, pix = i - b * plane;
+        half_t *o = dst + i * 2 * psh;
+        for (int c = 0; c < psh; ++c) {
+            const float v = c < C ? src[(b * C + c) * plane + pix] : 0.0f;
+            const half_t hi = (half_t)v;
+            o[c] = hi;
+            o[psh + c] = (half_t)(v - (float)hi);
+        }
+    }
+}
+__global__ void cl_to_nchw_x3_kernel(const half_t *__restrict__ src, float *__restrict__ dst, int B, int C, int H, int W, int psh, int coff)
+{
+    const size_t plane = (size_t)H * W, total = (size_t)B * plane;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / plane, pix = i - b * plane;
+        const half_t *o = src + i * 2 * psh + coff;
+        for (int c = 0; c < C; ++c) dst[(b * C + c) * plane + pix] = (float)o[c] + (float)o[psh + c];
+    }
+}
+int launch_nchw_to_cl_x3(const float *src, void *dst, int B, int C, int H, int W, int ps_half, hipStream_t s)
+{
+    const int grid = (int)std::min<size_t>(((size_t)B * H * W + 255) / 256, 65535 * 4);
+    nchw_to_cl_x3_kernel<<<grid, 256, 0, s>>>(src, (half_t *)dst, B, C, H, W, ps_half);
+    return (int)hipGetLastError();
+}
+int launch_cl_to_nchw_x3(const void *src, float *dst, int B, int C, int H, int W, int ps_half, int coff, hipStream_t s)
+{
+    const int grid = (int)std::min<size_t>(((size_t)B * H * W + 255) / 256, 65535 * 4);
+    cl_to_nchw_x3_kernel<<<grid, 256, 0, s>>>((const half_t *)src, dst, B, C, H, W, ps_half, coff);
+    return (int)hipGetLastError();
+}
+__global__ void pack_input_x3_kernel(const float *__restrict__ f1, const float *__restrict__ f2, half_t *__restrict__ dst, int B, int C, int H, int W, int cpad)
+{
+    const size_t plane = (size_t)H * W, total = (size_t)B * plane;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / plane, pix = i - b * plane;
+        half_t *o = dst + i * 2 * cpad;
+        for (int c = 0; c < cpad; ++c) {
+            float v = 0.0f;
+            if (c < C) v = f1[(b * C + c) * plane + pix];
+            else if (c < 2 * C) v = f2[(b * C + (c - C)) * plane + pix];
+            const half_t hi = (half_t)v;
+            o[c] = hi;
+            o[cpad + c] = (half_t)(v - (float)hi);
+        }
+    }
+}
+int launch_pack_input_x3(const float *f1, const float *f2, void *dst, int B, int C, int H, int W, int cpad, hipStream_t s)
+{
+    const int grid = (int)std::min<size_t>(((size_t)B * H * W + 255) / 256, 65535 * 4);
+    pack_input_x3_kernel<<<grid, 256, 0, s>>>(f1, f2, (half_t *)dst, B, C, H, W, cpad);
+    return (int)hipGetLastError();
+}
+
 int launch_nchw_to_cl_sub(const float *src, void *dst, int B, int C, int c0, int ctake, int H, int W, int ps, int dtype, hipStream_t s)
 {
     const int grid = (int)std::min<size_t>(((size_t)B * H * W + 255) / 256, 65535 * 4);
@@ -320,7 +386,7 @@ int launch_cl_to_nchw(const void *src, float *dst, int B, int C, int H, int W, i
 // EMAVFI_AMP16 keeps the fusion tensor twice: fp32 (what the fp32 DCN reads and writes) and fp16 (what the fp16
 // convolutions read).  One thread = 4 channels of one pixel.
 template <bool WIDEN>
-__global__ void convert_cl_kernel(const void *__restrict__ src, void *__restrict__ dst, size_t npx, int ps_src, int ps_dst, int c0, int nc)
+__global__ void convert_cl_kernel(const void *__restrict__ src, void *__restrict__ dst, size_t npx, int ps_src, int ps_dst, int c0, int nc, int lo_off)
 {
     const int groups = nc / 4;
     const size_t total = npx * groups;
@@ -329,18 +395,27 @@ __global__ void convert_cl_kernel(const void *__restrict__ src, void *__restrict
         const int c = c0 + 4 * (int)(i - px * groups);
         if (WIDEN) {
             const f16x4 v = *reinterpret_cast<const f16x4 *>((const half_t *)src + px * ps_src + c);
-            *reinterpret_cast<f32x4 *>((float *)dst + px * ps_dst + c) = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+            f32x4 o = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+            if (lo_off > 0) {
+                const f16x4 l = *reinterpret_cast<const f16x4 *>((const half_t *)src + px * ps_src + lo_off + c);
+                o = f32x4{o[0] + (float)l[0], o[1] + (float)l[1], o[2] + (float)l[2], o[3] + (float)l[3]};
+            }
+            *reinterpret_cast<f32x4 *>((float *)dst + px * ps_dst + c) = o;
         } else {
             const f32x4 v = *reinterpret_cast<const f32x4 *>((const float *)src + px * ps_src + c);
-            *reinterpret_cast<f16x4 *>((half_t *)dst + px * ps_dst + c) = f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            const f16x4 hi = f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            *reinterpret_cast<f16x4 *>((half_t *)dst + px * ps_dst + c) = hi;
+            if (lo_off > 0)
+                *reinterpret_cast<f16x4 *>((half_t *)dst + px * ps_dst + lo_off + c) =
+                    f16x4{(half_t)(v[0] - (float)hi[0]), (half_t)(v[1] - (float)hi[1]), (half_t)(v[2] - (float)hi[2]), (half_t)(v[3] - (float)hi[3])};
         }
     }
 }
-int launch_convert_cl(const void *src, void *dst, size_t npx, int ps_src, int ps_dst, int c0, int nc, int widen, hipStream_t s)
+int launch_convert_cl(const void *src, void *dst, size_t npx, int ps_src, int ps_dst, int c0, int nc, int widen, hipStream_t s, int lo_off)
 {
     const int grid = (int)std::min<size_t>((npx * (nc / 4) + 255) / 256, 65535 * 4);
-    if (widen) convert_cl_kernel<true><<<grid, 256, 0, s>>>(src, dst, npx, ps_src, ps_dst, c0, nc);
-    else convert_cl_kernel<false><<<grid, 256, 0, s>>>(src, dst, npx, ps_src, ps_dst, c0, nc);
+    if (widen) convert_cl_kernel<true><<<grid, 256, 0, s>>>(src, dst, npx, ps_src, ps_dst, c0, nc, lo_off);
+    else convert_cl_kernel<false><<<grid, 256, 0, s>>>(src, dst, npx, ps_src, ps_dst, c0, nc, lo_off);
     return (int)hipGetLastError();
 }
 
@@ -437,7 +512,7 @@ int launch_pool_partial(const void *src, float *part, int B, int npix, int cp, i
 constexpr int kCtxThreads = 1024;
 __global__ __launch_bounds__(kCtxThreads) void ctx_finish_kernel(const float *__restrict__ part, const float *__restrict__ ctxw,
                                                                  float *__restrict__ ctx_out, float *__restrict__ table,
-                                                                 int m, int cp, int nparts, int npix, int coutpad, int round16)
+                                                                 int m, int cp, int nparts, int npix, int coutpad, int round16, int lo_off)
 {
     // round16 (EMAVFI_AMP16): the pooled mean and the Linear output are fp16 tensors under autocast
     const auto rq = [round16](float v) { return round16 ? (float)(half_t)v : v; };
@@ -450,7 +525,10 @@ __global__ __launch_bounds__(kCtxThreads) void ctx_finish_kernel(const float *__
         const int C4 = 4 * m, G = NT / C4, c = tid % C4, g = tid / C4;
         float a = 0.0f;
         if (g < G)
-            for (int q = g; q < nparts; q += G) a += part[((size_t)b * nparts + q) * cp + c];
+            for (int q = g; q < nparts; q += G) {
+                a += part[((size_t)b * nparts + q) * cp + c];
+                if (lo_off > 0) a += part[((size_t)b * nparts + q) * cp + lo_off + c];   // EMAVFI_F32X3: the lo halves' sums
+            }
         if (g < G) red[g * C4 + c] = a;
         __syncthreads();
         if (tid < C4) {
@@ -525,11 +603,11 @@ __global__ __launch_bounds__(kCtxThreads) void ctx_finish_kernel(const float *__
     }
 }
 int launch_ctx_finish(const float *part, const float *ctxw, float *ctx_out, float *table, int B, int m, int cp, int nparts,
-                      int npix, int coutpad, int round16, hipStream_t s)
+                      int npix, int coutpad, int round16, hipStream_t s, int lo_off)
 {
     const int nred = kCtxThreads > 27 * m ? kCtxThreads : 27 * m;
     const size_t sh = (size_t)(4 * m + m + 9 * m + nred) * sizeof(float);
-    ctx_finish_kernel<<<B, kCtxThreads, sh, s>>>(part, ctxw, ctx_out, table, m, cp, nparts, npix, coutpad, round16);
+    ctx_finish_kernel<<<B, kCtxThreads, sh, s>>>(part, ctxw, ctx_out, table, m, cp, nparts, npix, coutpad, round16, lo_off);
     return (int)hipGetLastError();
 }
 

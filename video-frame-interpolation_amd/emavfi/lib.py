@@ -11,7 +11,7 @@ import collections
 import threading
 from ctypes import c_int, c_size_t, c_void_p, c_char_p, POINTER
 
-F32, BF16, F16, AMP16 = 0, 1, 2, 3
+F32, BF16, F16, AMP16, F32X3 = 0, 1, 2, 3, 4
 ACT_NONE, ACT_RELU, ACT_TANH01 = 0, 1, 2
 MDCN_IN_F16, MDCN_OUT_F16, MDCN_SPLIT_TAIL = 1, 2, 4
 # emavfi_debug_switches bits (include/emavfi.h)
@@ -19,7 +19,9 @@ SW_NO_CONV_FIRST, SW_NO_FIRSTRING, SW_NO_HEAD, SW_NO_TAILFUSE, SW_NO_CONV_LIGHT,
 DTYPES = {"fp32": F32, "f32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16,
           "fp16": F16, "f16": F16, "float16": F16, "half": F16,
           # the reference's forward under torch.cuda.amp.autocast(), op policy restated (include/emavfi.h, EMAVFI_AMP16)
-          "amp16": AMP16, "autocast": AMP16, "autocast16": AMP16}
+          "amp16": AMP16, "autocast": AMP16, "autocast16": AMP16,
+          # fp32-accurate three-term f16 split on the 16-bit matrix pipe, exact fp32 DCN (include/emavfi.h, EMAVFI_F32X3)
+          "fp32x3": F32X3, "f32x3": F32X3}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EMAVFI_LIB", os.path.join(_HERE, "lib", "libemavfi.so"))
