@@ -275,6 +275,7 @@ struct DeformParams {
     void *out16;          // fp32 LDS-window kernel (deform_f32w.inl) only, EMAVFI_AMP16: ALSO write the result's fp16 rounding, channels-last with
     int out16_ps;         // pixel stride out16_ps (elements) - what the fp16 offset_conv / reconstruction.0 read (was a separate conversion pass)
     int out16_lo_off;     // EMAVFI_F32X3: > 0 = also write the lo half f16(v - f16(v)) at this element offset of the out16 pixel
+    int x3;               // EMAVFI_F32X3: deform_f32w.inl contracts with the three-term f16 split (16x16x16 f16 MFMAs) instead of fp32 MFMAs
     unsigned long long *stamps;  // diagnostic build (-DEMAVFI_DEFORM_STAMPS=1) only, else null
     unsigned *census;            // deform_pack3.inl: null, or 64 slots x 4 u32 (zeroed by the host before the launch) that receive
                                  // {(wave, tap) groups in the fix-up, samples outside the window, max |offset| as float bits, 0}

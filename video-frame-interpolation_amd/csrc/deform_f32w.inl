@@ -35,7 +35,27 @@ struct F32W {
 };
 
 __device__ __forceinline__ void mma_f32_k4(f32x4 &acc, float w, float x) { acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w, x, acc, 0, 0, 0); }
+// EMAVFI_F32X3 (round 6): the same contraction as a three-term f16 split on v_mfma_f32_16x16x16_f16.  Lane (j, kb) of the B operand holds K
+// elements 4 kb .. 4 kb + 3 - exactly the four blended channels {16 G + 4 kb + t} this kernel's lanes already hold, and lane (i, kb) of the A
+// operand the four weights the fp32 form feeds to its four MFMA steps: ONE 8-cycle MFMA per term instead of four 32-cycle ones.
+// hi = f16(v) (round toward zero is as good as any: lo takes the rest), lo = f16(v - hi): 22 bits of each operand, exact products, fp32 sums.
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+struct HiLo { f16x4_t hi, lo; };
+__device__ __forceinline__ HiLo split_f16x4(const f32x4 v)
+{
+    HiLo r;
+    r.hi = f16x4_t{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+    r.lo = f16x4_t{(half_t)(v[0] - (float)r.hi[0]), (half_t)(v[1] - (float)r.hi[1]), (half_t)(v[2] - (float)r.hi[2]), (half_t)(v[3] - (float)r.hi[3])};
+    return r;
+}
+__device__ __forceinline__ void mma_x3(f32x4 &acc, const HiLo &w, const HiLo &x)
+{
+    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(w.hi, x.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(w.lo, x.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(w.hi, x.lo, acc, 0, 0, 0);
+}
 
+template <bool X3>
 __global__ __launch_bounds__(256, 2) void deform_f32w_kernel(const DeformParams p)
 {
     using C = F32W;
@@ -156,6 +176,19 @@ __global__ __launch_bounds__(256, 2) void deform_f32w_kernel(const DeformParams 
                 a16[c][1] = *reinterpret_cast<const f32x4 *>(wt + c * C::CB_BYTES + 1024 + lane16);
                 a4[c] = half ? 0.0f : *reinterpret_cast<const float *>(wt + c * C::CB_BYTES + 2048 + lane4);
             }
+            // EMAVFI_F32X3: the tap's weights as f16 (hi, lo) pairs; the leftover channel of lane (i, kb) sits at K = 4 kb of a K = 16 step
+            // (kept as one packed dword per output block: hi | lo << 16)
+            HiLo w16[X3 ? 5 : 1][X3 ? 2 : 1];
+            unsigned w4p[X3 ? 5 : 1];
+            if constexpr (X3) {
+#pragma unroll
+                for (int c = 0; c < 5; ++c) {
+                    w16[c][0] = split_f16x4(a16[c][0]);
+                    w16[c][1] = split_f16x4(a16[c][1]);
+                    const half_t h4 = (half_t)a4[c], l4 = (half_t)(a4[c] - (float)h4);
+                    w4p[c] = (unsigned)__builtin_bit_cast(unsigned short, h4) | ((unsigned)__builtin_bit_cast(unsigned short, l4) << 16);
+                }
+            }
             Geo g[4];
 #pragma unroll
             for (int blk = 0; blk < 4; ++blk) {
@@ -193,16 +226,34 @@ __global__ __launch_bounds__(256, 2) void deform_f32w_kernel(const DeformParams 
                     for (int c = 0; c < 4; ++c)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) x[e] = fmaf(w[c], v[c][e], x[e]);
+                    if constexpr (X3) {
+                        const HiLo xs = split_f16x4(x);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
+                        for (int c = 0; c < 5; ++c) mma_x3(acc[c][blk], w16[c][part], xs);
+                    } else {
 #pragma unroll
-                        for (int c = 0; c < 5; ++c) mma_f32_k4(acc[c][blk], a16[c][part][t], x[t]);
+                        for (int t = 0; t < 4; ++t)
+#pragma unroll
+                            for (int c = 0; c < 5; ++c) mma_f32_k4(acc[c][blk], a16[c][part][t], x[t]);
+                    }
                 } else if (!half) {   // (wave-uniform)
                     float x = 0.f;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) x = fmaf(w[c], v[c][0], x);
+                    if constexpr (X3) {
+                        const HiLo xs = split_f16x4(f32x4{x, 0.0f, 0.0f, 0.0f});
 #pragma unroll
-                    for (int c = 0; c < 5; ++c) mma_f32_k4(acc[c][blk], a4[c], x);
+                        for (int c = 0; c < 5; ++c) {
+                            typedef __attribute__((ext_vector_type(2))) unsigned u2_t;
+                            HiLo ws;
+                            ws.hi = __builtin_bit_cast(f16x4_t, u2_t{w4p[c] & 0xffffu, 0u});
+                            ws.lo = __builtin_bit_cast(f16x4_t, u2_t{w4p[c] >> 16, 0u});
+                            mma_x3(acc[c][blk], ws, xs);
+                        }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 5; ++c) mma_f32_k4(acc[c][blk], a4[c], x);
+                    }
                 }
             }
         }
@@ -310,9 +361,13 @@ static int launch_deform_f32w(const DeformParams &p, hipStream_t s)
 {
     using C = F32W;
     static PerDeviceOnce once;   // (the library is re-entrant and serves several devices per process)
-    if (const hipError_t e_ = set_lds_limit(once, reinterpret_cast<const void *>(&deform_f32w_kernel), C::LDS_BYTES); e_ != hipSuccess) return (int)e_;
+    static PerDeviceOnce once3;
+    const bool x3 = p.out16_lo_off > 0 || p.x3;   // EMAVFI_F32X3: the contraction as a three-term f16 split (the fix-up loop stays on fp32 MFMAs)
+    if (const hipError_t e_ = x3 ? set_lds_limit(once3, reinterpret_cast<const void *>(&deform_f32w_kernel<true>), C::LDS_BYTES)
+                                 : set_lds_limit(once, reinterpret_cast<const void *>(&deform_f32w_kernel<false>), C::LDS_BYTES); e_ != hipSuccess) return (int)e_;
     const long long nwg = (long long)((p.W + C::TCOLS - 1) / C::TCOLS) * ((p.H + C::TROWS - 1) / C::TROWS) * p.B;
     if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    deform_f32w_kernel<<<(unsigned)nwg, C::THREADS, C::LDS_BYTES, s>>>(p);
+    if (x3) deform_f32w_kernel<true><<<(unsigned)nwg, C::THREADS, C::LDS_BYTES, s>>>(p);
+    else deform_f32w_kernel<false><<<(unsigned)nwg, C::THREADS, C::LDS_BYTES, s>>>(p);
     return (int)hipGetLastError();
 }

@@ -436,6 +436,7 @@ int run_deform(const Plan &P, const Layer &L, const void *packed, const void *x,
     DeformParams d{};
     d.census = census;
     d.out16_lo_off = out16_lo_off;
+    d.x3 = P.x3 && kd == EMAVFI_F32 ? 1 : 0;
     d.x = x; d.om = om; d.out = out;
     d.x_tail = x_tail; d.tail_ps = tail_ps;
     if (off) {  // fused ModulatedDeformConvPack: the kernel computes om itself (off = the copy in the kernel's on-chip type)

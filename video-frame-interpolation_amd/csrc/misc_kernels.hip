@@ -345,6 +345,22 @@ __global__ void pack_input_x3_kernel(const float *__restrict__ f1, const float *
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t b = i / plane, pix = i - b * plane;
         half_t *o = dst + i * 2 * cpad;
+        if (cpad == 16) {   // the model's case: 16-byte stores (the scalar loop below cost 1.1 ms at B = 8 x 720p)
+            float v[16], l[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                v[c] = 0.0f;
+                if (c < C) v[c] = f1[(b * C + c) * plane + pix];
+                else if (c < 2 * C) v[c] = f2[(b * C + (c - C)) * plane + pix];
+                l[c] = v[c] - (float)(half_t)v[c];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                store4(o + 4 * q, v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                store4(o + 16 + 4 * q, l[4 * q], l[4 * q + 1], l[4 * q + 2], l[4 * q + 3]);
+            }
+            continue;
+        }
         for (int c = 0; c < cpad; ++c) {
             float v = 0.0f;
             if (c < C) v = f1[(b * C + c) * plane + pix];
