@@ -177,16 +177,16 @@ __global__ __launch_bounds__(256, 2) void deform_f32w_kernel(const DeformParams 
                 a4[c] = half ? 0.0f : *reinterpret_cast<const float *>(wt + c * C::CB_BYTES + 2048 + lane4);
             }
             // EMAVFI_F32X3: the tap's weights as f16 (hi, lo) pairs; the leftover channel of lane (i, kb) sits at K = 4 kb of a K = 16 step
-            // (kept as one packed dword per output block: hi | lo << 16)
+            // (kept as one packed dword per output block: hi | lo << 16).  The x3 model's blob carries them already split
+            // (pack_deform_f32w_kernel, PackDesc::x3): a lane's 16 bytes are {hi[4], lo[4]} f16 instead of four floats
             HiLo w16[X3 ? 5 : 1][X3 ? 2 : 1];
             unsigned w4p[X3 ? 5 : 1];
             if constexpr (X3) {
 #pragma unroll
                 for (int c = 0; c < 5; ++c) {
-                    w16[c][0] = split_f16x4(a16[c][0]);
-                    w16[c][1] = split_f16x4(a16[c][1]);
-                    const half_t h4 = (half_t)a4[c], l4 = (half_t)(a4[c] - (float)h4);
-                    w4p[c] = (unsigned)__builtin_bit_cast(unsigned short, h4) | ((unsigned)__builtin_bit_cast(unsigned short, l4) << 16);
+                    w16[c][0] = __builtin_bit_cast(HiLo, a16[c][0]);
+                    w16[c][1] = __builtin_bit_cast(HiLo, a16[c][1]);
+                    w4p[c] = __float_as_uint(a4[c]);
                 }
             }
             Geo g[4];
@@ -312,14 +312,30 @@ __global__ __launch_bounds__(256, 2) void deform_f32w_kernel(const DeformParams 
                             }
                         }
                     }
+                    HiLo xs;
+                    if constexpr (X3) xs = split_f16x4(x);
 #pragma unroll
                     for (int c = 0; c < 5; ++c) {
                         if (part < 2) {
                             const f32x4 a = *reinterpret_cast<const f32x4 *>(wt + c * C::CB_BYTES + part * 1024 + lane16);
+                            if constexpr (X3) {
+                                mma_x3(accb[c], __builtin_bit_cast(HiLo, a), xs);
+                            } else {
 #pragma unroll
-                            for (int t = 0; t < 4; ++t) mma_f32_k4(accb[c], a[t], x[t]);
+                                for (int t = 0; t < 4; ++t) mma_f32_k4(accb[c], a[t], x[t]);
+                            }
                         } else {
-                            mma_f32_k4(accb[c], *reinterpret_cast<const float *>(wt + c * C::CB_BYTES + 2048 + lane4), x[0]);
+                            const float a1 = *reinterpret_cast<const float *>(wt + c * C::CB_BYTES + 2048 + lane4);
+                            if constexpr (X3) {
+                                typedef __attribute__((ext_vector_type(2))) unsigned u2_t;
+                                const unsigned pk = __float_as_uint(a1);
+                                HiLo ws;
+                                ws.hi = __builtin_bit_cast(f16x4_t, u2_t{pk & 0xffffu, 0u});
+                                ws.lo = __builtin_bit_cast(f16x4_t, u2_t{pk >> 16, 0u});
+                                mma_x3(accb[c], ws, xs);
+                            } else {
+                                mma_f32_k4(accb[c], a1, x[0]);
+                            }
                         }
                     }
                 }
@@ -362,7 +378,7 @@ static int launch_deform_f32w(const DeformParams &p, hipStream_t s)
     using C = F32W;
     static PerDeviceOnce once;   // (the library is re-entrant and serves several devices per process)
     static PerDeviceOnce once3;
-    const bool x3 = p.out16_lo_off > 0 || p.x3;   // EMAVFI_F32X3: the contraction as a three-term f16 split (the fix-up loop stays on fp32 MFMAs)
+    const bool x3 = p.x3 != 0;   // EMAVFI_F32X3: the contraction as a three-term f16 split; the blob carries the weights as f16 (hi, lo) pairs
     if (const hipError_t e_ = x3 ? set_lds_limit(once3, reinterpret_cast<const void *>(&deform_f32w_kernel<true>), C::LDS_BYTES)
                                  : set_lds_limit(once, reinterpret_cast<const void *>(&deform_f32w_kernel<false>), C::LDS_BYTES); e_ != hipSuccess) return (int)e_;
     const long long nwg = (long long)((p.W + C::TCOLS - 1) / C::TCOLS) * ((p.H + C::TROWS - 1) / C::TROWS) * p.B;

@@ -316,6 +316,7 @@ bool build_plan(Plan &P, int in_ch, int mid, int nb, int dtype)
         for (int i = 0; i < nb && ok; ++i) {
             P.dcn32[i] = mk(P.dcn[i].param, f, f);
             ok = deform_geometry(P.dcn32[i], 4);
+
             P.dcn32[i].w_off = o; o = rup256(o + P.dcn32[i].w_bytes);
             P.dcn32[i].b_off = o; o = rup256(o + (size_t)P.dcn32[i].coutpad * sizeof(float));
         }
@@ -326,7 +327,10 @@ bool build_plan(Plan &P, int in_ch, int mid, int nb, int dtype)
             if (deform_f32w_shape(P.dcn[i].ck, P.dcn[i].nf, P.dcn[i].cin_take, P.dcn[i].cout)) P.dcn[i].pack3 = 3;
     if (ok && P.wide())
         for (int i = 0; i < nb; ++i)
-            if (deform_f32w_shape(P.dcn32[i].ck, P.dcn32[i].nf, P.dcn32[i].cin_take, P.dcn32[i].cout)) P.dcn32[i].pack3 = 3;
+            if (deform_f32w_shape(P.dcn32[i].ck, P.dcn32[i].nf, P.dcn32[i].cin_take, P.dcn32[i].cout)) {
+                P.dcn32[i].pack3 = 3;
+                P.dcn32[i].x3 = P.x3;   // deform_f32w.inl's x3 form reads its weights as f16 (hi, lo) pairs (pack_deform_f32w_kernel)
+            }
     P.has_offh = false;
     P.feat16 = false;
     const bool p3 = ok && !P.wide() && dtype != EMAVFI_F32 && nb > 0 && deform_pack3_shape(P.dcn[0].ck, P.dcn[0].nf, P.dcn[0].cin_take, P.dcn[0].cout) &&
@@ -436,7 +440,7 @@ int run_deform(const Plan &P, const Layer &L, const void *packed, const void *x,
     DeformParams d{};
     d.census = census;
     d.out16_lo_off = out16_lo_off;
-    d.x3 = P.x3 && kd == EMAVFI_F32 ? 1 : 0;
+    d.x3 = L.x3 && L.pack3 == 3 ? 1 : 0;
     d.x = x; d.om = om; d.out = out;
     d.x_tail = x_tail; d.tail_ps = tail_ps;
     if (off) {  // fused ModulatedDeformConvPack: the kernel computes om itself (off = the copy in the kernel's on-chip type)

@@ -190,7 +190,29 @@ __global__ void pack_deform_f32w_kernel(const float *__restrict__ w, const float
         if (t < 512) { const int G = t / 256, r = t - G * 256; lane = r >> 2; ci = 36 * half + 16 * G + 4 * (lane >> 4) + (r & 3); }
         else { lane = t - 512; ci = 36 * half + 32 + (lane >> 4); }
         const int co = 16 * c + (lane & 15);
-        wp[idx] = (co < d.cout && ci < d.cin_take) ? w[((size_t)co * d.cin_raw + d.cin_off + ci) * 9 + tap] : 0.0f;
+        if (!d.x3) {
+            wp[idx] = (co < d.cout && ci < d.cin_take) ? w[((size_t)co * d.cin_raw + d.cin_off + ci) * 9 + tap] : 0.0f;
+            continue;
+        }
+        // EMAVFI_F32X3: the same bytes hold f16 (hi, lo) pairs - a lane's four floats become {hi[4], lo[4]}, the leftover float {hi, lo}:
+        // float slot r of the lane's quad (r = 0..3) holds half elements (2 r, 2 r + 1) of that 8-half vector
+        half_t *hp = reinterpret_cast<half_t *>(wp + idx);
+        auto wval = [&](int cin) { return (co < d.cout && cin < d.cin_take) ? w[((size_t)co * d.cin_raw + d.cin_off + cin) * 9 + tap] : 0.0f; };
+        if (t < 512) {
+            const int r = t & 3, cbase = ci - r;   // the quad's first channel
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int e = 2 * r + q;           // element of {hi0..hi3, lo0..lo3}
+                const float v = wval(cbase + (e & 3));
+                const half_t hi = (half_t)v;
+                hp[q] = e < 4 ? hi : (half_t)(v - (float)hi);
+            }
+        } else {
+            const float v = wval(ci);
+            const half_t hi = (half_t)v;
+            hp[0] = hi;
+            hp[1] = (half_t)(v - (float)hi);
+        }
     }
     const int coutpad = d.npass * d.nf * 32;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < coutpad; i += gridDim.x * blockDim.x) bp[i] = (i < d.cout && bias) ? bias[i] : 0.0f;
