@@ -79,7 +79,10 @@ extern "C" {
  * fp16-valued flow and torchvision's deform_conv2d (ema_vfi.py:60)
  * in fp32 on the UNROUNDED fp32 fusion tensor with the fp32 master weights (its Autocast kernel casts every argument
  * to float and the result back to the input's dtype, which is fp32 because cat(feat, warped) promotes), offsets /
- * sigmoid(mask) as fp16 values, tanh and (t+1)/2 in fp16.  The frame holds fp16-representable values.
+ * sigmoid(mask) as fp16 values, tanh and (t+1)/2 in fp16.  The frame holds fp16-representable values.  Since 0.4.3 the fp32 deform_conv2d
+ * of THIS mode contracts as a three-term f16 split (22 bits of each operand, exact products, fp32 accumulation: 3e-7 .. 1.4e-6 relative,
+ * the spread between two fp32 summation orders - which is what separates any GPU run of the reference from its CPU run anyway); its
+ * sampling positions, corner weights and blend are fp32 as before.  EMAVFI_F32 is the mode with exact fp32 FMA chains.
  * EMAVFI_F16 stays the FAST half-precision mode (DCN contraction and blend in fp16 too). */
 #define EMAVFI_AMP16 3
 /* fp32-ACCURATE contractions on the 16-bit matrix pipe (round 6; gfx950 has no TF32 and its fp32 MFMA runs at 1/16 of the f16 rate):

@@ -329,7 +329,11 @@ bool build_plan(Plan &P, int in_ch, int mid, int nb, int dtype)
         for (int i = 0; i < nb; ++i)
             if (deform_f32w_shape(P.dcn32[i].ck, P.dcn32[i].nf, P.dcn32[i].cin_take, P.dcn32[i].cout)) {
                 P.dcn32[i].pack3 = 3;
-                P.dcn32[i].x3 = P.x3;   // deform_f32w.inl's x3 form reads its weights as f16 (hi, lo) pairs (pack_deform_f32w_kernel)
+                // deform_f32w.inl's x3 form (weights as f16 (hi, lo) pairs, three 16x16x16 f16 MFMAs per K = 16 step: 22 bits of each operand,
+                // exact products, fp32 accumulation - the error class of an fp32 convolution's own summation order).  Also the autocast-policy
+                // mode's DCN since round 6: torchvision's CUDA kernel is an fp32 computation in ANOTHER summation order, every result of this
+                // mode is rounded to fp16 behind it, and the op is 73 % of that mode's step (6.9 -> 4.7 ms per launch).  EMAVFI_F32 stays exact.
+                P.dcn32[i].x3 = P.x3 || P.amp;
             }
     P.has_offh = false;
     P.feat16 = false;
