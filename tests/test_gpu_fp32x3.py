@@ -132,3 +132,20 @@ def test_stage_entries_refuse_the_mode_they_do_not_have():
     x = torch.randn(1, 67, 8, 8, device=DEV)
     with pytest.raises(RuntimeError, match="F32X3"):
         lib.mdcn(x, torch.randn(27, 67, 3, 3, device=DEV), torch.zeros(27, device=DEV), torch.randn(67, 67, 3, 3, device=DEV), None, dtype="fp32x3")
+
+
+@pytest.mark.parametrize("mid,B,H,W", [(64, 1, 1, 40), (64, 1, 33, 1), (64, 2, 5, 7), (64, 1, 75, 131), (16, 2, 23, 37), (32, 1, 24, 40), (8, 1, 9, 70)])
+def test_forward_ragged_sizes_and_other_widths_against_the_oracle(mid, B, H, W):
+    """Images smaller than a tile, one row, one column, ragged remainders, and the narrower models (generic fp32 deformable kernel instead
+    of the LDS-window one): the frame against the CPU oracle under the fp32 gate, the flow and the fused tensors at 5e-4 relative."""
+    sd = synth.synthetic_state_dict(seed=3, mid_channels=mid)
+    f1, f2 = synth.synthetic_frames(40 + H, B, H, W, "natural")
+    ref = {}
+    oracle.forward(sd, f1, f2, taps=ref)
+    m = make_model(sd, mid=mid)
+    with torch.no_grad():
+        out, taps = m(f1.to(DEV), f2.to(DEV), return_taps=True)
+    assert (out.cpu() - ref["out"]).abs().max().item() <= 1e-3
+    for k in ("feat", "flow", "fused_2"):
+        err = (taps[k].cpu() - ref[k]).abs().max().item() / max(1.0, ref[k].abs().max().item())
+        assert err <= 5e-4, (k, err)
