@@ -76,7 +76,11 @@ def test_bench_json_contract():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert rf["traffic"] is None or rf["traffic"] > 0
     assert "traffic_source" in rf     # PMC bytes are refused when profiles/traffic.json was measured on other kernel sources
+    # round 6: where the headline sits on the pack's offset curve - the kernels' own counters of the last timed forward
+    assert len(rf["fixup_share"]) == 3 and all(0.0 <= v <= 1.0 for v in rf["fixup_share"])
+    assert all(pp["wave_taps"] == 2 * 6 * 8 * 4 * 9 for pp in rf["offset_census"]["per_pack"])      # B = 2, 96 x 128: 6 x 8 tiles x 4 waves x 9 taps
     cb = r["cpu_baseline"]
+    assert 0.3 <= cb["dcn_restatement_share"] <= 0.99 and cb["gflops_aten_only"] > cb["gflops"] and cb["cores"] <= 16
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb and cb["unit"] == "frames/s"
     assert cb["cpu_model"] and cb["also_256x256"]["value"] > 0 and "1 full-size warm-up + 2 timed" in cb["sample"]
     assert cb["also_config1_b16_256x256"]["value"] > 0
@@ -84,7 +88,8 @@ def test_bench_json_contract():
     assert r["accuracy_vs_cpu_oracle"]["fp16"]["psnr_db"] >= r["accuracy_vs_cpu_oracle"]["bf16"]["psnr_db"]
     # reported beside `value`, never instead of it: the other arithmetic modes at the same size, BASELINE configs[1]
     # (batch 16 of 256x256) in fp32 and bf16, and the warp kernel the forward itself runs
-    for k in ("also_fp16_fast", "also_amp16_autocast_policy", "also_fp32_exact"):
+    assert r["accuracy_vs_cpu_oracle"]["fp32x3"]["max_abs"] <= 1e-3      # the fp32-accurate split mode under the fp32 gate
+    for k in ("also_fp16_fast", "also_amp16_autocast_policy", "also_fp32_exact", "also_fp32_split16"):
         assert r[k]["value"] > 0 and r[k]["height"] == 96, k
     assert r["config1_256"]["fp32"]["value"] > 0 and r["config1_256"]["bf16"]["pairs_per_step"] == 16
     # the exact-fp32 mode (the one north_star's 1e-3 bound is about) with ITS dominant kernel's roofline, at both sizes

@@ -210,6 +210,8 @@ struct ConvParams {
     // x_hi w_hi, x_hi w_lo, x_lo w_hi (the products are exact in fp32; x_lo w_lo, 2^-22 relative, is dropped).  nchunk counts the VIRTUAL
     // chunks; x3_lo_off / out_lo_off = element offset of the lo half inside an input / output pixel; in_ps / out_ps are whole-pixel strides.
     int x3, x3_lo_off, out_lo_off;
+    float *out32;   // x3 only: ALSO store the fp32 value, channels-last with pixel stride out32_ps (the last feature layer writes `feat` into the
+    int out32_ps;   // fp32 fusion tensor the exact DCN reads: saves the widening pass' read of 1.9 GB at B = 8 x 720p)
 };
 
 // In-kernel stamps of the LDS-ring convolution kernels (diagnostic build only; cdna_hip_programming.md section 7): s_memtime at the

@@ -169,6 +169,9 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[MF][NF], const
                         const float r = relu ? fmaxf(v, 0.0f) : v;
                         return r - (float)(T)r;
                     });
+                    if (p.out32)
+                        store_frag(p.out32 + pix * p.out32_ps + p.out_coff + (pass * NF + n) * 32, acc[m][n], h, limit,
+                                   [relu](float v, int) { return relu ? fmaxf(v, 0.0f) : v; });
                 }
                 continue;
             }

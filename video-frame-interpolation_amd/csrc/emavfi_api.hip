@@ -372,9 +372,11 @@ unsigned long long *debug_stamp_buffer();
 int run_conv(const Plan &P, const Layer &L, const void *packed, const void *in, int in_ps, int Hin, int Win, void *out,
              int out_ps, int out_coff, int cstore, int epi, int B, hipStream_t s, const float *bias_table = nullptr,
              float *planar = nullptr, int nplanes = 0, const void *zeros = nullptr, const Layer *head = nullptr,
-             const FirstParams *first = nullptr, int epi2 = 0, int out_alt = 0, const Layer *second = nullptr, float *pool_part = nullptr)
+             const FirstParams *first = nullptr, int epi2 = 0, int out_alt = 0, const Layer *second = nullptr, float *pool_part = nullptr,
+             float *out32 = nullptr, int out32_ps = 0)
 {
     ConvParams c{};
+    c.out32 = L.x3 ? out32 : nullptr; c.out32_ps = out32_ps;
     c.pool_part = pool_part;
     if (second) {   // conv_ring2.inl: `second` runs behind L in the same launch; out / out_ps / cstore / out_alt are ITS output's
         c.w2 = (const char *)packed + second->w_off;
@@ -838,9 +840,10 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
                                  nullptr, nullptr, 0, last && feat16 ? 1 : 0, &P.blk[j]));
             i = j;
         } else {
-            EMAVFI_STEP(rec, conv_name(P, P.blk[i]) + " feat_ext_blocks", fl, by,
+            // (EMAVFI_F32X3: the last block also writes `feat` in fp32 into the fusion tensor the exact DCN reads)
+            EMAVFI_STEP(rec, conv_name(P, P.blk[i]) + " feat_ext_blocks", fl, by + (last && P.x3 ? px * mid * 4.0 : 0.0),
                         run_conv(P, P.blk[i], packed, cur, P.p_mid, H, W, dst, last ? P.fps : P.p_mid, 0, P.p_mid, EPI_RELU, B, s, nullptr, nullptr, 0, nullptr,
-                                 nullptr, nullptr, 0, last && feat16 ? 1 : 0));
+                                 nullptr, nullptr, 0, last && feat16 ? 1 : 0, nullptr, nullptr, last && P.x3 ? f.fuF0 : nullptr, P.fpad));
         }
         if (!last) { void *t = cur; cur = nxt; nxt = t; }
     }
@@ -893,7 +896,8 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
         if (P.x3) {
             EMAVFI_STEP(rec, "warp_fused<f32>", 24.0 * px, px * (8.0 + 8.0 * C), launch_warp_fused(frame2, f.flow, xF, B, C, H, W, P.fpad, mid, EMAVFI_F32, s));
             EMAVFI_STEP(rec, "fusion_split_warped", 0, px * (P.fpad - mid) * 8.0, launch_convert_cl(xF, f.fu0, npx, P.fpad, 2 * P.fps, mid, P.fpad - mid, 0, s, P.fps));
-            EMAVFI_STEP(rec, "fusion_widen_feat", 0, px * mid * 8.0, launch_convert_cl(f.fu0, xF, npx, 2 * P.fps, P.fpad, 0, mid, 1, s, P.fps));
+            // (`feat`'s fp32 copy is already in xF: the last feature layer wrote it beside its f16 halves; nb == 0 has no such layer)
+            if (P.nb == 0) EMAVFI_STEP(rec, "fusion_widen_feat", 0, px * mid * 8.0, launch_convert_cl(f.fu0, xF, npx, 2 * P.fps, P.fpad, 0, mid, 1, s, P.fps));
         } else {
             EMAVFI_STEP(rec, "warp_fused<f32>", 24.0 * px, px * (8.0 + 8.0 * C + 2.0 * C),
                         launch_warp_fused(frame2, f.flow, xF, B, C, H, W, P.fpad, mid, EMAVFI_F32, s, f.fu0, P.fps));

@@ -449,8 +449,41 @@ __global__ void convert_cl_kernel(const void *__restrict__ src, void *__restrict
         }
     }
 }
+// EMAVFI_F32X3, the model's case of the narrow conversion: 16 fp32 channels of every pixel -> their f16 (hi, lo) halves, one thread per
+// pixel, whole 16-byte stores (the generic kernel above ran four threads per pixel on 8-byte stores: 0.8 ms at B = 8 x 720p for 16 channels)
+__global__ void split16_cl_kernel(const float *__restrict__ src, half_t *__restrict__ dst, size_t npx, int ps_src, int ps_dst, int c0, int lo_off)
+{
+    for (size_t px = (size_t)blockIdx.x * blockDim.x + threadIdx.x; px < npx; px += (size_t)gridDim.x * blockDim.x) {
+        const float *i = src + px * ps_src + c0;
+        half_t *o = dst + px * ps_dst + c0;
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(i + 4 * q);
+            v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+        }
+        unsigned hi[8], lo[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const half_t h0 = (half_t)v[2 * q], h1 = (half_t)v[2 * q + 1];
+            const half_t l0 = (half_t)(v[2 * q] - (float)h0), l1 = (half_t)(v[2 * q + 1] - (float)h1);
+            hi[q] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+            lo[q] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            *reinterpret_cast<uint4 *>(o + 8 * q) = make_uint4(hi[4 * q], hi[4 * q + 1], hi[4 * q + 2], hi[4 * q + 3]);
+            *reinterpret_cast<uint4 *>(o + lo_off + 8 * q) = make_uint4(lo[4 * q], lo[4 * q + 1], lo[4 * q + 2], lo[4 * q + 3]);
+        }
+    }
+}
 int launch_convert_cl(const void *src, void *dst, size_t npx, int ps_src, int ps_dst, int c0, int nc, int widen, hipStream_t s, int lo_off)
 {
+    if (!widen && lo_off > 0 && nc == 16 && (c0 & 7) == 0 && (lo_off & 7) == 0 && (ps_dst & 7) == 0 && (ps_src & 3) == 0) {
+        const int grid16 = (int)std::min<size_t>((npx + 255) / 256, 65535 * 4);
+        split16_cl_kernel<<<grid16, 256, 0, s>>>((const float *)src, (half_t *)dst, npx, ps_src, ps_dst, c0, lo_off);
+        return (int)hipGetLastError();
+    }
     const int grid = (int)std::min<size_t>((npx * (nc / 4) + 255) / 256, 65535 * 4);
     if (widen) convert_cl_kernel<true><<<grid, 256, 0, s>>>(src, dst, npx, ps_src, ps_dst, c0, nc, lo_off);
     else convert_cl_kernel<false><<<grid, 256, 0, s>>>(src, dst, npx, ps_src, ps_dst, c0, nc, lo_off);
