@@ -46,8 +46,9 @@ int main()
     CHECK(emavfi_version() == EMAVFI_VERSION);
     CHECK(emavfi_param_count(3) == 40 && emavfi_param_count(1) == 28);
     const int dtypes[4] = {EMAVFI_F32, EMAVFI_BF16, EMAVFI_F16, EMAVFI_AMP16};
+    const int modes[5] = {EMAVFI_F32, EMAVFI_BF16, EMAVFI_F16, EMAVFI_AMP16, EMAVFI_F32X3};   // (the split mode has a forward and a conv3x3 stage entry only)
     for (int mid : {8, 16, 32, 64})
-        for (int dt : dtypes)
+        for (int dt : modes)
             for (int nb : {1, 2, 3, 8}) {
                 CHECK(emavfi_supported(3, mid, nb, dt) == EMAVFI_OK);
                 CHECK(emavfi_packed_bytes(3, mid, nb, dt) > 256);
@@ -63,7 +64,7 @@ int main()
     CHECK(emavfi_workspace_bytes(3, 64, 3, 1, -5, 8, EMAVFI_F32) == 0);
 
     // launch enumeration: exact buffers, a names buffer that is too small, capacity too small, null outputs
-    for (int dt : dtypes) {
+    for (int dt : modes) {
         const int n = emavfi_forward_launches(3, 64, 3, 2, 96, 128, dt, nullptr, 0, nullptr, nullptr, 0);
         CHECK(n >= 12 && n <= 40);
         std::vector<char> names(128 * (size_t)n);
@@ -125,6 +126,10 @@ int main()
     CHECK(emavfi_deform_conv2d(ff, ff, ff, ff, ff, fo, 1, 67, 67, 16, 16, EMAVFI_BF16, fake, 16, nullptr) == EMAVFI_E_WORKSPACE);
     CHECK(emavfi_deform_conv2d(ff, ff, ff, ff, ff, fo, 1, 67, 67, 4096, 4096, EMAVFI_BF16, fake, 16, nullptr) == EMAVFI_E_ARG);
     for (int dt : dtypes) CHECK(emavfi_mdcn_workspace_bytes(2, 67, 75, 131, dt, 0) > 0);
+    CHECK(emavfi_mdcn_workspace_bytes(2, 67, 75, 131, EMAVFI_F32X3, 0) == 0 && strstr(emavfi_last_error(), "F32X3"));
+    CHECK(emavfi_context_workspace_bytes(2, 64, 75, 131, EMAVFI_F32X3) == 0 && emavfi_conv3x3_workspace_bytes(2, 67, 64, 75, 131, 1, EMAVFI_F32X3) > 0);
+    // the split mode's pixels are two f16 halves: the bytes of the fp32 mode's activations, three weight copies per chunk
+    CHECK(emavfi_conv3x3_workspace_bytes(2, 64, 64, 75, 131, 1, EMAVFI_F32X3) > emavfi_conv3x3_workspace_bytes(2, 64, 64, 75, 131, 1, EMAVFI_F16));
     CHECK(emavfi_mdcn_workspace_bytes(1, 67, 32, 32, EMAVFI_BF16, EMAVFI_MDCN_SPLIT_TAIL | EMAVFI_MDCN_IN_F16 | EMAVFI_MDCN_OUT_F16) > 0);
     CHECK(emavfi_mdcn_workspace_bytes(1, 66, 32, 32, EMAVFI_F32, 0) == 0 && emavfi_mdcn_workspace_bytes(1, 3, 32, 32, EMAVFI_F32, 0) == 0);
     CHECK(emavfi_mdcn_workspace_bytes(1, 67, 32, 32, EMAVFI_F32, EMAVFI_MDCN_IN_F16) == 0 && emavfi_mdcn_workspace_bytes(1, 67, 32, 32, EMAVFI_BF16, 8) == 0);

@@ -37,6 +37,16 @@ def test_host_queries_and_error_codes():
         for dt in (lib.F32, lib.BF16, lib.F16):
             assert L.emavfi_supported(3, mid, 3, dt) == 0
             assert L.emavfi_packed_bytes(3, mid, 3, dt) > 0
+    # round 6: the fp32-accurate split mode - its own dtype code, a plan on the generic tile kernels (three weight copies per chunk),
+    # activations as two f16 halves (the workspace of the autocast-policy mode and more), launches enumerable without a GPU
+    for mid in (8, 64):
+        assert L.emavfi_supported(3, mid, 3, lib.F32X3) == 0
+    assert lib.dtype_code("fp32x3") == lib.F32X3 == 4 and "#define EMAVFI_F32X3 4\n" in open(os.path.join(ROOT, "include", "emavfi.h")).read()
+    assert L.emavfi_packed_bytes(3, 64, 3, lib.F32X3) > L.emavfi_packed_bytes(3, 64, 3, lib.AMP16)
+    assert L.emavfi_workspace_bytes(3, 64, 3, 2, 96, 128, lib.F32X3) > L.emavfi_workspace_bytes(3, 64, 3, 2, 96, 128, lib.AMP16)
+    names = [n for n, _, _ in lib.forward_launches(3, 64, 3, 2, 96, 128, "fp32x3")]
+    assert sum("deform<f32" in n for n in names) == 3 and "fusion_split_warped" in names and not any("ring" in n or "+" in n.split(" ")[0] for n in names)
+    assert L.emavfi_mdcn_workspace_bytes(1, 67, 8, 8, lib.F32X3, 0) == 0 and "F32X3" in lib.last_error()
     assert L.emavfi_supported(3, 7, 3, lib.F32) == -2 and "multiple of 8" in lib.last_error()
     assert L.emavfi_supported(3, 64, 3, 5) == -2
     assert L.emavfi_supported(3, 24, 3, lib.F32) == -2  # 27 -> 32 wide fusion has kernels, 96-wide context does not
