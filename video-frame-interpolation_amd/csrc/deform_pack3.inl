@@ -17,8 +17,9 @@
 //     (pixel, piece) and its source pointer / row increment are computed ONCE and a DMA instruction costs one 64-bit add
 //     and one select (was ~25 address instructions per DMA instruction, 6 200 cycles of issue per tile).
 //   * The blend is issued corner-major (four independent chains), which hipcc's scheduler had turned back into four dependent
-//     chains with a wait state behind every v_pk_fma_f16 (63 s_nop per tap); the sample-outside-the-window fallback is a
-//     separate copy of the tap body, so the common path carries none of its address arithmetic or EXEC regions.
+//     chains with a wait state behind every v_pk_fma_f16 (63 s_nop per tap); the sample-outside-the-window fix-up is a pass of its
+//     own behind the tap loop (round 6: an arena in the then dead window, the same tap body), so the common path carries none of
+//     its address arithmetic or EXEC regions.
 //   * bf16 storage may hand f16 bit patterns between consecutive packs (DeformParams::in_f16 / out_f16): the window is f16 on
 //     chip anyway (deform_pack.inl), so pack i+1 skips the in-LDS conversion pass and the intermediate fusion tensor keeps 11
 //     significant bits instead of 8.
@@ -77,33 +78,6 @@ struct Pack3 {
 
 // window byte offset of plain tap t relative to tap 0 (taps past 8 re-read tap 8: finite data against zero weights)
 __host__ __device__ constexpr int pack3_tap_off(int t) { return t < 9 ? ((t / 3) * Pack3::TC + (t % 3)) * Pack3::PSB : (2 * Pack3::TC + 2) * Pack3::PSB; }
-
-// storage -> on-chip f16: bf16 storage converts unless the producer already wrote f16 bit patterns (DeformParams::in_f16)
-template <typename TS> __device__ __forceinline__ u32x4_t to_f16_piece_rt(u32x4_t v, int in_f16)
-{
-    if constexpr (std::is_same<TS, bf16_t>::value) return in_f16 ? v : to_f16_piece<TS>(v);
-    return v;
-}
-
-// corner-major blend with the four passes pinned in order for VALU (other instruction classes may move across)
-template <int NQ> __device__ __forceinline__ void blend_corners_cm(const unsigned (&d)[4][4], unsigned w01, unsigned w23, unsigned (&out)[4])
-{
-    f16x2_t a[4];
-    constexpr int KEEP = 0x0008 | 0x0010 | 0x0080 | 0x0004;  // MFMA, VMEM, DS, SALU may cross; VALU may not
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) a[q] = __builtin_bit_cast(f16x2_t, d[0][q]) * bcast_half<0>(w01);
-    __builtin_amdgcn_sched_barrier(KEEP);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) a[q] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d[1][q]), bcast_half<1>(w01), a[q]);
-    __builtin_amdgcn_sched_barrier(KEEP);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) a[q] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d[2][q]), bcast_half<0>(w23), a[q]);
-    __builtin_amdgcn_sched_barrier(KEEP);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) a[q] = __builtin_elementwise_fma(__builtin_bit_cast(f16x2_t, d[3][q]), bcast_half<1>(w23), a[q]);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) out[q] = __builtin_bit_cast(unsigned, a[q]);
-}
 
 // Pins a point of the hand-made schedule: an empty volatile asm that "rewrites" the four partial sums (instruction selection
 // otherwise places plain arithmetic anywhere between its operands and its users, on either side of a scheduling fence - half of
