@@ -167,6 +167,23 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
+def granted_cpu_threads(cgroup_file="/sys/fs/cgroup/cpu.max"):
+    """Every core this job is GRANTED: the affinity mask, a cgroup CPU quota if one is set, and the pool's stated share for a one-GPU
+    job (16; EMAVFI_CPU_THREADS overrides the share).  The GPU box lists ALL 256 host cores in the affinity mask against a 16-CPU
+    quota: taking them all oversubscribes the quota 16 x and the oracle crawls (round 6: a 7-minute silence in the first bench run)."""
+    try:
+        granted = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        granted = os.cpu_count() or 1
+    try:
+        quota, period = open(cgroup_file).read().split()
+        if quota != "max":
+            granted = min(granted, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(granted, int(os.environ.get("EMAVFI_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(sd, height, width, reps, dev=None):
     """The oracle (CPU restatement, kind "port") per SURVEY.md section 8(d): fp32, ONE full-size warm-up + `reps` (default 3) timed
     forwards, median - one 1280x720 pair (B = 1: the unit `value` counts), one 256x256 pair, and BASELINE configs[1]'s batch of 16
@@ -174,20 +191,7 @@ def cpu_baseline(sd, height, width, reps, dev=None):
     The full frame then goes through the HIP path in all three arithmetic modes for the accuracy fields."""
     from emavfi import synth
     from oracle import emavfi_oracle as oracle
-    # every core this job is GRANTED: the affinity mask, a cgroup CPU quota if one is set, and the pool's stated share for a one-GPU job
-    # (16: the GPU box exposes ALL host cores in the affinity mask - taking them all oversubscribes the share and the oracle crawls;
-    # EMAVFI_CPU_THREADS overrides the share)
-    try:
-        granted = len(os.sched_getaffinity(0))
-    except (AttributeError, OSError):
-        granted = os.cpu_count() or 1
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            granted = min(granted, max(1, int(quota) // int(period)))
-    except (OSError, ValueError):
-        pass
-    threads = max(1, min(granted, int(os.environ.get("EMAVFI_CPU_THREADS", "16"))))
+    threads = granted_cpu_threads()
     torch.set_num_threads(threads)
     cpu_sd = {k: v.float().cpu() for k, v in sd.items()}
     # the split VERDICT r5 asks for: the three deformable convolutions are a restatement in Python-level tensor ops (torchvision's C++

@@ -194,3 +194,22 @@ def test_fixup_census_restates_the_pack_kernels_window_test():
     assert abs(got["samples_outside_window"] - out / (9 * H * W)) < 1e-5
     assert abs(got["wave_taps_in_fixup_loop"] - len(groups) / (9 * (Hp // 4) * (Wp // 16))) < 1e-5
     assert out > 0 and len(groups) > 0
+
+
+def test_bench_host_helpers(tmp_path, monkeypatch):
+    """bench.py's host-side helpers of round 6 (no GPU): the CPU thread count of the oracle baseline = min(affinity, cgroup quota, share),
+    and the summary of the per-rank PCIe leg (aggregate = all pairs / the SLOWEST rank's time)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    q = tmp_path / "cpu.max"
+    q.write_text("400000 100000\n")
+    monkeypatch.delenv("EMAVFI_CPU_THREADS", raising=False)
+    n_aff = len(os.sched_getaffinity(0))
+    assert bench.granted_cpu_threads(str(q)) == min(4, n_aff)                     # a 4-CPU quota caps a wider mask
+    q.write_text("max 100000\n")
+    assert bench.granted_cpu_threads(str(q)) == min(16, n_aff)                    # no quota: the pool's stated share
+    monkeypatch.setenv("EMAVFI_CPU_THREADS", "2")
+    assert bench.granted_cpu_threads(str(tmp_path / "missing")) == min(2, n_aff)
+    s = bench.stream_leg_summary([[1.0, 64.0, 129.0, 0.5], [0.0, 64.0, 128.0, 0.4]], 1000.0)
+    assert s["stream_pcie_per_rank"] == [160.0, 128.0] and s["stream_pcie_aggregate"] == 256.0 and s["fraction_of_resident_value"] == 0.256
+    assert s["pairs_per_rank"] == [64, 64] and s["frames_out_per_rank"] == [128, 129]
