@@ -580,13 +580,14 @@ def per_kernel_table(hip, ev, launches, steps, dtype):
 def warp_in_forward(table, agg, dtype, px):
     """The warp kernel the forward actually runs (row W inside the timed region).  Two accountings, both printed: the ALGORITHMIC
     bytes (8 B flow + 12 B frame2 read + 3 channels of the storage type written: 26 B/px in the 16-bit modes, 32 B/px in fp32) and the
-    bytes the layout forces it to move (16-bit modes: the three channels leave as one 16-byte slot of the first pack's window DMA,
-    8 + 12 + 16 = 36 B/px; fp32: the warp fills channels 64..79 of the 80-channel fusion pixels, 8 + 12 + 64 = 84 B/px)."""
+    bytes the layout forces it to move (16-bit modes: the three channels leave as a four-channel tail record, 8 + 12 + 8 = 28 B/px -
+    round 6; 36 with the 16-byte record of rounds 3-5; fp32: the warp fills channels 64..79 of the 80-channel fusion pixels,
+    8 + 12 + 64 = 84 B/px)."""
     wk = [t for t in table if t["kernel"].startswith("warp_fused")]
     if not wk:
         return None
     wa = agg[wk[0]["kernel"]]
-    moved = (36.0 if dtype != "fp32" else 84.0) * px
+    moved = (28.0 if dtype != "fp32" else 84.0) * px
     return {"kernel": wk[0]["kernel"], "bound": "hbm", "achieved": wk[0]["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": round(wk[0]["gbs"] / PEAK_HBM_GBS, 4), "avg_launch_us": wk[0]["avg_us"],
             "algorithmic_bytes_per_launch": wa["bytes"] / wa["n"], "layout_bytes_per_launch": moved,

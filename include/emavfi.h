@@ -238,7 +238,7 @@ int emavfi_deform_conv2d(const float *x, const float *offset, const float *mask,
  * runs conv3x3 + the fp32 LDS-window DCN; EMAVFI_AMP16 the fp16 offset_conv + fp32 DCN pair; other widths conv3x3 + the
  * global-gather DCN.  `flags` reproduce the forms the forward hands the tensor over in (one-launch kernel only):
  *   EMAVFI_MDCN_IN_F16 / _OUT_F16  bf16 model: x is stored / y is produced as IEEE f16 bit patterns (hand-off between packs, `feat`);
- *   EMAVFI_MDCN_SPLIT_TAIL         channels mid.. of x reach the kernel through the compact 8-channel buffer (the first pack's input). */
+ *   EMAVFI_MDCN_SPLIT_TAIL         channels mid.. of x reach the kernel through the compact tail buffer - 4 channels per pixel - (the first pack's input). */
 #define EMAVFI_MDCN_IN_F16 1
 #define EMAVFI_MDCN_OUT_F16 2
 #define EMAVFI_MDCN_SPLIT_TAIL 4

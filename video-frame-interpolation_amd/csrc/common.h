@@ -261,7 +261,7 @@ struct DeformParams {
     const void *off_w;
     const float *off_bias;
     // split input (bf16/f16 LDS kernel only): channels [64, 72) of every pixel come from the compact channels-last
-    // buffer x_tail[px][tail_ps = 8] instead of x (the warp writes 16 contiguous bytes per pixel there instead of 6
+    // buffer x_tail[px][tail_ps = 4 since round 6: 8 bytes per pixel; 8 before] instead of x (the warp writes one contiguous record per pixel there instead of 6
     // useful bytes into every 160-byte fusion pixel); channels 72.. are zero
     const void *x_tail;
     int tail_ps;

@@ -498,6 +498,13 @@ struct Workspace {
 constexpr size_t kCensusBlock = (size_t)DEFORM_CENSUS_SLOTS * 4 * sizeof(unsigned);   // one launch's census
 constexpr size_t kCensusBytes = (size_t)kMaxBlocks * kCensusBlock;
 
+// The compact tail of the fusion input (channels mid .. mid + 2, the warped frame): FOUR 16-bit channels = 8 bytes per pixel (round 6; was 8
+// channels = 16 bytes).  The pack kernel's window DMA fetches 16 bytes per pixel from it - the pixel's tail and its right neighbour's,
+// which land in channels 68..71 of the window slot: finite values against zero weights, never read by the 8-byte tail reads - so the
+// buffer keeps 8 bytes of slack behind its last pixel (it lives in the 16-channel packed-input buffer: plenty).  The warp then moves
+// 8 + 12 + 8 = 28 bytes per pixel instead of 36.
+constexpr int kTailPs = 4;
+
 struct FwdBuffers {
     void *in16, *fA, *fB, *fu0, *fu1, *c1, *c2, *c3;
     float *fuF0, *fuF1;  // amp: fp32 copies of the fusion tensor (input / output of the fp32 DCN)
@@ -617,7 +624,7 @@ bool pack_f16_link(const Plan &P, int i)
     return P.dtype == EMAVFI_BF16 && pack_f16_chain() && i >= 0 && i + 1 < P.nb && P.dcn[i].pack3 && P.dcn[i + 1].pack3 && pack_fuses(P, i) &&
            pack_fuses(P, i + 1);
 }
-// 16-bit / fp32 models: x -> y (channels-last, pixel stride P.fps).  x_tail: the compact 8-channel buffer the first pack takes channels
+// 16-bit / fp32 models: x -> y (channels-last, pixel stride P.fps).  x_tail: the compact tail buffer (kTailPs channels per pixel) the first pack takes channels
 // 64.. from (or null); in_f16 / out_f16: the bf16 model's f16 hand-off (DeformParams)
 int attention_block(const Plan &P, int i, const void *packed, const void *x, void *y, float *om, const void *x_tail, int in_f16, int out_f16,
                     int B, int H, int W, hipStream_t s, Recorder &rec, unsigned *census = nullptr)
@@ -629,7 +636,7 @@ int attention_block(const Plan &P, int i, const void *packed, const void *x, voi
         // one launch for the whole pack (ema_vfi.py:54-60): offset_conv on the staged window, then the DCN;
         // the input is read once and the offsets / masks never leave the registers
         EMAVFI_STEP(rec, deform_name(P, P.dcn[i]) + " offset_conv+dcn_v2", fl + 2.0 * 9.0 * cf * cf * px, px * (2.0 * cf * e) + 9.0 * cf * (cf + 27.0) * e,
-                    run_deform(P, P.dcn[i], packed, x, P.fps, om, y, P.fps, P.fps, B, H, W, s, nullptr, P.has_offh ? &P.offh[i] : &P.off[i], x_tail, 8,
+                    run_deform(P, P.dcn[i], packed, x, P.fps, om, y, P.fps, P.fps, B, H, W, s, nullptr, P.has_offh ? &P.offh[i] : &P.off[i], x_tail, kTailPs,
                                -1, in_f16, out_f16, nullptr, 0, census));
     } else {
         if (x_tail || in_f16 || out_f16) return fail(EMAVFI_E_UNSUPPORTED, "attention block: split tail / f16 hand-off need the one-launch pack kernel");
@@ -916,14 +923,14 @@ int forward_impl(int in_channels, int mid_channels, int num_blocks, const void *
     } else {
         // --- warp frame2 by the flow into channels [mid, fpad) of the fusion buffer (ema_vfi.py:130,134).
         // When the first pack runs as the one-launch LDS kernel, those 16 channels go to a compact buffer of their own
-        // (8 channels = 16 bytes per pixel, in the packed-input buffer, free since conv1) and the kernel's window DMA picks
+        // (kTailPs = 4 channels = 8 bytes per pixel, in the packed-input buffer, free since conv1) and the kernel's window DMA picks
         // them up from there: contiguous 16-byte pixels instead of 6 useful bytes scattered into every 160-byte fusion pixel.
         const bool split_tail = P.nb > 0 && pack_fuses(P, 0) && P.fpad - mid == 16;
         EMAVFI_STEP(rec, std::string("warp_fused<") + dtype_name(dtype) + ">", 24.0 * px, px * (8.0 + 4.0 * C + C * e),
-                    split_tail ? launch_warp_fused(frame2, f.flow, f.in16, B, C, H, W, 8, 0, feat_dtype, s)
+                    split_tail ? launch_warp_fused(frame2, f.flow, f.in16, B, C, H, W, kTailPs, 0, feat_dtype, s)
                                : launch_warp_fused(frame2, f.flow, f.fu0, B, C, H, W, P.fps, mid, feat_dtype, s));
         if (!rec.dry && taps && taps[3])
-            EMAVFI_TRY(split_tail ? launch_cl_to_nchw(f.in16, taps[3], B, C, H, W, 8, 0, feat_dtype, s)
+            EMAVFI_TRY(split_tail ? launch_cl_to_nchw(f.in16, taps[3], B, C, H, W, kTailPs, 0, feat_dtype, s)
                                   : launch_cl_to_nchw(f.fu0, taps[3], B, C, H, W, P.fps, mid, feat_dtype, s), "tap warped");
         EMAVFI_STAGE_EVENT(rec, 0);
 
@@ -1407,9 +1414,9 @@ static int mdcn_impl(const float *x, const float *offset_weight, const float *of
         return EMAVFI_OK;
     }
     const int xdt = in_f16 ? (int)EMAVFI_F16 : kd, ydt = out_f16 ? (int)EMAVFI_F16 : kd;
-    if (split) {   // the first pack's input form: channels 0..mid-1 in the fusion pixels, channels mid.. in the compact 8-channel buffer
+    if (split) {   // the first pack's input form: channels 0..mid-1 in the fusion pixels, channels mid.. in the compact tail buffer
         EMAVFI_TRY(launch_nchw_to_cl_sub(x, m.xcl, B, C, 0, mid, H, W, P.fps, xdt, s), "mdcn layout in");
-        EMAVFI_TRY(launch_nchw_to_cl_sub(x, m.tail, B, C, mid, C - mid, H, W, 8, xdt, s), "mdcn layout in (tail)");
+        EMAVFI_TRY(launch_nchw_to_cl_sub(x, m.tail, B, C, mid, C - mid, H, W, kTailPs, xdt, s), "mdcn layout in (tail)");
     } else {
         EMAVFI_TRY(launch_nchw_to_cl(x, m.xcl, B, C, H, W, P.fps, xdt, s), "mdcn layout in");
     }

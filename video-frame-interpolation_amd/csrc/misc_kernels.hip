@@ -834,12 +834,16 @@ __device__ const float g_zero_page[64] = {0};
 
 // T = void: NCHW fp32 planes (emavfi_warp).  T = float / bf16_t: the forward's fused variant, which
 // writes channels [coff, ps) of the channels-last fusion buffer (warped RGB, then zero padding).
-template <int C, typename T>
+// TH = tile rows (32: a 49-row window, 48 KiB, three workgroups per CU).  Round 6 measured TH = 16 (33 KiB, four per CU) for the forward's
+// variant: 66.4 against 64.0 us - the kernel is bound by the LDS-DMA ingest of its window (46 KB per 2 048 pixels = 1.87 x the tile,
+// 169 MB per launch through a path that takes ~ 6.4 TB/s chip-wide) and by ~ 100 issued instructions per pixel, not by occupancy;
+// smaller tiles only raise the halo share (profiles/r06_experiments_that_lost.txt)
+template <int C, typename T, int TH = 32>
 __global__ __launch_bounds__(256) void warp_tiled_kernel(const float *__restrict__ frame2, const float *__restrict__ flow,
                                                          float *__restrict__ out, int B, int H, int W, void *cl_dst, int ps,
                                                          int coff, void *cl_dst16 = nullptr, int ps16 = 0)
 {
-    constexpr int TH = 32, TW = 64, R = 8, WR = TH + 2 * R + 1, WC = 84, PCS = WC / 4;
+    constexpr int TW = 64, R = 8, WR = TH + 2 * R + 1, WC = 84, PCS = WC / 4;
     constexpr int NPIECE = C * WR * PCS, NINST = (NPIECE + 63) / 64;
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
@@ -871,8 +875,9 @@ __global__ __launch_bounds__(256) void warp_tiled_kernel(const float *__restrict
     }
     const float wden = (float)max(W - 1, 1), hden = (float)max(H - 1, 1);
     if constexpr (std::is_same<T, bf16_t>::value || std::is_same<T, half_t>::value) {
-        if (ps == 8 && coff == 0) {
-            // The forward's 16-bit variant (compact 8-channel tail of the fusion input, 16 bytes per pixel): a wave takes whole ROWS of the
+        if ((ps == 8 || ps == 4) && coff == 0) {
+            // The forward's 16-bit variant (compact tail of the fusion input: 8 channels = 16 bytes per pixel, or - round 6 - 4 channels =
+            // 8 bytes, which is what the forward passes: 22 % fewer bytes moved): a wave takes whole ROWS of the
             // tile, lane = column.  A store instruction then writes 1 KiB of consecutive addresses (the 4-pixels-per-thread mapping
             // below wrote 16 bytes of every 64: four partial passes over each line), the corner reads of a wave are consecutive dwords
             // of the window (conflict-free for a smooth flow; lanes four pixels apart were a four-way bank conflict) and the flow loads
@@ -918,18 +923,24 @@ __global__ __launch_bounds__(256) void warp_tiled_kernel(const float *__restrict
                     for (int c = 0; c < C; ++c) v[c] = warp_sample(src_b + (size_t)c * plane, t);
                 }
                 const T z = (T)0.0f;
-                T *o = reinterpret_cast<T *>(cl_dst) + ((size_t)b * plane + (size_t)y * W + x) * 8;
-                *reinterpret_cast<vec8 *>(o) = vec8{(T)v[0], C > 1 ? (T)v[C > 1 ? 1 : 0] : z, C > 2 ? (T)v[C > 2 ? 2 : 0] : z, z, z, z, z, z};
+                T *o = reinterpret_cast<T *>(cl_dst) + ((size_t)b * plane + (size_t)y * W + x) * ps;
+                if (ps == 4) {
+                    typedef __attribute__((ext_vector_type(4))) T vec4;
+                    *reinterpret_cast<vec4 *>(o) = vec4{(T)v[0], C > 1 ? (T)v[C > 1 ? 1 : 0] : z, C > 2 ? (T)v[C > 2 ? 2 : 0] : z, z};
+                } else {
+                    *reinterpret_cast<vec8 *>(o) = vec8{(T)v[0], C > 1 ? (T)v[C > 1 ? 1 : 0] : z, C > 2 ? (T)v[C > 2 ? 2 : 0] : z, z, z, z, z, z};
+                }
             }
             return;
         }
     }
-    // flow for this thread's two items (4 pixels each) while the DMA is in flight
-    f32x4 fx[2], fy[2];
-    int iy[2], ix[2];
-    bool live[2];
+    // flow for this thread's items (4 pixels each; two per thread for the 32-row tile) while the DMA is in flight
+    constexpr int NI = TH * TW / 4 / 256;
+    f32x4 fx[NI], fy[NI];
+    int iy[NI], ix[NI];
+    bool live[NI];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < NI; ++k) {
         const int item = tid + 256 * k;
         iy[k] = ty + item / (TW / 4);
         ix[k] = tx + 4 * (item % (TW / 4));
@@ -941,7 +952,7 @@ __global__ __launch_bounds__(256) void warp_tiled_kernel(const float *__restrict
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA has landed before the barrier, whatever hipcc does with its own wait
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < NI; ++k) {
         if (!live[k]) continue;
         float v[C][4];
 #pragma unroll
