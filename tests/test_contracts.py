@@ -127,7 +127,8 @@ def test_bench_two_ranks_the_way_the_driver_calls_it():
     assert sp["pairs_per_rank"] == [64, 64] and sp["frames_out_per_rank"] == [128, 129] and len(sp["stream_pcie_per_rank"]) == 2
     assert all(v > 0 for v in sp["stream_pcie_per_rank"]) and sp["stream_pcie_aggregate"] > 0
     assert abs(sp["stream_pcie_aggregate"] - 128 / max(sp["seconds_per_rank"])) <= 0.02 * sp["stream_pcie_aggregate"]
-    assert abs(sp["fraction_of_resident_value"] - sp["stream_pcie_aggregate"] / r["value"]) < 1e-3
+    frac = sp["stream_pcie_aggregate"] / r["value"]      # (both printed rounded to two decimals: a relative tolerance)
+    assert abs(sp["fraction_of_resident_value"] - frac) <= 2e-3 * max(1.0, frac)
 
 
 @pytest.mark.gpu
