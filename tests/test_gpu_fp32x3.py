@@ -149,3 +149,31 @@ def test_forward_ragged_sizes_and_other_widths_against_the_oracle(mid, B, H, W):
     for k in ("feat", "flow", "fused_2"):
         err = (taps[k].cpu() - ref[k]).abs().max().item() / max(1.0, ref[k].abs().max().item())
         assert err <= 5e-4, (k, err)
+
+
+def test_forward_is_graph_capturable_and_replays_bit_identically():
+    """The split mode's launch sequence (21 launches, one memset) under torch.cuda.graph: the replay equals the eager result bit for bit,
+    also with new frames written into the captured inputs."""
+    sd = synth.synthetic_state_dict(seed=0)
+    m = make_model(sd)
+    f1, f2 = (t.to(DEV) for t in synth.synthetic_frames(61, 2, 72, 104, "natural"))
+    g1, g2 = (t.to(DEV) for t in synth.synthetic_frames(62, 2, 72, 104, "stress"))
+    side = torch.cuda.Stream()
+    with torch.no_grad():
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                eager = m(f1, f2).clone()
+            eager2 = m(g1, g2).clone()
+        torch.cuda.current_stream().wait_stream(side)
+        a, b = f1.clone(), f2.clone()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            out = m(a, b)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager)
+        a.copy_(g1); b.copy_(g2)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager2)
